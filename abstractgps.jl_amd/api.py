@@ -1,0 +1,671 @@
+"""Host-side mirror of the AbstractGPs.jl API surface for the accelerated path.
+
+Line-for-line Python counterpart of the Julia shim (julia/HipGPs.jl): same names, argument meaning
+and error behaviour as the reference (file:line cited per function, relative to the upstream repo),
+every numeric step a call through the C ABI (include/gpmi355.h) into the HIP library.  Nothing here
+computes Gram matrices, factorisations or solves on the host.
+
+    f   = GP(SqExponentialKernel())                    # src/base_gp.jl:57-64
+    fx  = f(x, 0.01)                                   # src/finite_gp_projection.jl:32
+    lp  = logpdf(fx, y)                                # src/finite_gp_projection.jl:306
+    fp  = posterior(fx, y)                             # src/exact_gpr_posterior.jl:29
+    m, v = mean_and_var(fp(xs))                        # src/exact_gpr_posterior.jl:85
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import threading
+import weakref
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import PosDefException, check, gp_kernel, gp_noise, gp_points, gp_timings
+
+default_sigma2 = 1e-18  # src/finite_gp_projection.jl:17
+
+
+# --------------------------------------------------------------------------------------------
+# Kernels and transforms (KernelFunctions.jl surface used by the path)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ScaleTransform:
+    s: float
+
+
+@dataclass(frozen=True)
+class ARDTransform:
+    v: tuple
+
+    def __init__(self, v):
+        object.__setattr__(self, "v", tuple(float(t) for t in np.asarray(v).ravel()))
+
+
+@dataclass(frozen=True)
+class Kernel:
+    kind: int
+    variance: float = 1.0
+    transform: Union[None, ScaleTransform, ARDTransform] = None
+
+    def __matmul__(self, t):  # k ∘ ScaleTransform(s)  /  k ∘ ARDTransform(v)
+        if not isinstance(t, (ScaleTransform, ARDTransform)):
+            raise TypeError("only ScaleTransform / ARDTransform are accelerated")
+        if self.transform is not None:
+            raise TypeError("nested transforms are not accelerated")
+        return Kernel(self.kind, self.variance, t)
+
+    def __rmul__(self, a):  # α * k  (ScaledKernel)
+        return Kernel(self.kind, self.variance * float(a), self.transform)
+
+    __mul__ = __rmul__
+
+
+def SqExponentialKernel():
+    return Kernel(0)
+
+
+SEKernel = RBFKernel = GaussianKernel = SqExponentialKernel
+
+
+def Matern12Kernel():
+    return Kernel(1)
+
+
+ExponentialKernel = Matern12Kernel
+
+
+def Matern32Kernel():
+    return Kernel(2)
+
+
+def Matern52Kernel():
+    return Kernel(3)
+
+
+def compose(k: Kernel, t) -> Kernel:
+    return k @ t
+
+
+def with_lengthscale(k: Kernel, l) -> Kernel:
+    """with_lengthscale(k, ℓ) ≡ k ∘ ScaleTransform(1/ℓ) (scalar) or k ∘ ARDTransform(1 ./ ℓ)."""
+    l = np.asarray(l, dtype=np.float64)
+    return k @ (ScaleTransform(1.0 / float(l)) if l.ndim == 0 else ARDTransform(1.0 / l))
+
+
+# --------------------------------------------------------------------------------------------
+# Input containers (KernelFunctions ColVecs / RowVecs; src/finite_gp_projection.jl:32-37)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class ColVecs:
+    X: np.ndarray  # D × N, points are columns
+
+    def __len__(self):
+        return self.X.shape[1]
+
+
+@dataclass
+class RowVecs:
+    X: np.ndarray  # N × D, points are rows
+
+    def __len__(self):
+        return self.X.shape[0]
+
+
+def _as_input(x):
+    if isinstance(x, (ColVecs, RowVecs)):
+        return x
+    x = np.asarray(x)
+    if x.ndim == 1:
+        return x
+    if x.ndim == 2:
+        return RowVecs(x)  # a bare matrix is taken as N × D
+    raise TypeError("inputs must be a vector, RowVecs or ColVecs")
+
+
+def _npoints(x) -> int:
+    return len(x)
+
+
+class _Marshal:
+    """Keeps the numpy buffers behind the ctypes structs alive for the duration of a call."""
+
+    def __init__(self, dtype):
+        self.dtype = np.dtype(dtype)
+        self.keep = []
+
+    def arr(self, a, order="C"):
+        a = np.ascontiguousarray(a, dtype=self.dtype) if order == "C" else np.asfortranarray(a, dtype=self.dtype)
+        self.keep.append(a)
+        return a
+
+    def ptr(self, a):
+        return None if a is None else C.c_void_p(a.ctypes.data)
+
+    def points(self, x) -> gp_points:
+        x = _as_input(x)
+        if isinstance(x, ColVecs):  # D×N column-major  == (N, D) C-contiguous
+            X = self.arr(np.asarray(x.X).T)
+            return gp_points(X.ctypes.data, X.shape[0], X.shape[1], 1)
+        if isinstance(x, RowVecs):  # N×D column-major == (D, N) C-contiguous
+            X = self.arr(np.asarray(x.X).T)
+            return gp_points(X.ctypes.data, X.shape[1], X.shape[0], 2)
+        v = self.arr(x)
+        return gp_points(v.ctypes.data, v.shape[0], 1, 0)
+
+    def kernel(self, k: Kernel, d: int) -> gp_kernel:
+        dt = 0 if self.dtype == np.float64 else 1
+        if k.transform is None:
+            return gp_kernel(k.kind, dt, k.variance, 0, None)
+        if isinstance(k.transform, ScaleTransform):
+            s = np.array([k.transform.s], dtype=np.float64)
+        else:
+            s = np.array(k.transform.v, dtype=np.float64)
+            if s.shape[0] != d:
+                raise ValueError(f"DimensionMismatch: ARDTransform has {s.shape[0]} scales, inputs have D={d}")
+        self.keep.append(s)
+        return gp_kernel(k.kind, dt, k.variance, s.shape[0], s.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def noise(self, sigma2, n: int) -> gp_noise:
+        s = np.asarray(sigma2)
+        if s.ndim == 0:
+            return gp_noise(0, float(s), None)
+        if s.ndim == 1:
+            if s.shape[0] != n:
+                raise ValueError("DimensionMismatch: noise vector length != number of points")
+            v = self.arr(s)
+            return gp_noise(1, 0.0, v.ctypes.data)
+        raise NotImplementedError("dense Σy is outside the accelerated path (falls back to stock AbstractGPs in the Julia shim)")
+
+
+def _input_dim(x) -> int:
+    x = _as_input(x)
+    if isinstance(x, ColVecs):
+        return x.X.shape[0]
+    if isinstance(x, RowVecs):
+        return x.X.shape[1]
+    return 1
+
+
+def _input_dtype(x):
+    x = _as_input(x)
+    a = x.X if isinstance(x, (ColVecs, RowVecs)) else x
+    return np.float32 if np.asarray(a).dtype == np.float32 else np.float64
+
+
+# --------------------------------------------------------------------------------------------
+# Engine context (one per device)
+# --------------------------------------------------------------------------------------------
+class Context:
+    """gp_ctx wrapper.  `stream` = a raw hipStream_t (int) to issue main-stream work on, or None."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.gp_ctx_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None))
+        self.handle = h
+        self.device = device
+        self._fin = weakref.finalize(self, self.lib.gp_ctx_destroy, h)
+
+    def set_param(self, name: str, value: int) -> None:
+        check(self.lib.gp_ctx_set_param(self.handle, name.encode(), int(value)))
+
+    def timings(self) -> dict:
+        t = gp_timings()
+        check(self.lib.gp_get_timings(self.handle, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in gp_timings._fields_ if f != "reserved"}
+
+    def close(self):
+        self._fin()
+
+
+_default_ctx = {}
+_ctx_lock = threading.Lock()
+
+
+def default_context(device: int = 0) -> Context:
+    with _ctx_lock:
+        if device not in _default_ctx:
+            _default_ctx[device] = Context(device)
+        return _default_ctx[device]
+
+
+# --------------------------------------------------------------------------------------------
+# GP types
+# --------------------------------------------------------------------------------------------
+Mean = Union[None, float, Callable]
+
+
+def _mean_vector(mean: Mean, x, dtype) -> Optional[np.ndarray]:
+    """mean_vector — src/mean_function.jl:27,40,52-55.  None = ZeroMean (stays lazy)."""
+    if mean is None:
+        return None
+    n = _npoints(x)
+    if isinstance(mean, (int, float, np.floating)):
+        return np.full(n, mean, dtype=dtype)
+    x = _as_input(x)
+    if isinstance(x, ColVecs):
+        return np.asarray([mean(c) for c in x.X.T], dtype=dtype)
+    if isinstance(x, RowVecs):
+        return np.asarray([mean(r) for r in x.X], dtype=dtype)
+    return np.asarray([mean(v) for v in x], dtype=dtype)
+
+
+class AbstractGP:
+    def __call__(self, x, sigma2=default_sigma2) -> "FiniteGP":  # src/finite_gp_projection.jl:32
+        return FiniteGP(self, _as_input(x), sigma2)
+
+    def mean(self, x=None):  # src/abstract_gp.jl:66-87
+        if x is None:
+            raise TypeError("`mean(f)` for an AbstractGP requires inputs: use `mean(f(x))` or `mean(f, x)`")
+        raise NotImplementedError
+
+
+@dataclass(eq=False)
+class GP(AbstractGP):
+    """HipGP: GP(mean, kernel) whose FiniteGP methods run on the MI355X (src/base_gp.jl:57-64)."""
+
+    kernel: Kernel
+    mean_fn: Mean = None
+    ctx: Optional[Context] = None
+
+    def __init__(self, *args, ctx: Optional[Context] = None):
+        if len(args) == 1:
+            self.mean_fn, self.kernel = None, args[0]  # GP(kernel) -> ZeroMean  base_gp.jl:64
+        elif len(args) == 2:
+            self.mean_fn, self.kernel = args  # GP(c::Real, k) / GP(f, k)  base_gp.jl:62-63
+        else:
+            raise TypeError("GP(kernel) or GP(mean, kernel)")
+        if not isinstance(self.kernel, Kernel):
+            raise TypeError("kernel must be one of the accelerated kernels")
+        self.ctx = ctx
+
+    def context(self) -> Context:
+        return self.ctx or default_context()
+
+    # internal AbstractGP API (src/base_gp.jl:68-74)
+    def mean(self, x=None):
+        if x is None:
+            return super().mean()
+        m = _mean_vector(self.mean_fn, x, _input_dtype(x))
+        return np.zeros(_npoints(x), dtype=_input_dtype(x)) if m is None else m
+
+    def cov(self, x, z=None):
+        return kernelmatrix(self.kernel, x, z, ctx=self.context())
+
+    def var(self, x):
+        return np.full(_npoints(x), self.kernel.variance, dtype=_input_dtype(x))  # kernelmatrix_diag
+
+    def mean_and_var(self, x):
+        return self.mean(x), self.var(x)
+
+
+@dataclass(eq=False)
+class FiniteGP:
+    """src/finite_gp_projection.jl:7-21."""
+
+    f: AbstractGP
+    x: object
+    sigma2: object = default_sigma2
+
+    def __len__(self):
+        return _npoints(self.x)
+
+    def noise_vector(self):
+        s = np.asarray(self.sigma2)
+        return np.full(len(self), float(s)) if s.ndim == 0 else s
+
+
+def kernelmatrix(k: Kernel, x, z=None, ctx: Optional[Context] = None) -> np.ndarray:
+    """KernelFunctions.kernelmatrix(k, x[, z]) on the device (src/base_gp.jl:70,74)."""
+    ctx = ctx or default_context()
+    dt = _input_dtype(x)
+    m = _Marshal(dt)
+    px = m.points(x)
+    kk = m.kernel(k, px.d)
+    n = px.n
+    if z is None:
+        out = np.empty((n, n), dtype=dt, order="F")
+        check(ctx.lib.gp_kernelmatrix(ctx.handle, C.byref(kk), C.byref(px), None, out.ctypes.data))
+    else:
+        pz = m.points(z)
+        out = np.empty((n, pz.n), dtype=dt, order="F")
+        check(ctx.lib.gp_kernelmatrix(ctx.handle, C.byref(kk), C.byref(px), C.byref(pz), out.ctypes.data))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# FiniteGP API on GP priors: logpdf / posterior
+# --------------------------------------------------------------------------------------------
+def _check_y(fx: FiniteGP, y):
+    y = np.asarray(y)
+    if y.shape[0] != len(fx):
+        raise ValueError(f"DimensionMismatch: length(fx) = {len(fx)} but y has {y.shape[0]} rows")
+    return y
+
+
+def logpdf(fx: FiniteGP, y):
+    """logpdf(f::FiniteGP, Y) — src/finite_gp_projection.jl:306-311.  Vector -> scalar of the input
+    eltype; matrix (N×S) -> length-S vector."""
+    y = _check_y(fx, y)
+    f = fx.f
+    if isinstance(f, PosteriorGP):
+        return _logpdf_posterior(fx, y)
+    if not isinstance(f, GP):
+        raise TypeError("logpdf: unsupported GP type")
+    ctx = f.context()
+    dt = np.result_type(_input_dtype(fx.x), np.float32 if y.dtype == np.float32 else np.float64).type
+    m = _Marshal(dt)
+    px = m.points(fx.x)
+    kk = m.kernel(f.kernel, px.d)
+    nz = m.noise(fx.sigma2, px.n)
+    mean = _mean_vector(f.mean_fn, fx.x, dt)
+    mean = None if mean is None else m.arr(mean)
+    Y = m.arr(y if y.ndim == 2 else y[:, None], order="F")
+    out = np.empty(Y.shape[1], dtype=dt)
+    check(ctx.lib.gp_logpdf(ctx.handle, C.byref(kk), C.byref(px), C.byref(nz), m.ptr(mean), Y.ctypes.data,
+                            Y.shape[0], Y.shape[1], out.ctypes.data))
+    return out[0] if y.ndim == 1 else out
+
+
+def loglikelihood(fx: FiniteGP, Y):  # src/finite_gp_projection.jl:304
+    return np.sum(logpdf(fx, Y))
+
+
+class _Factor:
+    """Device-resident Cholesky factor handle (PosteriorGP.data.C)."""
+
+    def __init__(self, ctx: Context, handle: C.c_void_p, n: int, dtype):
+        self.ctx, self.handle, self.n, self.dtype = ctx, handle, n, dtype
+        self._fin = weakref.finalize(self, ctx.lib.gp_posterior_free, handle)
+
+    @property
+    def U(self) -> np.ndarray:
+        """C.U on the host (parity/debug; N×N copy)."""
+        out = np.empty((self.n, self.n), dtype=self.dtype, order="F")
+        check(self.ctx.lib.gp_posterior_get_factor(self.handle, out.ctypes.data))
+        return out
+
+    def free(self):
+        self._fin()
+
+
+@dataclass
+class _PostData:
+    alpha: np.ndarray  # α
+    C: _Factor
+    x: object
+    delta: np.ndarray  # δ
+
+
+class PosteriorGP(AbstractGP):
+    """src/exact_gpr_posterior.jl:1-4, with data = (α, C, x, δ) (:34); C lives on the device."""
+
+    def __init__(self, prior: GP, data: _PostData, logpdf_value):
+        self.prior, self.data, self.logpdf_value = prior, data, logpdf_value
+
+    def _predict(self, x, what):
+        ctx = self.data.C.ctx
+        dt = self.data.C.dtype
+        m = _Marshal(dt)
+        px = m.points(x)
+        ns = px.n
+        pm = _mean_vector(self.prior.mean_fn, x, dt)
+        pm = None if pm is None else m.arr(pm)
+        mean = np.empty(ns, dtype=dt) if what & 1 else None
+        var = np.empty(ns, dtype=dt) if what & 2 else None
+        cov = np.empty((ns, ns), dtype=dt, order="F") if what & 4 else None
+        check(ctx.lib.gp_posterior_predict(self.data.C.handle, C.byref(px), m.ptr(pm), what, m.ptr(mean), m.ptr(var),
+                                           m.ptr(cov)))
+        return mean, var, cov
+
+    def mean(self, x=None):  # :60-62
+        if x is None:
+            return super().mean()
+        return self._predict(x, 1)[0]
+
+    def var(self, x):  # :68-70
+        return self._predict(x, 2)[1]
+
+    def cov(self, x, z=None):  # :64-66, :72-76
+        if z is None:
+            return self._predict(x, 4)[2]
+        # cov(f, x, z) = block of the joint covariance over [x; z]
+        xa, za = _stack_inputs(x, z)
+        nx = _npoints(x)
+        return np.asfortranarray(self._predict(xa, 4)[2][:nx, nx:]) if za else None
+
+    def mean_and_var(self, x):  # :85-90
+        m, v, _ = self._predict(x, 3)
+        return m, v
+
+    def mean_and_cov(self, x):  # :78-83
+        m, _, c = self._predict(x, 5)
+        return m, c
+
+
+def _stack_inputs(x, z):
+    x, z = _as_input(x), _as_input(z)
+    if isinstance(x, ColVecs):
+        return ColVecs(np.concatenate([x.X, (z.X if isinstance(z, ColVecs) else z.X.T)], axis=1)), True
+    if isinstance(x, RowVecs):
+        return RowVecs(np.concatenate([x.X, (z.X if isinstance(z, RowVecs) else z.X.T)], axis=0)), True
+    return np.concatenate([x, z]), True
+
+
+def _posterior_exact(fx: FiniteGP, y) -> PosteriorGP:
+    """posterior(fx::FiniteGP, y) — src/exact_gpr_posterior.jl:29-35.  One device call: Gram, Cholesky,
+    α and logpdf(fx, y) (kept as .logpdf_value) from a single factorisation."""
+    y = _check_y(fx, y)
+    if y.ndim != 1:
+        raise TypeError("posterior expects a vector of observations")
+    f = fx.f
+    if not isinstance(f, GP):
+        raise NotImplementedError("sequential conditioning (posterior of a PosteriorGP) is not accelerated yet")
+    ctx = f.context()
+    dt = np.result_type(_input_dtype(fx.x), np.float32 if y.dtype == np.float32 else np.float64).type
+    m = _Marshal(dt)
+    px = m.points(fx.x)
+    kk = m.kernel(f.kernel, px.d)
+    nz = m.noise(fx.sigma2, px.n)
+    mean = _mean_vector(f.mean_fn, fx.x, dt)
+    yv = m.arr(y)
+    delta = yv - mean if mean is not None else yv.copy()  # δ = y - m  (:32)
+    mean = None if mean is None else m.arr(mean)
+    alpha = np.empty(px.n, dtype=dt)
+    lp = np.empty(1, dtype=dt)
+    h = C.c_void_p()
+    check(ctx.lib.gp_posterior_fit(ctx.handle, C.byref(kk), C.byref(px), C.byref(nz), m.ptr(mean), yv.ctypes.data,
+                                   C.byref(h), alpha.ctypes.data, lp.ctypes.data))
+    return PosteriorGP(f, _PostData(alpha, _Factor(ctx, h, px.n, dt), fx.x, delta), lp[0])
+
+
+def _logpdf_posterior(fx: FiniteGP, y):
+    """logpdf(post(x*, Σy*), y*): predictive mean/cov from the device, small N* Cholesky on the host
+    (N* is a handful of held-out points in the reference's usage; README.md:46-54)."""
+    if y.ndim != 1:
+        raise NotImplementedError
+    m, Cm = fx.f.mean_and_cov(fx.x)
+    Cm = np.array(Cm, dtype=np.float64)
+    Cm[np.diag_indices_from(Cm)] += fx.noise_vector()
+    try:
+        L = np.linalg.cholesky(Cm)
+    except np.linalg.LinAlgError:
+        raise PosDefException(-1)
+    z = np.linalg.solve(L, np.asarray(y, dtype=np.float64) - m)
+    return -0.5 * (len(y) * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(L))) + z @ z)
+
+
+# Distribution-style accessors on FiniteGP (src/finite_gp_projection.jl:53,96,114,133,154,203)
+def mean(fx_or_f, x=None):
+    if isinstance(fx_or_f, FiniteGP):
+        return fx_or_f.f.mean(fx_or_f.x)
+    return fx_or_f.mean(x)
+
+
+def var(fx_or_f, x=None):
+    if isinstance(fx_or_f, FiniteGP):
+        return fx_or_f.f.var(fx_or_f.x) + fx_or_f.noise_vector()
+    return fx_or_f.var(x)
+
+
+def cov(fx_or_f, x=None, z=None):
+    if isinstance(fx_or_f, FiniteGP):
+        fx = fx_or_f
+        if isinstance(x, FiniteGP):  # cov(fx, gx)  :177-180
+            assert fx.f is x.f
+            return fx.f.cov(fx.x, x.x)
+        Cm = np.array(fx.f.cov(fx.x))
+        Cm[np.diag_indices_from(Cm)] += fx.noise_vector()
+        return Cm
+    return fx_or_f.cov(x, z)
+
+
+def mean_and_var(fx_or_f, x=None):
+    if isinstance(fx_or_f, FiniteGP):
+        m, v = fx_or_f.f.mean_and_var(fx_or_f.x)
+        return m, v + fx_or_f.noise_vector()
+    return fx_or_f.mean_and_var(x)
+
+
+def mean_and_cov(fx_or_f, x=None):
+    if isinstance(fx_or_f, FiniteGP):
+        return mean(fx_or_f), cov(fx_or_f)
+    return fx_or_f.mean_and_cov(x)
+
+
+def marginals(fx: FiniteGP):
+    """marginals(fx) = Normal.(m, sqrt.(c)) -> (mean, std) arrays (src/finite_gp_projection.jl:203-206)."""
+    m, c = mean_and_var(fx)
+    return m, np.sqrt(c)
+
+
+# --------------------------------------------------------------------------------------------
+# Sparse approximations: VFE / DTC (src/sparse_approximations.jl)
+# --------------------------------------------------------------------------------------------
+@dataclass(eq=False)
+class VFE:
+    """VFE(fz::FiniteGP) — src/sparse_approximations.jl:12-14."""
+
+    fz: FiniteGP
+
+
+@dataclass(eq=False)
+class DTC:
+    """DTC(fz::FiniteGP) — src/sparse_approximations.jl:21-23."""
+
+    fz: FiniteGP
+
+
+class ExactInference:  # src/exact_gpr_posterior.jl:6-12
+    pass
+
+
+class _VfeState:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+        self._fin = weakref.finalize(self, ctx.lib.gp_vfe_free, handle)
+
+
+def _vfe_call(approx, fx: FiniteGP, y, want_post: bool):
+    y = _check_y(fx, y)
+    if y.ndim != 1:
+        raise TypeError("expected a vector of observations")
+    f = fx.f
+    if approx.fz.f is not f:  # @assert vfe.fz.f === fx.f  (:59, :249, :283)
+        raise AssertionError("vfe.fz.f === fx.f")
+    if not isinstance(f, GP):
+        raise TypeError("VFE/DTC: unsupported prior type")
+    ctx = f.context()
+    dt = np.result_type(_input_dtype(fx.x), np.float32 if y.dtype == np.float32 else np.float64).type
+    m = _Marshal(dt)
+    px, pz = m.points(fx.x), m.points(approx.fz.x)
+    kk = m.kernel(f.kernel, px.d)
+    nz = m.noise(fx.sigma2, px.n)
+    jit = np.asarray(approx.fz.sigma2)
+    if jit.ndim != 0:
+        raise NotImplementedError("inducing-point noise must be a scalar jitter")
+    mean = _mean_vector(f.mean_fn, fx.x, dt)
+    mean = None if mean is None else m.arr(mean)
+    yv = m.arr(y)
+    obj = np.empty(1, dtype=dt)
+    h = C.c_void_p()
+    check(ctx.lib.gp_vfe_fit(ctx.handle, C.byref(kk), C.byref(px), C.byref(pz), C.byref(nz), float(jit), m.ptr(mean),
+                             yv.ctypes.data, 0 if isinstance(approx, VFE) else 1,
+                             C.byref(h) if want_post else None, obj.ctypes.data))
+    return (h if want_post else None), obj[0], ctx, dt, pz.n
+
+
+class ApproxPosteriorGP(AbstractGP):
+    """src/sparse_approximations.jl:25-29; the cache (:73) lives on the device."""
+
+    def __init__(self, approx, prior: GP, state: _VfeState, dtype, m: int, objective):
+        self.approx, self.prior, self._state, self._dtype, self._m = approx, prior, state, dtype, m
+        self.objective = objective
+
+    @property
+    def data(self):
+        a = np.empty(self._m, dtype=self._dtype)
+        me = np.empty(self._m, dtype=self._dtype)
+        check(self._state.ctx.lib.gp_vfe_get(self._state.handle, a.ctypes.data, me.ctypes.data))
+        return {"alpha": a, "m_eps": me}
+
+    def _predict(self, x, what):
+        st = self._state
+        mm = _Marshal(self._dtype)
+        px = mm.points(x)
+        pm = _mean_vector(self.prior.mean_fn, x, self._dtype)
+        pm = None if pm is None else mm.arr(pm)
+        mean = np.empty(px.n, dtype=self._dtype) if what & 1 else None
+        var = np.empty(px.n, dtype=self._dtype) if what & 2 else None
+        check(st.ctx.lib.gp_vfe_predict(st.handle, C.byref(px), mm.ptr(pm), what, mm.ptr(mean), mm.ptr(var)))
+        return mean, var
+
+    def mean(self, x=None):  # :183-185
+        if x is None:
+            return super().mean()
+        return self._predict(x, 1)[0]
+
+    def var(self, x):  # :192-195
+        return self._predict(x, 2)[1]
+
+    def mean_and_var(self, x):  # :212-217
+        return self._predict(x, 3)
+
+
+def inducing_points(f: ApproxPosteriorGP):  # :219
+    return f.approx.fz.x
+
+
+def posterior(*args):
+    """posterior(fx, y)                      — src/exact_gpr_posterior.jl:29-35
+    posterior(VFE(fz)|DTC(fz), fx, y)     — src/sparse_approximations.jl:58-75
+    posterior(ExactInference(), fx, y)    — src/exact_gpr_posterior.jl:8"""
+    if len(args) == 2:
+        return _posterior_exact(*args)
+    if len(args) == 3:
+        a, fx, y = args
+        if isinstance(a, ExactInference):
+            return _posterior_exact(fx, y)
+        if isinstance(a, (VFE, DTC)):
+            h, obj, ctx, dt, m = _vfe_call(a, fx, y, True)
+            return ApproxPosteriorGP(a, fx.f, _VfeState(ctx, h), dt, m, obj)
+    raise TypeError("posterior(fx, y) or posterior(approx, fx, y)")
+
+
+def approx_log_evidence(a, fx: FiniteGP, y):
+    """src/sparse_approximations.jl:248-252 (VFE), :282-286 (DTC); src/exact_gpr_posterior.jl:10-12."""
+    if isinstance(a, ExactInference):
+        return logpdf(fx, y)
+    if not isinstance(a, (VFE, DTC)):
+        raise TypeError("approx_log_evidence: unsupported approximation")
+    return _vfe_call(a, fx, y, False)[1]
+
+
+def elbo(a, fx: FiniteGP, y):
+    """elbo(vfe, fx, y) = approx_log_evidence(vfe, fx, y) (:254); elbo(::DTC) is deprecated upstream."""
+    if not isinstance(a, VFE):
+        raise TypeError("elbo is defined for VFE")
+    return approx_log_evidence(a, fx, y)

@@ -1,0 +1,1101 @@
+// gpmi355.hip — host engine + C ABI (include/gpmi355.h) of libgpmi355.so.
+//
+// Host orchestration of the kernels in kernels.hpp:
+//   assemble (kmat)  ->  right-looking blocked Cholesky with a recursive panel and look-ahead
+//   (potf2_64 / trsm_64 / MFMA gemm_nt_sub)  ->  logdet + forward solve (carried as extra RHS rows
+//   of the factorisation)  ->  backward substitution  ->  logpdf scalar and α.
+// Mirrors, on the device, reference src/finite_gp_projection.jl:306-311 and
+// src/exact_gpr_posterior.jl:29-35, 60-90 (see include/gpmi355.h for the per-entry citations).
+#include "kernels.hpp"
+#include "../../include/gpmi355.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace gpmi;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int32_t set_hip_err(hipError_t e, const char* what, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), what, line);
+    g_err = buf;
+    return -1000 - (int)e;
+}
+static int32_t set_arg_err(int i, const char* msg) {
+    g_err = std::string("invalid argument ") + std::to_string(i) + ": " + msg;
+    return -i;
+}
+#define HIPCHK(expr)                                                   \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return set_hip_err(e_, #expr, __LINE__); \
+    } while (0)
+#define RC(expr)                \
+    do {                        \
+        int32_t rc_ = (expr);   \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+static const double LOG2PI = 1.8378770664093454835606594728112;
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct FreeBlock {
+    void* p;
+    size_t bytes;
+};
+
+struct gp_ctx {
+    int device = 0;
+    hipStream_t sm = nullptr;  // main stream (trailing updates, assembly, solves)
+    hipStream_t sp = nullptr;  // panel stream (look-ahead)
+    bool own_sm = false;
+    std::mutex mu;
+    long nb = 2048;        // outer panel width
+    int lookahead = 1;
+    int time_kernels = 0;
+    int gemm_variant = 0;
+    long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
+    gp_timings tm{};
+    std::vector<FreeBlock> pool;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct GemmRec {
+        hipEvent_t a, b;
+        double flops;
+    };
+    std::vector<GemmRec> gemm_recs;
+    hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* info_dev = nullptr;
+    double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
+    long scal_cap = 0;
+    int refs = 1;
+    bool dead = false;
+};
+
+static std::mutex g_reg_mu;
+static std::set<void*> g_live;
+static void reg_add(void* p) {
+    std::lock_guard<std::mutex> l(g_reg_mu);
+    g_live.insert(p);
+}
+static bool reg_take(void* p) {
+    std::lock_guard<std::mutex> l(g_reg_mu);
+    return g_live.erase(p) > 0;
+}
+static bool reg_has(void* p) {
+    std::lock_guard<std::mutex> l(g_reg_mu);
+    return g_live.count(p) > 0;
+}
+
+static int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out) {
+    size_t best = (size_t)-1;
+    int bi = -1;
+    for (size_t i = 0; i < c->pool.size(); ++i)
+        if (c->pool[i].bytes >= bytes && c->pool[i].bytes < best && c->pool[i].bytes <= bytes + bytes / 4 + (1 << 20)) {
+            best = c->pool[i].bytes;
+            bi = (int)i;
+        }
+    if (bi >= 0) {
+        *out = c->pool[bi].p;
+        c->pool.erase(c->pool.begin() + bi);
+        return 0;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {  // drop the cache and retry once
+        for (auto& b : c->pool) (void)hipFree(b.p);
+        c->pool.clear();
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return set_hip_err(e, "hipMalloc", __LINE__);
+    return 0;
+}
+static size_t block_bytes(size_t want) { return want; }
+static void ctx_release(gp_ctx* c, void* p, size_t bytes) {
+    if (!p) return;
+    if (c->dead) {
+        (void)hipFree(p);
+        return;
+    }
+    c->pool.push_back({p, bytes});
+    while (c->pool.size() > 6) {  // bound the cache
+        (void)hipFree(c->pool.front().p);
+        c->pool.erase(c->pool.begin());
+    }
+}
+static void ctx_unref(gp_ctx* c) {
+    bool destroy = false;
+    {
+        std::lock_guard<std::mutex> l(c->mu);
+        destroy = (--c->refs == 0);
+    }
+    if (!destroy) return;
+    (void)hipSetDevice(c->device);
+    for (auto& b : c->pool) (void)hipFree(b.p);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : c->ev_phase)
+        if (e) (void)hipEventDestroy(e);
+    if (c->info_dev) (void)hipFree(c->info_dev);
+    if (c->scal_dev) (void)hipFree(c->scal_dev);
+    if (c->sp) (void)hipStreamDestroy(c->sp);
+    if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
+    delete c;
+}
+static int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing) {
+    // timing events are separate objects (created on demand, pooled)
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    (void)timing;
+    *out = c->ev_pool[c->ev_used++];
+    return 0;
+}
+static int32_t ctx_scal(gp_ctx* c, long n) {
+    if (c->scal_cap >= n) return 0;
+    if (c->scal_dev) (void)hipFree(c->scal_dev);
+    c->scal_cap = round_up(n, 1024);
+    HIPCHK(hipMalloc((void**)&c->scal_dev, sizeof(double) * c->scal_cap));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+static double lower_count(long M, long N, long row0, long col0) {
+    // number of (r, c) in [row0,row0+M) × [col0,col0+N) with c <= r
+    double cnt = 0;
+    for (long r = row0; r < row0 + M; ++r) {
+        long hi = std::min(col0 + N - 1, r);
+        if (hi >= col0) cnt += (double)(hi - col0 + 1);
+    }
+    return cnt;
+}
+
+template <typename T>
+static int32_t launch_gemm(gp_ctx* c, hipStream_t s, T* C, long ldc, const T* A, long lda, const T* B, long ldb,
+                           long M, long N, long K, GridMap g) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    gp_ctx::GemmRec rec{};
+    const bool timed = c->time_kernels != 0;
+    if (timed) {
+        RC(ctx_event(c, &rec.a, true));
+        RC(ctx_event(c, &rec.b, true));
+        rec.flops = 2.0 * (double)K * ((g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0)
+                                                                          : (double)M * (double)N);
+        HIPCHK(hipEventRecord(rec.a, s));
+    }
+    if (c->gemm_variant == 0) {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+        hipLaunchKernelGGL(gemm_nt_sub_kernel<T>, grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                           (int)K, g);
+    } else {
+        dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16));
+        hipLaunchKernelGGL(gemm_nt_sub_ref_kernel<T>, grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                           (int)K, g);
+    }
+    HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(rec.b, s));
+        c->gemm_recs.push_back(rec);
+    }
+    return 0;
+}
+
+static GridMap plain_map(int lower, long row0, long col0) {
+    GridMap g;
+    g.lower = lower;
+    g.P = 1; g.p = 0; g.Q = 1; g.q = 0;
+    g.nb = 128;
+    g.row0 = row0;
+    g.col0 = col0;
+    return g;
+}
+
+static long split_half(long n) {  // largest multiple of 64 that is <= n/2 (>= 64)
+    long h = (n / 128) * 64;
+    return h < 64 ? 64 : h;
+}
+
+// Factor columns [j0, j0+n) of the row-major matrix A (n multiple of 64) including all rows below
+// (rows [j0, mtot)).  Recursive: left half, MFMA update of the right half, right half.
+template <typename T>
+static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long n, long mtot, int* info_dev,
+                         long gcol0, long n_valid, double* logdet_dev) {
+    if (n <= 64) {
+        T* d = A + j0 * lda + j0;
+        hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(64), 0, s, d, lda, info_dev, (int)(gcol0 + j0),
+                           (int)n_valid, logdet_dev);
+        HIPCHK(hipGetLastError());
+        const long mrows = mtot - j0 - 64;
+        if (mrows > 0) {
+            hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((mrows + 255) / 256)), dim3(256), 0, s,
+                               A + (j0 + 64) * lda + j0, lda, (int)mrows, d, lda);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
+    const long h = split_half(n);
+    RC(potrf_rec<T>(c, s, A, lda, j0, h, mtot, info_dev, gcol0, n_valid, logdet_dev));
+    RC(launch_gemm<T>(c, s, A + (j0 + h) * lda + (j0 + h), lda, A + (j0 + h) * lda + j0, lda,
+                      A + (j0 + h) * lda + j0, lda, mtot - j0 - h, n - h, h, plain_map(1, j0 + h, j0 + h)));
+    RC(potrf_rec<T>(c, s, A, lda, j0 + h, n - h, mtot, info_dev, gcol0, n_valid, logdet_dev));
+    return 0;
+}
+
+// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n multiple of 64, M multiple of 64).
+template <typename T>
+static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
+    if (n <= 64) {
+        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, X, ldx, (int)M, L,
+                           ldl);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const long h = split_half(n);
+    RC(trsm_rec<T>(c, s, X, ldx, M, L, ldl, h));
+    RC(launch_gemm<T>(c, s, X + h, ldx, X, ldx, L + h * ldl, ldl, M, n - h, h, plain_map(0, 0, 0)));
+    RC(trsm_rec<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h));
+    return 0;
+}
+
+// Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows).  Right-looking
+// over panels of width nb with a one-panel look-ahead: the next panel is factored on the panel
+// stream while the rest of the trailing update still runs on the main stream.
+template <typename T>
+static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
+                          double* logdet_dev) {
+    long nb = c->nb;
+    if (nb <= 0 || nb >= np) {
+        return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    }
+    nb = round_up(nb, 128);
+    const bool la = c->lookahead != 0;
+    hipStream_t sP = la ? c->sp : c->sm;
+    hipEvent_t ev_u1 = nullptr, ev_panel = nullptr;
+    if (la) {
+        // panel stream starts after everything queued so far on the main stream (assembly)
+        RC(ctx_event(c, &ev_u1, false));
+        HIPCHK(hipEventRecord(ev_u1, c->sm));
+        HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
+    }
+    for (long k = 0; k < np; k += nb) {
+        const long nbk = std::min(nb, np - k);
+        RC(potrf_rec<T>(c, sP, A, lda, k, nbk, mtot, info_dev, 0, n_valid, logdet_dev));
+        const long k1 = k + nbk;
+        if (k1 >= np && mtot <= np) break;
+        if (la) {
+            RC(ctx_event(c, &ev_panel, false));
+            HIPCHK(hipEventRecord(ev_panel, sP));
+            HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
+        }
+        if (k1 >= np) break;  // RHS rows were already solved inside potrf_rec
+        const long nb1 = std::min(nb, np - k1);
+        // U1: next panel's columns, all rows below
+        RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, mtot - k1,
+                          nb1, nbk, plain_map(1, k1, k1)));
+        if (la) {
+            RC(ctx_event(c, &ev_u1, false));
+            HIPCHK(hipEventRecord(ev_u1, c->sm));
+            HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
+        }
+        // U2: the rest of the trailing matrix
+        const long k2 = k1 + nb1;
+        if (k2 < np)
+            RC(launch_gemm<T>(c, c->sm, A + k2 * lda + k2, lda, A + k2 * lda + k, lda, A + k2 * lda + k, lda,
+                              mtot - k2, np - k2, nbk, plain_map(1, k2, k2)));
+    }
+    if (la) {
+        RC(ctx_event(c, &ev_panel, false));
+        HIPCHK(hipEventRecord(ev_panel, sP));
+        HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
+    }
+    return 0;
+}
+
+// Vector solves with the resident factor: R rows hold nrhs right-hand sides of length np.
+template <typename T>
+static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* R, long ldr, int nrhs, bool fwd) {
+    const int NBV = 1024;
+    const size_t smem = sizeof(T) * (NBV + 64 * 65);
+    const long nblk = (np + NBV - 1) / NBV;
+    for (long bb = 0; bb < nblk; ++bb) {
+        const long b = fwd ? bb : (nblk - 1 - bb);
+        const long b0 = b * NBV;
+        const int nbv = (int)std::min<long>(NBV, np - b0);  // multiple of 64 (np is a multiple of 128)
+        if (fwd) {
+            hipLaunchKernelGGL((trsv_diag_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr,
+                               nrhs);
+            HIPCHK(hipGetLastError());
+            const long lo = b0 + nbv;
+            if (lo < np) {
+                hipLaunchKernelGGL(trsv_upd_fwd_kernel<T>, dim3((unsigned)((np - lo + 3) / 4)), dim3(256), 0, s, L,
+                                   ldl, b0, nbv, lo, np, R, ldr, nrhs);
+                HIPCHK(hipGetLastError());
+            }
+        } else {
+            hipLaunchKernelGGL((trsv_diag_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr,
+                               nrhs);
+            HIPCHK(hipGetLastError());
+            if (b0 > 0) {
+                hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((b0 + 255) / 256), (unsigned)(nbv / 64)),
+                                   dim3(256), 0, s, L, ldl, b0, nbv, R, ldr, nrhs);
+                HIPCHK(hipGetLastError());
+            }
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side input marshalling
+// ------------------------------------------------------------------------------------------------
+template <typename T> static T pt_get(const gp_points* x, long i, int dd) {
+    const T* p = (const T*)x->data;
+    if (x->layout == 0) return p[i];
+    if (x->layout == 1) return p[(long)dd + i * x->d];
+    return p[i + (long)dd * x->n];
+}
+static int32_t check_kernel(const gp_kernel* k, int d, int argi) {
+    if (!k) return set_arg_err(argi, "kernel is NULL");
+    if (k->kind < 0 || k->kind > 3) return set_arg_err(argi, "kernel kind must be 0..3");
+    if (k->dtype != 0 && k->dtype != 1) return set_arg_err(argi, "dtype must be 0 (f64) or 1 (f32)");
+    if (!(k->variance > 0)) return set_arg_err(argi, "variance must be > 0");
+    if (k->nscale != 0 && k->nscale != 1 && k->nscale != d) return set_arg_err(argi, "nscale must be 0, 1 or D");
+    if (k->nscale != 0 && !k->scale) return set_arg_err(argi, "scale is NULL");
+    return 0;
+}
+static int32_t check_points(const gp_points* x, int argi) {
+    if (!x || !x->data) return set_arg_err(argi, "points NULL");
+    if (x->n <= 0) return set_arg_err(argi, "n must be > 0");
+    if (x->d <= 0) return set_arg_err(argi, "d must be > 0");
+    if (x->layout < 0 || x->layout > 2) return set_arg_err(argi, "layout must be 0..2");
+    if (x->layout == 0 && x->d != 1) return set_arg_err(argi, "layout 0 requires d == 1");
+    return 0;
+}
+// scaled, dimension-major, zero-padded copy [d][ldx]
+template <typename T>
+static void scale_points(const gp_kernel* k, const gp_points* x, long ldx, std::vector<T>& out) {
+    const int d = x->d;
+    out.assign((size_t)d * ldx, T(0));
+    for (int dd = 0; dd < d; ++dd) {
+        T s = T(1);
+        if (k->nscale == 1) s = (T)k->scale[0];
+        else if (k->nscale > 1) s = (T)k->scale[dd];
+        T* o = out.data() + (size_t)dd * ldx;
+        for (long i = 0; i < x->n; ++i) o[i] = s * pt_get<T>(x, i, dd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// posterior handle
+// ------------------------------------------------------------------------------------------------
+struct gp_post {
+    gp_ctx* ctx;
+    int dtype;
+    long n, np, ld, mtot;
+    int d;
+    int kind;
+    double variance;
+    int nscale;
+    std::vector<double> scale;
+    void* A;
+    size_t A_bytes;  // factor (+ RHS rows)
+    void* xs;
+    size_t xs_bytes;  // scaled train inputs [d][np]
+    void* alpha;
+    size_t alpha_bytes;  // [np]
+};
+
+template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k, const T* xs_dev, long ldx, int d,
+                                                  const T* noise_dev, long n, long np, T* A, long ld) {
+    GridMap g = plain_map(1, 0, 0);
+    dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
+    hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, A, ld, xs_dev, ldx, xs_dev, ldx, d, k->kind,
+                       (T)k->variance, noise_dev, n, n, 1, g, (const T*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+struct FitOut {
+    std::vector<double> logpdf;  // per RHS column
+    int32_t info = 0;
+};
+
+// Shared by gp_logpdf and gp_posterior_fit.  Y: n×ncols column-major host.  If post != NULL the factor
+// is kept and α is computed for column 0.
+template <typename T>
+static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise,
+                        const void* mean_or_null, const void* Yv, long ldy, int ncols, FitOut& out, gp_post* post,
+                        void* alpha_out) {
+    const long n = x->n, np = round_up(n, 128);
+    const int d = x->d;
+    const long R = round_up(std::max(ncols, 1), 128);
+    const long mtot = np + R;
+    const long ld = np + c->ldpad;
+    const T* Y = (const T*)Yv;
+    const T* mean = (const T*)mean_or_null;
+
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    for (auto& e : c->ev_phase)
+        if (!e) HIPCHK(hipEventCreate(&e));
+    if (!c->info_dev) HIPCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    RC(ctx_scal(c, 8 + R));
+
+    // ---- host marshalling
+    std::vector<T> xs_h;
+    scale_points<T>(k, x, np, xs_h);
+    std::vector<T> noise_h((size_t)np, T(0));
+    for (long i = 0; i < n; ++i) noise_h[i] = noise->kind == 0 ? (T)noise->s : ((const T*)noise->diag)[i];
+    std::vector<T> rhs_h((size_t)ncols * np, T(0));  // rows: δ_sᵀ = (Y[:,s] - m)ᵀ, zero padded
+    for (int s = 0; s < ncols; ++s)
+        for (long i = 0; i < n; ++i) rhs_h[(size_t)s * np + i] = Y[(size_t)s * ldy + i] - (mean ? mean[i] : T(0));
+
+    // ---- device buffers
+    void *A_v = nullptr, *xs_v = nullptr, *noise_v = nullptr, *alpha_v = nullptr;
+    const size_t A_bytes = sizeof(T) * (size_t)(mtot + 128) * ld;
+    const size_t xs_bytes = sizeof(T) * (size_t)d * np, nz_bytes = sizeof(T) * (size_t)np;
+    RC(ctx_alloc(c, A_bytes, &A_v));
+    RC(ctx_alloc(c, xs_bytes, &xs_v));
+    RC(ctx_alloc(c, nz_bytes, &noise_v));
+    RC(ctx_alloc(c, nz_bytes, &alpha_v));
+    T* A = (T*)A_v;
+    auto cleanup = [&](bool keep) {
+        ctx_release(c, noise_v, nz_bytes);
+        if (!keep) {
+            ctx_release(c, A_v, A_bytes);
+            ctx_release(c, xs_v, xs_bytes);
+            ctx_release(c, alpha_v, nz_bytes);
+        }
+    };
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipEventRecord(c->ev_phase[0], c->sm));
+        HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), xs_bytes, hipMemcpyHostToDevice, c->sm));
+        HIPCHK(hipMemcpyAsync(noise_v, noise_h.data(), nz_bytes, hipMemcpyHostToDevice, c->sm));
+        HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), c->sm));
+        HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * (8 + R), c->sm));
+        // RHS rows (+ the 128 slack rows) zeroed, then δ rows copied in
+        HIPCHK(hipMemsetAsync(A + np * ld, 0, sizeof(T) * (size_t)(R + 128) * ld, c->sm));
+        HIPCHK(hipMemcpy2DAsync(A + np * ld, sizeof(T) * ld, rhs_h.data(), sizeof(T) * np, sizeof(T) * np, ncols,
+                                hipMemcpyHostToDevice, c->sm));
+        RC(assemble_sym<T>(c, k, (const T*)xs_v, np, d, (const T*)noise_v, n, np, A, ld));
+        HIPCHK(hipEventRecord(c->ev_phase[1], c->sm));
+        RC(potrf_full<T>(c, A, ld, np, mtot, c->info_dev, n, c->scal_dev));
+        HIPCHK(hipEventRecord(c->ev_phase[2], c->sm));
+        // sqmahal per RHS row: ‖z_s‖², z_sᵀ = δ_sᵀ L⁻ᵀ sits in row np+s
+        hipLaunchKernelGGL(rowsumsq_kernel<T>, dim3((unsigned)ncols), dim3(256), 0, c->sm, A + np * ld, ld, np,
+                           c->scal_dev + 8);
+        HIPCHK(hipGetLastError());
+        if (post) {  // α = L⁻ᵀ z for column 0
+            HIPCHK(hipMemcpyAsync(alpha_v, A + np * ld, sizeof(T) * np, hipMemcpyDeviceToDevice, c->sm));
+            RC(trsv<T>(c, c->sm, A, ld, np, (T*)alpha_v, np, 1, false));
+        }
+        HIPCHK(hipEventRecord(c->ev_phase[3], c->sm));
+        int info_h = 0;
+        std::vector<double> scal_h(8 + ncols);
+        HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, c->sm));
+        HIPCHK(hipMemcpyAsync(scal_h.data(), c->scal_dev, sizeof(double) * (8 + ncols), hipMemcpyDeviceToHost, c->sm));
+        if (post && alpha_out)
+            HIPCHK(hipMemcpyAsync(alpha_out, alpha_v, sizeof(T) * n, hipMemcpyDeviceToHost, c->sm));
+        HIPCHK(hipStreamSynchronize(c->sm));
+        out.info = info_h;
+        out.logpdf.resize(ncols);
+        const double logdet = 2.0 * scal_h[0];
+        for (int s = 0; s < ncols; ++s) out.logpdf[s] = -0.5 * ((double)n * LOG2PI + logdet + scal_h[8 + s]);
+        // timings
+        float ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[1]));
+        c->tm.assemble_ms = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[1], c->ev_phase[2]));
+        c->tm.potrf_ms = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[2], c->ev_phase[3]));
+        c->tm.solve_ms = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[3]));
+        c->tm.total_ms = ms;
+        c->tm.gemm_ms = 0;
+        c->tm.gemm_flops = 0;
+        c->tm.gemm_launches = (int64_t)c->gemm_recs.size();
+        for (auto& r : c->gemm_recs) {
+            HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+            c->tm.gemm_ms += ms;
+            c->tm.gemm_flops += r.flops;
+        }
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        (void)hipStreamSynchronize(c->sp);
+        cleanup(false);
+        return rc;
+    }
+    if (out.info != 0 || !post) {
+        cleanup(false);
+        return out.info;
+    }
+    cleanup(true);
+    post->dtype = k->dtype;
+    post->n = n; post->np = np; post->ld = ld; post->mtot = mtot; post->d = d;
+    post->kind = k->kind; post->variance = k->variance; post->nscale = k->nscale;
+    post->scale.clear();
+    if (k->scale && k->nscale > 0) post->scale.assign(k->scale, k->scale + k->nscale);
+    post->A = A_v; post->A_bytes = A_bytes;
+    post->xs = xs_v; post->xs_bytes = xs_bytes;
+    post->alpha = alpha_v; post->alpha_bytes = nz_bytes;
+    return 0;
+}
+
+template <typename T>
+static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, int what, void* mean_out,
+                            void* var_out, void* cov_out) {
+    gp_ctx* c = post->ctx;
+    const long n = post->n, np = post->np, ld = post->ld;
+    const long ns = xs->n, nsp = round_up(ns, 128);
+    const int d = post->d;
+    gp_kernel k{};
+    k.kind = post->kind; k.dtype = post->dtype; k.variance = post->variance; k.nscale = post->nscale;
+    k.scale = post->scale.empty() ? nullptr : post->scale.data();
+    std::vector<T> xs_h;
+    scale_points<T>(&k, xs, nsp, xs_h);
+    void* xs_v = nullptr;
+    const size_t xs_bytes = sizeof(T) * (size_t)d * nsp;
+    RC(ctx_alloc(c, xs_bytes, &xs_v));
+    void *m_v = nullptr, *X_v = nullptr, *C_v = nullptr;
+    size_t m_bytes = sizeof(T) * (size_t)nsp, X_bytes = 0, C_bytes = 0;
+    const T* prior_mean = (const T*)pm;
+    const T* A = (const T*)post->A;
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), xs_bytes, hipMemcpyHostToDevice, c->sm));
+        if (what & 1) {
+            RC(ctx_alloc(c, m_bytes, &m_v));
+            hipLaunchKernelGGL(kvec_kernel<T>, dim3((unsigned)ns), dim3(256), 0, c->sm, (const T*)xs_v, nsp,
+                               (const T*)post->xs, np, d, post->kind, (T)post->variance, n, (const T*)post->alpha,
+                               (T*)m_v);
+            HIPCHK(hipGetLastError());
+            std::vector<T> m_h(ns);
+            HIPCHK(hipMemcpyAsync(m_h.data(), m_v, sizeof(T) * ns, hipMemcpyDeviceToHost, c->sm));
+            HIPCHK(hipStreamSynchronize(c->sm));
+            T* mo = (T*)mean_out;
+            for (long i = 0; i < ns; ++i) mo[i] = (prior_mean ? prior_mean[i] : T(0)) + m_h[i];
+        }
+        if (what & 6) {
+            const bool want_cov = (what & 4) != 0;
+            // test points are processed in row chunks of the cross-covariance X = K_*x (chunk × np);
+            // the full covariance needs all of X at once.
+            const long chunk = want_cov ? nsp : std::min<long>(nsp, 4096);
+            const long ldx = np + c->ldpad;
+            X_bytes = sizeof(T) * (size_t)(chunk + 128) * ldx;
+            RC(ctx_alloc(c, X_bytes, &X_v));
+            RC(ctx_scal(c, 8 + chunk));
+            T* X = (T*)X_v;
+            std::vector<double> ss(chunk);
+            T* vo = (T*)var_out;
+            for (long r0 = 0; r0 < nsp; r0 += chunk) {
+                const long rows = std::min(chunk, nsp - r0);
+                GridMap g = plain_map(0, r0, 0);
+                dim3 grid((unsigned)(np / 128), (unsigned)(rows / 128));
+                hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, X, ldx, (const T*)xs_v, nsp,
+                                   (const T*)post->xs, np, d, post->kind, (T)post->variance, (const T*)nullptr, ns, n,
+                                   0, g, (const T*)nullptr);
+                HIPCHK(hipGetLastError());
+                RC(trsm_rec<T>(c, c->sm, X, ldx, rows, A, ld, np));
+                if (what & 2) {
+                    hipLaunchKernelGGL(rowsumsq_kernel<T>, dim3((unsigned)rows), dim3(256), 0, c->sm, X, ldx, np,
+                                       c->scal_dev + 8);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(ss.data(), c->scal_dev + 8, sizeof(double) * rows, hipMemcpyDeviceToHost,
+                                          c->sm));
+                    HIPCHK(hipStreamSynchronize(c->sm));
+                    for (long i = 0; i < rows && r0 + i < ns; ++i)
+                        vo[r0 + i] = (T)((double)post->variance - ss[i]);
+                }
+            }
+            if (want_cov) {
+                const long ldc = nsp + c->ldpad;
+                C_bytes = sizeof(T) * (size_t)(nsp + 128) * ldc;
+                RC(ctx_alloc(c, C_bytes, &C_v));
+                T* Cm = (T*)C_v;
+                GridMap g = plain_map(0, 0, 0);
+                dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
+                hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, Cm, ldc, (const T*)xs_v, nsp,
+                                   (const T*)xs_v, nsp, d, post->kind, (T)post->variance, (const T*)nullptr, ns, ns,
+                                   0, g, (const T*)nullptr);
+                HIPCHK(hipGetLastError());
+                RC(launch_gemm<T>(c, c->sm, Cm, ldc, X, ldx, X, ldx, nsp, nsp, np, plain_map(0, 0, 0)));
+                // symmetric: row-major == column-major
+                HIPCHK(hipMemcpy2DAsync(cov_out, sizeof(T) * ns, Cm, sizeof(T) * ldc, sizeof(T) * ns, ns,
+                                        hipMemcpyDeviceToHost, c->sm));
+                HIPCHK(hipStreamSynchronize(c->sm));
+            }
+        }
+        return 0;
+    }();
+    if (rc != 0) (void)hipStreamSynchronize(c->sm);
+    ctx_release(c, xs_v, xs_bytes);
+    ctx_release(c, m_v, m_bytes);
+    ctx_release(c, X_v, X_bytes);
+    ctx_release(c, C_v, C_bytes);
+    return rc;
+}
+
+#include "vfe.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t gp_abi_version(void) { return GPMI355_ABI_VERSION; }
+const char* gp_last_error(void) { return g_err.c_str(); }
+
+int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null) {
+    if (!out) return set_arg_err(1, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return set_arg_err(2, "no such device");
+    HIPCHK(hipSetDevice(device));
+    gp_ctx* c = new gp_ctx();
+    c->device = device;
+    if (stream_or_null) {
+        c->sm = (hipStream_t)stream_or_null;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return set_hip_err(e, "hipStreamCreate", __LINE__);
+        }
+        c->own_sm = true;
+    }
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipError_t e = hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, hi);
+    if (e != hipSuccess) {
+        if (c->own_sm) (void)hipStreamDestroy(c->sm);
+        delete c;
+        return set_hip_err(e, "hipStreamCreateWithPriority", __LINE__);
+    }
+    if (const char* s = getenv("GPMI_NB")) c->nb = atol(s);
+    if (const char* s = getenv("GPMI_LOOKAHEAD")) c->lookahead = atoi(s);
+    if (const char* s = getenv("GPMI_LDPAD")) c->ldpad = round_up(std::max(0L, atol(s)), 16);
+    reg_add(c);
+    *out = c;
+    return 0;
+}
+
+int32_t gp_ctx_destroy(gp_ctx* c) {
+    if (!c || !reg_take(c)) return set_arg_err(1, "not a live gp_ctx");
+    {
+        std::lock_guard<std::mutex> l(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->sm);
+        (void)hipStreamSynchronize(c->sp);
+        c->dead = true;
+    }
+    ctx_unref(c);
+    return 0;
+}
+
+int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (!name) return set_arg_err(2, "name is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    if (!strcmp(name, "nb")) c->nb = (v <= 0) ? 0 : round_up(v, 128);
+    else if (!strcmp(name, "lookahead")) c->lookahead = v != 0;
+    else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
+    else if (!strcmp(name, "gemm_variant")) c->gemm_variant = (int)v;
+    else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
+    else return set_arg_err(2, "unknown parameter");
+    return 0;
+}
+
+int32_t gp_get_timings(gp_ctx* c, gp_timings* out) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (!out) return set_arg_err(2, "out is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    *out = c->tm;
+    return 0;
+}
+
+int32_t gp_kernelmatrix(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_points* y, void* out) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    RC(check_points(x, 3));
+    RC(check_kernel(k, x->d, 2));
+    if (y) {
+        RC(check_points(y, 4));
+        if (y->d != x->d) return set_arg_err(4, "x and y have different D");
+    }
+    if (!out) return set_arg_err(5, "out is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    auto run = [&](auto tag) -> int32_t {
+        using T = decltype(tag);
+        // device rows = y points (or x), device cols = x points: row-major (m×n) == column-major (n×m)
+        const gp_points* rp = y ? y : x;
+        const long n = x->n, m = rp->n, np = round_up(n, 128), mp = round_up(m, 128);
+        const long ld = np + c->ldpad;
+        std::vector<T> xc_h, xr_h;
+        scale_points<T>(k, x, np, xc_h);
+        if (y) scale_points<T>(k, y, mp, xr_h);
+        void *xc_v = nullptr, *xr_v = nullptr, *K_v = nullptr;
+        const size_t xcb = sizeof(T) * xc_h.size(), xrb = sizeof(T) * xr_h.size(), Kb = sizeof(T) * (size_t)mp * ld;
+        RC(ctx_alloc(c, xcb, &xc_v));
+        if (y) RC(ctx_alloc(c, xrb, &xr_v));
+        RC(ctx_alloc(c, Kb, &K_v));
+        int32_t rc = [&]() -> int32_t {
+            HIPCHK(hipMemcpyAsync(xc_v, xc_h.data(), xcb, hipMemcpyHostToDevice, c->sm));
+            if (y) HIPCHK(hipMemcpyAsync(xr_v, xr_h.data(), xrb, hipMemcpyHostToDevice, c->sm));
+            GridMap g = plain_map(0, 0, 0);
+            dim3 grid((unsigned)(np / 128), (unsigned)(mp / 128));
+            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, (T*)K_v, ld, (const T*)(y ? xr_v : xc_v),
+                               y ? mp : np, (const T*)xc_v, np, x->d, k->kind, (T)k->variance, (const T*)nullptr, m, n,
+                               0, g, (const T*)nullptr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy2DAsync(out, sizeof(T) * n, K_v, sizeof(T) * ld, sizeof(T) * n, m, hipMemcpyDeviceToHost,
+                                    c->sm));
+            HIPCHK(hipStreamSynchronize(c->sm));
+            return 0;
+        }();
+        if (rc != 0) (void)hipStreamSynchronize(c->sm);
+        ctx_release(c, xc_v, xcb);
+        ctx_release(c, xr_v, xrb);
+        ctx_release(c, K_v, Kb);
+        return rc;
+    };
+    return k->dtype == 0 ? run(double()) : run(float());
+}
+
+static int32_t check_fit_args(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    RC(check_points(x, 3));
+    RC(check_kernel(k, x->d, 2));
+    if (!noise) return set_arg_err(4, "noise is NULL");
+    if (noise->kind != 0 && noise->kind != 1) return set_arg_err(4, "noise kind must be 0 or 1");
+    if (noise->kind == 1 && !noise->diag) return set_arg_err(4, "noise diag is NULL");
+    return 0;
+}
+
+int32_t gp_logpdf(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean,
+                  const void* Y, int64_t ldy, int32_t ncols, void* out) {
+    RC(check_fit_args(c, k, x, noise));
+    if (!Y) return set_arg_err(6, "Y is NULL");
+    if (ncols < 1) return set_arg_err(8, "ncols must be >= 1");
+    if (ldy < x->n) return set_arg_err(7, "ldy < n");
+    if (!out) return set_arg_err(9, "out is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    FitOut fo;
+    int32_t rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr)
+                               : fit_impl<float>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr);
+    if (rc != 0) return rc;
+    for (int s = 0; s < ncols; ++s) {
+        if (k->dtype == 0) ((double*)out)[s] = fo.logpdf[s];
+        else ((float*)out)[s] = (float)fo.logpdf[s];
+    }
+    return 0;
+}
+
+int32_t gp_posterior_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean,
+                         const void* y, gp_post** out, void* alpha_out, void* logpdf_out) {
+    RC(check_fit_args(c, k, x, noise));
+    if (!y) return set_arg_err(6, "y is NULL");
+    if (!out) return set_arg_err(7, "out is NULL");
+    *out = nullptr;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    gp_post* p = new gp_post();
+    p->ctx = c;
+    FitOut fo;
+    int32_t rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out)
+                               : fit_impl<float>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out);
+    if (rc != 0) {
+        delete p;
+        return rc;
+    }
+    if (logpdf_out) {
+        if (k->dtype == 0) *(double*)logpdf_out = fo.logpdf[0];
+        else *(float*)logpdf_out = (float)fo.logpdf[0];
+    }
+    c->refs++;
+    reg_add(p);
+    *out = p;
+    return 0;
+}
+
+int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm, int32_t what, void* mean_out,
+                             void* var_out, void* cov_out) {
+    if (!post || !reg_has(post)) return set_arg_err(1, "not a live gp_post");
+    RC(check_points(xs, 2));
+    if (xs->d != post->d) return set_arg_err(2, "xs has a different D than the training inputs");
+    if (what <= 0 || what > 7) return set_arg_err(4, "what must be a combination of 1|2|4");
+    if ((what & 1) && !mean_out) return set_arg_err(5, "mean_out is NULL");
+    if ((what & 2) && !var_out) return set_arg_err(6, "var_out is NULL");
+    if ((what & 4) && !cov_out) return set_arg_err(7, "cov_out is NULL");
+    gp_ctx* c = post->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return post->dtype == 0 ? predict_impl<double>(post, xs, pm, what, mean_out, var_out, cov_out)
+                            : predict_impl<float>(post, xs, pm, what, mean_out, var_out, cov_out);
+}
+
+int64_t gp_posterior_n(gp_post* post) {
+    if (!post || !reg_has(post)) return -1;
+    return post->n;
+}
+
+int32_t gp_posterior_get_factor(gp_post* post, void* U_out) {
+    if (!post || !reg_has(post)) return set_arg_err(1, "not a live gp_post");
+    if (!U_out) return set_arg_err(2, "U_out is NULL");
+    gp_ctx* c = post->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t es = post->dtype == 0 ? 8 : 4;
+    const long n = post->n;
+    // device row j (row-major lower L[j][0..j]) == host column j of the column-major upper U
+    HIPCHK(hipMemcpy2DAsync(U_out, es * n, post->A, es * post->ld, es * n, n, hipMemcpyDeviceToHost, c->sm));
+    HIPCHK(hipStreamSynchronize(c->sm));
+    for (long j = 0; j < n; ++j) {  // strictly-lower part of U (i > j) is not part of the factor
+        char* col = (char*)U_out + (size_t)j * n * es;
+        if (j + 1 < n) memset(col + (size_t)(j + 1) * es, 0, (size_t)(n - j - 1) * es);
+    }
+    return 0;
+}
+
+int32_t gp_posterior_free(gp_post* post) {
+    if (!post || !reg_take(post)) return set_arg_err(1, "not a live gp_post");
+    gp_ctx* c = post->ctx;
+    {
+        std::lock_guard<std::mutex> l(c->mu);
+        (void)hipSetDevice(c->device);
+        ctx_release(c, post->A, post->A_bytes);
+        ctx_release(c, post->xs, post->xs_bytes);
+        ctx_release(c, post->alpha, post->alpha_bytes);
+    }
+    delete post;
+    ctx_unref(c);
+    return 0;
+}
+
+// ---- VFE / DTC ---------------------------------------------------------------------------------------
+int32_t gp_vfe_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_points* z, const gp_noise* noise,
+                   double jitter, const void* mean, const void* y, int32_t approx, gp_vfe** out, void* objective_out) {
+    RC(check_fit_args(c, k, x, noise));
+    RC(check_points(z, 4));
+    if (z->d != x->d) return set_arg_err(4, "z has a different D than x");
+    if (!(jitter >= 0)) return set_arg_err(6, "jitter must be >= 0");
+    if (!y) return set_arg_err(8, "y is NULL");
+    if (approx != 0 && approx != 1) return set_arg_err(9, "approx must be 0 (VFE) or 1 (DTC)");
+    if (out) *out = nullptr;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    gp_vfe* p = out ? new gp_vfe() : nullptr;
+    if (p) p->ctx = c;
+    double obj = 0;
+    int32_t rc = k->dtype == 0 ? vfe_fit_impl<double>(c, k, x, z, noise, jitter, mean, y, approx, p, &obj)
+                               : vfe_fit_impl<float>(c, k, x, z, noise, jitter, mean, y, approx, p, &obj);
+    if (rc != 0) {
+        delete p;
+        return rc;
+    }
+    if (objective_out) {
+        if (k->dtype == 0) *(double*)objective_out = obj;
+        else *(float*)objective_out = (float)obj;
+    }
+    if (p) {
+        c->refs++;
+        reg_add(p);
+        *out = p;
+    }
+    return 0;
+}
+
+int32_t gp_vfe_predict(gp_vfe* p, const gp_points* xs, const void* pm, int32_t what, void* mean_out, void* var_out) {
+    if (!p || !reg_has(p)) return set_arg_err(1, "not a live gp_vfe");
+    RC(check_points(xs, 2));
+    if (xs->d != p->d) return set_arg_err(2, "xs has a different D than the training inputs");
+    if (what <= 0 || what > 3) return set_arg_err(4, "what must be a combination of 1|2");
+    if ((what & 1) && !mean_out) return set_arg_err(5, "mean_out is NULL");
+    if ((what & 2) && !var_out) return set_arg_err(6, "var_out is NULL");
+    gp_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return p->dtype == 0 ? vfe_predict_impl<double>(p, xs, pm, what, mean_out, var_out)
+                         : vfe_predict_impl<float>(p, xs, pm, what, mean_out, var_out);
+}
+
+int32_t gp_vfe_get(gp_vfe* p, void* alpha_out, void* meps_out) {
+    if (!p || !reg_has(p)) return set_arg_err(1, "not a live gp_vfe");
+    gp_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<double> h((size_t)p->mp * 3);
+    HIPCHK(hipMemcpy(h.data(), p->alpha, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (long i = 0; i < p->m; ++i) {
+        if (alpha_out) {
+            if (p->dtype == 0) ((double*)alpha_out)[i] = h[2 * p->mp + i];
+            else ((float*)alpha_out)[i] = (float)h[2 * p->mp + i];
+        }
+        if (meps_out) {
+            if (p->dtype == 0) ((double*)meps_out)[i] = h[p->mp + i];
+            else ((float*)meps_out)[i] = (float)h[p->mp + i];
+        }
+    }
+    return 0;
+}
+
+int32_t gp_vfe_free(gp_vfe* p) {
+    if (!p || !reg_take(p)) return set_arg_err(1, "not a live gp_vfe");
+    gp_ctx* c = p->ctx;
+    {
+        std::lock_guard<std::mutex> l(c->mu);
+        (void)hipSetDevice(c->device);
+        ctx_release(c, p->Lz, p->L_bytes);
+        ctx_release(c, p->Ld, p->L_bytes);
+        ctx_release(c, p->zs, p->zs_bytes);
+        ctx_release(c, p->alpha, p->vec_bytes);
+    }
+    delete p;
+    ctx_unref(c);
+    return 0;
+}
+
+// ---- microbenchmarks / probes (tools/gpu_diag.py) ------------------------------------------------
+int32_t gp_probe_mfma_f64(gp_ctx* c, const double* A_host, const double* B_host, double* D_host) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    double* buf;
+    HIPCHK(hipMalloc((void**)&buf, sizeof(double) * (64 + 64 + 256)));
+    HIPCHK(hipMemcpy(buf, A_host, sizeof(double) * 64, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(buf + 64, B_host, sizeof(double) * 64, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mfma_probe_f64_kernel, dim3(1), dim3(64), 0, c->sm, buf, buf + 64, buf + 128);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->sm));
+    HIPCHK(hipMemcpy(D_host, buf + 128, sizeof(double) * 256, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(buf));
+    return 0;
+}
+// returns measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 (all CUs, 2 blocks per CU)
+int32_t gp_bench_mfma_f64(gp_ctx* c, int32_t iters, double* tflops_out) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    double* buf;
+    HIPCHK(hipMalloc((void**)&buf, 64));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    const int blocks = 256 * 2;
+    hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(blocks), dim3(256), 0, c->sm, buf, 16);
+    HIPCHK(hipEventRecord(a, c->sm));
+    hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(blocks), dim3(256), 0, c->sm, buf, iters);
+    HIPCHK(hipEventRecord(b, c->sm));
+    HIPCHK(hipStreamSynchronize(c->sm));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    *tflops_out = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIPCHK(hipFree(buf));
+    return 0;
+}
+
+// ---- device-level building blocks (multi-process block-cyclic driver) ------------------------------
+static GridMap to_map(const gp_grid* g, long row0, long col0) {
+    GridMap m = plain_map(0, row0, col0);
+    if (g) {
+        m.lower = g->lower;
+        m.P = g->P; m.p = g->p; m.Q = g->Q; m.q = g->q;
+        m.nb = (long)g->tb * 128;
+    }
+    return m;
+}
+
+int32_t gpd_assemble(gp_ctx* c, const gp_kernel* k, const double* x_dev, int64_t n_valid, int64_t n_pad, int32_t d,
+                     const double* noise_dev, const gp_grid* g, double* a_loc, int64_t lda, int64_t m_loc,
+                     int64_t n_loc) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    RC(check_kernel(k, d, 2));
+    if (m_loc % 128 || n_loc % 128) return set_arg_err(11, "m_loc, n_loc must be multiples of 128");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    GridMap m = to_map(g, 0, 0);
+    dim3 grid((unsigned)(n_loc / 128), (unsigned)(m_loc / 128));
+    if (grid.x == 0 || grid.y == 0) return 0;
+    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, c->sm, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d,
+                       k->kind, k->variance, noise_dev, n_valid, n_valid, 1, m, (const double*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int32_t gpd_potrf(gp_ctx* c, double* a, int64_t lda, int64_t m, int64_t n, int32_t* info_dev, int32_t col0,
+                  int64_t n_valid, double* logdet_dev) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (n % 64 || m % 64 || m < n) return set_arg_err(4, "m, n must be multiples of 64 with m >= n");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return potrf_rec<double>(c, c->sm, a, lda, 0, n, m, info_dev, col0, n_valid, logdet_dev);
+}
+
+int32_t gpd_trsm(gp_ctx* c, double* x, int64_t ldx, int64_t m, const double* lmat, int64_t ldl, int64_t n) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (n % 64 || m % 64) return set_arg_err(4, "m, n must be multiples of 64");
+    if (m == 0) return 0;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return trsm_rec<double>(c, c->sm, x, ldx, m, lmat, ldl, n);
+}
+
+int32_t gpd_gemm_nt(gp_ctx* c, double* cm, int64_t ldc, const double* a, int64_t lda, const double* b, int64_t ldb,
+                    int64_t m, int64_t n, int64_t k, const gp_grid* g, int64_t row0, int64_t col0) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (m % 64 || n % 64 || k % 16) return set_arg_err(8, "m, n multiples of 64 and k multiple of 16 required");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return launch_gemm<double>(c, c->sm, cm, ldc, a, lda, b, ldb, m, n, k, to_map(g, row0, col0));
+}
+
+int32_t gpd_trsv(gp_ctx* c, const double* lmat, int64_t ldl, int64_t np, double* r, int64_t ldr, int32_t nrhs,
+                 int32_t forward) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (np % 128) return set_arg_err(4, "np must be a multiple of 128");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return trsv<double>(c, c->sm, lmat, ldl, np, r, ldr, nrhs, forward != 0);
+}
+
+int32_t gpd_rowsumsq(gp_ctx* c, const double* x, int64_t ldx, int64_t nrows, int64_t ncols, double* out_dev) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (nrows <= 0) return 0;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(rowsumsq_kernel<double>, dim3((unsigned)nrows), dim3(256), 0, c->sm, x, ldx, ncols, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int32_t gpd_sync(gp_ctx* c) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->sm));
+    HIPCHK(hipStreamSynchronize(c->sp));
+    return 0;
+}
+
+}  // extern "C"

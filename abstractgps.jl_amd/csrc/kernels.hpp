@@ -1,0 +1,597 @@
+// kernels.hpp — hand-written gfx950 (CDNA4) device kernels of libgpmi355.
+//
+// Storage convention for every matrix touched here: ROW-MAJOR with leading dimension ld, lower
+// triangle = the factor L (K + Σy = L Lᵀ).  A row-major lower L is memory-identical to the
+// column-major upper C.U that Julia's cholesky returns (reference src/finite_gp_projection.jl:308),
+// so the factor can be handed to the host without a transpose.
+//
+// Kernels (reference call site each one replaces):
+//   kmat_kernel        KernelFunctions.kernelmatrix (+ Σy on the diagonal)   src/base_gp.jl:70,74; src/finite_gp_projection.jl:133-136
+//   gemm_nt_sub_kernel the SYRK/GEMM trailing update inside LAPACK dpotrf/dtrsm (MFMA)  src/finite_gp_projection.jl:308
+//   potf2_64_kernel    unblocked dpotf2 of a 64×64 diagonal tile + Σ log L_ii   :308, :310
+//   trsm_64_kernel     X ← X L⁻ᵀ against a 64×64 tile (dtrsm)               src/util/common_covmat_ops.jl:54-60
+//   trsv_*             forward / backward substitutions for vectors (dtrtrs/dpotrs)   src/exact_gpr_posterior.jl:33
+//   rowsumsq_kernel    sum(abs2, ·) reductions                              src/util/common_covmat_ops.jl:64-67
+//   kvec_kernel        K_*x α without materialising K_*x                    src/exact_gpr_posterior.jl:60-62
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpmi {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// MFMA traits.  A operand: lane l supplies A[i = l&15][k = l>>4]; B operand: B[k = l>>4][j = l&15]
+// (same for f64 16x16x4 and f32 16x16x4).  C/D: col = l&15 for both; row differs:
+//   f64: row = (l>>4) + 4*r      f32: row = 4*(l>>4) + r          (cdna_hip_programming.md §3)
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Tr;
+template <> struct Tr<double> {
+    typedef d2_t chunk_t;  // 16 B = 2 k-values
+    typedef d2_t pair_t;   // 2 output columns per lane in kmat
+    typedef d4_t acc_t;
+    static constexpr int VEC = 2;
+    __device__ static inline acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Tr<float> {
+    typedef f4_t chunk_t;  // 16 B = 4 k-values
+    typedef f2_t pair_t;
+    typedef f4_t acc_t;
+    static constexpr int VEC = 4;
+    __device__ static inline acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// 2D block-cyclic bookkeeping shared by kmat and gemm: local absolute index -> global index.
+struct GridMap {
+    int lower;       // 1: skip tiles strictly above the global diagonal
+    int P, p, Q, q;  // process grid / my coordinates (1,0,1,0 on a single GPU)
+    long nb;         // distribution block in elements (multiple of 128); ignored when P=Q=1
+    long row0, col0; // local absolute index of the region's first row / column
+};
+__device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
+    if (P == 1) return loc;
+    return ((loc / nb) * P + p) * nb + (loc % nb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_sub: C[M×N] -= A[M×K] · B[N×K]ᵀ    (all row-major)
+//   M, N multiples of 64; K multiple of 8*VEC (16 f64 / 32 f32).  128×128 block tile, 4 waves as
+//   2×2, each wave 64×64 = 4×4 MFMA 16×16 tiles (16 accumulators).  Operand tiles are staged
+//   global -> registers -> LDS, double-buffered, one barrier per K step.
+//   LDS image per operand and buffer: [8 chunks][128 rows] of 16 B; slot = row ^ f(chunk) with
+//   f(c) = (c&3) | (c&4 ? 12 : 0): conflict-free for the ds_read_b128 lane groups
+//   {0-3,12-15,20-27},... (MI355X_MICROARCH.md §LDS) AND for the 8-lane ds_write_b128 groups.
+//   Rows past M / N (M,N ≡ 64 mod 128) are over-read (allocations carry 128 slack rows) and
+//   their results are never stored.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_swz(int c) { return (c & 3) | ((c & 4) ? 12 : 0); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, long ldc, const T* __restrict__ A,
+                                                              long lda, const T* __restrict__ B, long ldb, int M,
+                                                              int N, int K, GridMap g) {
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    using acc_t = typename TR::acc_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int BK = 8 * VEC;
+
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    long gr0 = 0, gc0 = 0;
+    if (g.lower) {
+        gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
+        gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
+        if (gc0 > gr0 + 127) return;  // whole tile above the diagonal (block-uniform)
+    }
+    __shared__ chunk_t As[2][8][128];
+    __shared__ chunk_t Bs[2][8][128];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
+    if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
+
+    // staging map: thread -> (chunk lp, rows lr + 32 i)
+    const int lp = tid & 7, lr = tid >> 3;
+    const int fsw = lds_swz(lp);
+    const T* Ag = A + (long)(m0 + lr) * lda + lp * VEC;
+    const T* Bg = B + (long)(n0 + lr) * ldb + lp * VEC;
+    chunk_t ra[4], rb[4];
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t)(0);
+
+    const int li = lane & 15, lg = lane >> 4;
+    const int nk = K / BK;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const chunk_t*>(Ag + (long)(32 * i) * lda);
+        rb[i] = *reinterpret_cast<const chunk_t*>(Bg + (long)(32 * i) * ldb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        As[0][lp][(lr + 32 * i) ^ fsw] = ra[i];
+        Bs[0][lp][(lr + 32 * i) ^ fsw] = rb[i];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const long ko = (long)(kt + 1) * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const chunk_t*>(Ag + (long)(32 * i) * lda + ko);
+                rb[i] = *reinterpret_cast<const chunk_t*>(Bg + (long)(32 * i) * ldb + ko);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = 4 * h + lg;
+                const int fc = lds_swz(c);
+                chunk_t a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = As[cur][c][(wr * 64 + t * 16 + li) ^ fc];
+                    b[t] = Bs[cur][c][(wc * 64 + t * 16 + li) ^ fc];
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[mt][v], b[nt][v], acc[mt][nt]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                As[cur ^ 1][lp][(lr + 32 * i) ^ fsw] = ra[i];
+                Bs[cur ^ 1][lp][(lr + 32 * i) ^ fsw] = rb[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = m0 + wr * 64 + mt * 16 + TR::crow(lane, r);
+                    const long col = n0 + wc * 64 + nt * 16 + li;
+                    T* p = C + row * ldc + col;
+                    *p = *p - acc[mt][nt][r];
+                }
+    }
+}
+
+// Debug reference (gemm_variant = 1): same contract, plain VALU, one thread per C element.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* __restrict__ C, long ldc, const T* __restrict__ A,
+                                                               long lda, const T* __restrict__ B, long ldb, int M,
+                                                               int N, int K, GridMap g) {
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int row = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (row >= M || col >= N) return;
+    if (g.lower) {
+        const long gr = glob_idx(g.row0 + row, g.nb, g.P, g.p), gc = glob_idx(g.col0 + col, g.nb, g.Q, g.q);
+        // mirror the MFMA kernel's coverage: it updates whole 64×64 wave tiles touching the diagonal
+        if ((gc / 64) * 64 > (gr / 64) * 64 + 63) return;
+    }
+    T s = 0;
+    for (int k = 0; k < K; ++k) s += A[(long)row * lda + k] * B[(long)col * ldb + k];
+    C[(long)row * ldc + col] -= s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kmat: out[r][c] = variance * κ(‖xr_r − xc_c‖) (+ noise_r on the global diagonal when sym)
+//   xr / xc: pre-scaled inputs, dimension-major [d][ldx], indexed by GLOBAL point index.
+//   128×128 tile per block; wave w owns rows w, w+4, ...; lane l owns columns 2l, 2l+1 so every
+//   store instruction writes one contiguous 1 KiB (f64) row segment.
+//   Padding (global index >= n_valid): identity when sym, zero otherwise.
+//   colscale (nullable): column j of the result is multiplied by colscale[j] (VFE: K_zx Σy^-1/2).
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T kappa(int kind, T d2) {
+    if (kind == 0) return exp(T(-0.5) * d2);
+    const T d = sqrt(d2);
+    if (kind == 1) return exp(-d);
+    if (kind == 2) {
+        const T a = T(1.7320508075688772935) * d;
+        return (T(1) + a) * exp(-a);
+    }
+    const T a = T(2.2360679774997896964) * d;
+    return (T(1) + a + T(5.0 / 3.0) * d2) * exp(-a);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
+                                                    const T* __restrict__ xc, long ldxc, int d, int kind, T variance,
+                                                    const T* __restrict__ noise, long nr_valid, long nc_valid, int sym,
+                                                    GridMap g, const T* __restrict__ colscale) {
+    using pair_t = typename Tr<T>::pair_t;
+    constexpr int DC = 16;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const long gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
+    const long gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
+    if (g.lower && gc0 > gr0 + 127) return;
+
+    __shared__ T xi[DC][128];
+    __shared__ __attribute__((aligned(16))) T xj[DC][128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    T acc0[32], acc1[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc0[i] = acc1[i] = T(0);
+
+    for (int d0 = 0; d0 < d; d0 += DC) {
+        const int dc = (d - d0 < DC) ? (d - d0) : DC;
+        __syncthreads();
+        for (int e = tid; e < dc * 128; e += 256) {
+            const int dd = e >> 7, i = e & 127;
+            xi[dd][i] = xr[(long)(d0 + dd) * ldxr + gr0 + i];
+            xj[dd][i] = xc[(long)(d0 + dd) * ldxc + gc0 + i];
+        }
+        __syncthreads();
+        for (int dd = 0; dd < dc; ++dd) {
+            const pair_t yv = *reinterpret_cast<const pair_t*>(&xj[dd][2 * lane]);
+#pragma unroll
+            for (int rr = 0; rr < 32; ++rr) {
+                const T xv = xi[dd][w + 4 * rr];
+                const T t0 = xv - yv.x, t1 = xv - yv.y;
+                acc0[rr] = fma(t0, t0, acc0[rr]);
+                acc1[rr] = fma(t1, t1, acc1[rr]);
+            }
+        }
+    }
+    const long gj0 = gc0 + 2 * lane, gj1 = gj0 + 1;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+        const int row = w + 4 * rr;
+        const long gi = gr0 + row;
+        T v0, v1;
+        if (gi >= nr_valid) {
+            v0 = (sym && gi == gj0) ? T(1) : T(0);
+            v1 = (sym && gi == gj1) ? T(1) : T(0);
+        } else {
+            v0 = (gj0 < nc_valid) ? variance * kappa<T>(kind, acc0[rr]) : T(0);
+            v1 = (gj1 < nc_valid) ? variance * kappa<T>(kind, acc1[rr]) : T(0);
+            if (sym && noise != nullptr) {
+                if (gi == gj0) v0 += noise[gi];
+                if (gi == gj1) v1 += noise[gi];
+            }
+            if (colscale != nullptr) {
+                if (gj0 < nc_valid) v0 *= colscale[gj0];
+                if (gj1 < nc_valid) v1 *= colscale[gj1];
+            }
+        }
+        pair_t o;
+        o.x = v0;
+        o.y = v1;
+        *reinterpret_cast<pair_t*>(out + (long)(m0 + row) * ld + n0 + 2 * lane) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// potf2_64: in-place lower Cholesky of one 64×64 tile by ONE wave; lane r keeps row r in registers.
+//   Right-looking: after column c is final, every lane updates its remaining columns with the
+//   column-c entries broadcast through LDS.  info (device int32): first failing global column
+//   (1-based) if a pivot is not > 0 (LAPACK dpotrf info), untouched otherwise.
+//   logdet_acc += Σ_c log L_cc over columns with global index < n_valid.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long lda, int* __restrict__ info, int col0,
+                                                       int n_valid, double* __restrict__ logdet_acc) {
+    using chunk_t = typename Tr<T>::chunk_t;
+    constexpr int VEC = Tr<T>::VEC;
+    __shared__ __attribute__((aligned(16))) T colb[2][64];
+    const int r = threadIdx.x;
+    T a[64];
+    const chunk_t* row = reinterpret_cast<const chunk_t*>(A + (long)r * lda);
+#pragma unroll
+    for (int t = 0; t < 64 / VEC; ++t) {
+        const chunk_t v = row[t];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[VEC * t + e] = v[e];
+    }
+    int bad = 0;
+    T mydiag = T(1);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const T piv = __shfl(a[c], c, 64);  // pivot from lane c
+        if (!(piv > T(0)) && bad == 0) bad = c + 1;
+        const T dd = sqrt(piv);
+        const T v = (r == c) ? dd : a[c] / dd;
+        a[c] = v;
+        if (r == c) mydiag = dd;
+        T* cb = colb[c & 1];
+        cb[r] = v;
+        __syncthreads();
+#pragma unroll
+        for (int t = c + 1; t < 64; ++t) a[t] = fma(-v, cb[t], a[t]);
+    }
+    T* wrow = A + (long)r * lda;
+#pragma unroll
+    for (int t = 0; t < 64; ++t)
+        if (t <= r) wrow[t] = a[t];
+    double ldsum = (col0 + r < n_valid) ? log((double)mydiag) : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ldsum += __shfl_xor(ldsum, o, 64);
+    if (r == 0) {
+        if (logdet_acc) atomicAdd(logdet_acc, ldsum);
+        if (bad && info && *info == 0) *info = col0 + bad;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// trsm_64: X[M×64] ← X · L⁻ᵀ, L 64×64 lower (row-major).  One thread per row of X (row in
+//   registers), Lᵀ in LDS so the column of L needed after x_c is final is a contiguous broadcast.
+//   M multiple of 64; blocks of 256 rows.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_64_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L,
+                                                       long ldl) {
+    __shared__ __attribute__((aligned(16))) T Lt[64][64];  // Lt[c][t] = L[t][c]
+    __shared__ T rdiag[64];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int t = e >> 6, c = e & 63;  // coalesced read of row t
+        Lt[c][t] = L[(long)t * ldl + c];
+    }
+    if (tid < 64) rdiag[tid] = T(1) / L[(long)tid * ldl + tid];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + tid;
+    if (row >= M) return;
+    using chunk_t = typename Tr<T>::chunk_t;
+    constexpr int VEC = Tr<T>::VEC;
+    chunk_t* xr = reinterpret_cast<chunk_t*>(X + (long)row * ldx);
+    T x[64];
+#pragma unroll
+    for (int t = 0; t < 64 / VEC; ++t) {
+        const chunk_t v = xr[t];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[VEC * t + e] = v[e];
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const T v = x[c] * rdiag[c];
+        x[c] = v;
+#pragma unroll
+        for (int t = c + 1; t < 64; ++t) x[t] = fma(-v, Lt[c][t], x[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 64 / VEC; ++t) {
+        chunk_t v;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = x[VEC * t + e];
+        xr[t] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vector triangular solves, blocked by NBV = 1024 with 64-wide inner steps.  nrhs right-hand sides
+// are stored as rows: R[s*ldr + i].
+//   trsv_diag<FWD>: one workgroup solves the nbv×nbv diagonal block at b0 for all nrhs.
+//   trsv_upd_fwd : r[i] -= Σ_j L[i][b0+j] z[b0+j]   rows i >= b0+nbv          (one wave per row)
+//   trsv_upd_bwd : r[j] -= Σ_i L[b0+i][j] a[b0+i]   columns j < b0            (atomics over row chunks)
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool FWD>
+__global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
+                                                          T* __restrict__ R, long ldr, int nrhs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* rv = reinterpret_cast<T*>(smem_raw);  // [nbv] current rhs / solution
+    T* Ls = rv + nbv;                        // [64][65] diagonal sub-tile
+    const int tid = threadIdx.x;
+    const int ns = nbv / 64;
+    for (int s = 0; s < nrhs; ++s) {
+        T* r = R + (long)s * ldr + b0;
+        for (int i = tid; i < nbv; i += 1024) rv[i] = r[i];
+        __syncthreads();
+        for (int ss = 0; ss < ns; ++ss) {
+            const int sb = FWD ? ss : (ns - 1 - ss);
+            const int s0 = sb * 64;
+            // stage the 64×64 diagonal sub-tile
+            for (int e = tid; e < 64 * 64; e += 1024) {
+                const int t = e >> 6, c = e & 63;
+                Ls[t * 65 + c] = L[(b0 + s0 + t) * ldl + b0 + s0 + c];
+            }
+            __syncthreads();
+            if (tid < 64) {  // one wave: substitution, lane t owns rv[s0+t]
+                T v = rv[s0 + tid];
+                if (FWD) {
+                    for (int c = 0; c < 64; ++c) {
+                        const T zc = __shfl(v, c, 64) / Ls[c * 65 + c];
+                        if (tid == c) v = zc;
+                        if (tid > c) v = fma(-Ls[tid * 65 + c], zc, v);
+                    }
+                } else {
+                    for (int c = 63; c >= 0; --c) {
+                        const T zc = __shfl(v, c, 64) / Ls[c * 65 + c];
+                        if (tid == c) v = zc;
+                        if (tid < c) v = fma(-Ls[c * 65 + tid], zc, v);
+                    }
+                }
+                rv[s0 + tid] = v;
+            }
+            __syncthreads();
+            // update the not-yet-solved part of this diagonal block
+            if (FWD) {
+                for (int i = s0 + 64 + tid; i < nbv; i += 1024) {
+                    const T* lrow = L + (b0 + i) * ldl + b0 + s0;
+                    T acc = 0;
+                    for (int c = 0; c < 64; ++c) acc = fma(lrow[c], rv[s0 + c], acc);
+                    rv[i] -= acc;
+                }
+            } else {
+                for (int j = tid; j < s0; j += 1024) {
+                    T acc = 0;
+                    for (int c = 0; c < 64; ++c) acc = fma(L[(b0 + s0 + c) * ldl + b0 + j], rv[s0 + c], acc);
+                    rv[j] -= acc;
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < nbv; i += 1024) r[i] = rv[i];
+        __syncthreads();
+    }
+}
+
+// rows [row_lo, row_hi): r[s][i] -= Σ_{j<nbv} L[i][b0+j] z[s][b0+j]; one wave per row, 4 rows per block.
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_upd_fwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
+                                                            long row_lo, long row_hi, T* __restrict__ R, long ldr,
+                                                            int nrhs) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = row_lo + (long)blockIdx.x * 4 + w;
+    if (i >= row_hi) return;
+    const T* lrow = L + i * ldl + b0;
+    for (int s = 0; s < nrhs; ++s) {
+        const T* z = R + (long)s * ldr + b0;
+        T acc = 0;
+        for (int j = lane; j < nbv; j += 64) acc = fma(lrow[j], z[j], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) R[(long)s * ldr + i] -= acc;
+    }
+}
+
+// columns j < b0: r[s][j] -= Σ_{i<nbv} L[b0+i][j] a[s][b0+i].  grid (ceil(b0/256), nbv/64): each block
+// takes 64 rows × 256 columns, one column per thread, then one atomicAdd per column.
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_upd_bwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
+                                                            T* __restrict__ R, long ldr, int nrhs) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i0 = b0 + (long)blockIdx.y * 64;
+    if (j >= b0) return;
+    for (int s = 0; s < nrhs; ++s) {
+        const T* a = R + (long)s * ldr;
+        T acc = 0;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) acc = fma(L[(i0 + i) * ldl + j], a[i0 + i], acc);
+        atomicAdd(R + (long)s * ldr + j, -acc);
+    }
+}
+
+// out[row] = Σ_{c<ncols} X[row][c]²  (one block per row)
+template <typename T>
+__global__ __launch_bounds__(256) void rowsumsq_kernel(const T* __restrict__ X, long ldx, long ncols,
+                                                        double* __restrict__ out) {
+    __shared__ double red[4];
+    const T* x = X + (long)blockIdx.x * ldx;
+    double acc = 0;
+    for (long c = threadIdx.x; c < ncols; c += 256) {
+        const double v = (double)x[c];
+        acc = fma(v, v, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[s] = Σ_i variance κ(‖xs_s − x_i‖) α_i   (K_*x α fused with the kernel evaluation; one block per s)
+template <typename T>
+__global__ __launch_bounds__(256) void kvec_kernel(const T* __restrict__ xs, long ldxs, const T* __restrict__ x,
+                                                    long ldx, int d, int kind, T variance, long n,
+                                                    const T* __restrict__ alpha, T* __restrict__ out) {
+    __shared__ double red[4];
+    const long s = blockIdx.x;
+    double acc = 0;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        T d2 = 0;
+        for (int dd = 0; dd < d; ++dd) {
+            const T t = xs[(long)dd * ldxs + s] - x[(long)dd * ldx + i];
+            d2 = fma(t, t, d2);
+        }
+        acc += (double)(variance * kappa<T>(kind, d2) * alpha[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] = (T)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- small M×M helpers of the VFE path ------------------------------------------------------------
+// dst[i][j] = -(double) src[max(i,j)][min(i,j)]   (the SYRK accumulator holds -G in its lower triangle)
+template <typename T>
+__global__ __launch_bounds__(256) void neg_sym_to_f64_kernel(const T* __restrict__ src, long lds, double* __restrict__ dst,
+                                                              long ldd, long n) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    const long a = i > j ? i : j, b = i > j ? j : i;
+    dst[i * ldd + j] = -(double)src[a * lds + b];
+}
+// dst = srcᵀ (n×n, 32×32 LDS tiles)
+__global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst,
+                                                            long ldd, long n) {
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8) t[k][tx] = src[(r0 + k) * lds + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) dst[(c0 + k) * ldd + r0 + tx] = t[tx][k];
+}
+// A[i][i] += v for i < n; out[0] = Σ_{i<n_valid} A[i][i] BEFORE the shift (one block)
+__global__ __launch_bounds__(256) void diag_shift_trace_kernel(double* __restrict__ A, long lda, long n, long n_valid, double v,
+                                                               double* __restrict__ out) {
+    __shared__ double red[4];
+    double acc = 0;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const double d = A[i * lda + i];
+        if (i < n_valid) acc += d;
+        A[i * lda + i] = d + v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && out) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (TD)src[i];
+}
+
+// MFMA layout / rate probe: D = A·B for one 16×16×4 tile (A row-major 16×4, B row-major 4×16).
+__global__ void mfma_probe_f64_kernel(const double* A, const double* B, double* D) {
+    const int l = threadIdx.x;
+    d4_t c = (d4_t)(0.0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
+}
+// Peak-rate microbenchmark: 4 waves per block, 8 independent accumulators, iters back-to-back MFMAs.
+__global__ __launch_bounds__(256) void mfma_rate_f64_kernel(double* out, int iters) {
+    d4_t acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (d4_t)((double)i);
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;  // keep live
+}
+
+}  // namespace gpmi

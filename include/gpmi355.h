@@ -1,0 +1,196 @@
+/* gpmi355.h — C ABI of libgpmi355.so: MI355X-native (gfx950) exact / sparse GP inference.
+ *
+ * This is the drop-in boundary for ONE hot path of AbstractGPs.jl (reference paths are relative
+ * to the upstream repo): logpdf(fx, y)   src/finite_gp_projection.jl:306-311
+ *                         posterior(fx,y) src/exact_gpr_posterior.jl:29-35
+ * plus what callers do next (predictive mean/var/cov, src/exact_gpr_posterior.jl:60-90) and the
+ * VFE/DTC sparse variant (src/sparse_approximations.jl:58-75, 183-217, 248-313).
+ *
+ * The reference has no FFI of its own (pure Julia); its documented plug-in point is "subtype
+ * AbstractGP and implement the FiniteGP primary API" (docs/src/api.md:18-30, 49-73).  The Julia
+ * shim that does that with `ccall` into these entry points is abstractgps.jl_amd/julia/HipGPs.jl;
+ * a line-for-line Python ctypes mirror (abstractgps.jl_amd/api.py) is what the test-suite runs.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every function returns int32 status:
+ *        0      success
+ *        k > 0  LAPACK-style info: leading minor of order k is not positive definite
+ *               (the shim throws LinearAlgebra.PosDefException(k) exactly like `cholesky` at
+ *               src/finite_gp_projection.jl:308 / src/exact_gpr_posterior.jl:31)
+ *        -i     (1 <= i < 1000) argument i invalid
+ *        -1000-e HIP error e;  text in gp_last_error() (thread-local)
+ *  - host pointers are borrowed for the duration of the call only; outputs are caller-allocated
+ *    host buffers; device memory, streams and workspaces are owned by the handles.
+ *  - dtype: 0 = f64, 1 = f32.  All host arrays of one call share the kernel's dtype
+ *    (Float32 in -> Float32 out is a tested reference property, test/finite_gp_projection.jl:180-191).
+ *  - matrices handed back to the host are COLUMN-MAJOR (Julia layout).
+ *  - functions taking a gp_ctx are serialised per ctx by an internal mutex and may be called from
+ *    any OS thread (hipSetDevice is issued on entry).
+ */
+#ifndef GPMI355_H
+#define GPMI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMI355_ABI_VERSION 1
+
+typedef struct gp_ctx gp_ctx;   /* device + streams + workspace                          */
+typedef struct gp_post gp_post; /* PosteriorGP state: device-resident factor, alpha, x   */
+typedef struct gp_vfe gp_vfe;   /* ApproxPosteriorGP state (VFE / DTC)                    */
+
+/* Kernel descriptor: variance * base(kind) ∘ transform.   Replaces KernelFunctions.kernelmatrix
+ * at src/base_gp.jl:70,72,74.  kind: 0 SqExponential exp(-d²/2); 1 Matern12 exp(-d);
+ * 2 Matern32 (1+√3d)exp(-√3d); 3 Matern52 (1+√5d+5d²/3)exp(-√5d).
+ * nscale: 0 none; 1 ScaleTransform(scale[0]) (with_lengthscale(k,ℓ) ≡ scale = 1/ℓ); D ARDTransform(scale[0..D)). */
+typedef struct {
+    int32_t kind;
+    int32_t dtype;
+    double variance;
+    int32_t nscale;
+    const double* scale;
+} gp_kernel;
+
+/* Inputs (host).  layout: 0 = Vector{T} (d must be 1); 1 = ColVecs(X), X is d×n column-major
+ * (point-contiguous); 2 = RowVecs(X), X is n×d column-major (dimension-contiguous).
+ * src/finite_gp_projection.jl:32-37. */
+typedef struct {
+    const void* data;
+    int64_t n;
+    int32_t d;
+    int32_t layout;
+} gp_points;
+
+/* Observation noise Σy.  kind 0: σ²·I (Fill, src/finite_gp_projection.jl:19-21); kind 1: Diagonal(diag)
+ * (length n, host, kernel dtype) (:13-15).  Dense Σy is not accelerated (shim falls back). */
+typedef struct {
+    int32_t kind;
+    double s;
+    const void* diag;
+} gp_noise;
+
+/* Per-phase wall times (ms, HIP events on the ctx streams) of the last fit/logpdf call, and the
+ * accumulated duration / algorithmic FLOPs of the dominant kernel (gemm_nt trailing update) when
+ * parameter "time_kernels" is 1. */
+typedef struct {
+    double assemble_ms;
+    double potrf_ms;
+    double solve_ms;
+    double total_ms;
+    double gemm_ms;        /* Σ per-launch durations of gemm_nt_sub launches (time_kernels=1)  */
+    double gemm_flops;     /* Σ algorithmic flops of those launches                               */
+    int64_t gemm_launches;
+    int64_t reserved;
+} gp_timings;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* stream_or_null: a hipStream_t owned by the caller to issue the main-stream work on (e.g. the
+ * current torch stream in the multi-process driver); NULL = the ctx creates its own. */
+int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null);
+int32_t gp_ctx_destroy(gp_ctx* ctx);
+/* names: "nb" (outer panel width, multiple of 128), "lookahead" (0/1), "time_kernels" (0/1),
+ * "gemm_variant" (0 = MFMA, 1 = VALU debug reference). */
+int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
+int32_t gp_get_timings(gp_ctx* ctx, gp_timings* out);
+const char* gp_last_error(void);
+int32_t gp_abi_version(void);
+
+/* ---- kernelmatrix (parity / small N) ------------------------------------------------------- */
+/* out (host, column-major): n×n for y == NULL (exactly symmetric), else x.n × y.n.
+ * KernelFunctions.kernelmatrix(k, x[, y]) — src/base_gp.jl:70,74. */
+int32_t gp_kernelmatrix(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_points* y_or_null,
+                        void* out);
+
+/* ---- exact GP: logpdf / posterior --------------------------------------------------------- */
+/* logpdf(f(x, Σy), Y): Y is n×ncols column-major with leading dimension ldy; out has ncols entries.
+ * mean_or_null: prior mean vector m (length n) evaluated on the host, NULL = ZeroMean.
+ * src/finite_gp_projection.jl:306-311, 325-326. */
+int32_t gp_logpdf(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_noise* noise,
+                  const void* mean_or_null, const void* Y, int64_t ldy, int32_t ncols, void* out);
+
+/* posterior(f(x, Σy), y): ONE Gram assembly + ONE factorisation serve both results.
+ * alpha_out_or_null: length n (α = C \ (y - m));  logpdf_out_or_null: 1 entry (= logpdf(fx, y)).
+ * The factor stays on the device inside *out.  src/exact_gpr_posterior.jl:29-35. */
+int32_t gp_posterior_fit(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_noise* noise,
+                         const void* mean_or_null, const void* y, gp_post** out, void* alpha_out_or_null,
+                         void* logpdf_out_or_null);
+
+/* Predictive quantities at xs (src/exact_gpr_posterior.jl:60-90).  what: bit0 mean, bit1 var,
+ * bit2 full cov (ns×ns column-major).  prior_mean_xs_or_null: m(x*) evaluated on the host.
+ * mean = m(x*) + K_*x α;  var = k** - colsumsq(U⁻ᵀ K_x*);  cov = K** - VᵀV. */
+int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* prior_mean_xs_or_null,
+                             int32_t what, void* mean_out, void* var_out, void* cov_out);
+/* logpdf(post(x*, Σy*), y*) is not separate: predict + host.  */
+
+/* C.U (n×n column-major upper, strictly-lower part zero) to the host — parity / debugging only. */
+int32_t gp_posterior_get_factor(gp_post* post, void* U_out);
+int64_t gp_posterior_n(gp_post* post);
+int32_t gp_posterior_free(gp_post* post); /* NULL or already-freed handle: returns -1, never UB-free twice */
+
+/* ---- VFE / DTC sparse approximation -------------------------------------------------------- */
+/* posterior(VFE(f(z, jitter)), f(x, Σy), y)  (src/sparse_approximations.jl:58-75) and
+ * approx_log_evidence / elbo (:248-254 VFE, :282-286 DTC) from the same intermediates.
+ * approx: 0 VFE, 1 DTC.  objective_out_or_null: 1 entry.  K_xz is streamed in row blocks and never
+ * materialised; only M×M matrices live in HBM. */
+int32_t gp_vfe_fit(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_points* z,
+                   const gp_noise* noise, double jitter, const void* mean_or_null, const void* y,
+                   int32_t approx, gp_vfe** out, void* objective_out_or_null);
+/* mean_and_var / mean (src/sparse_approximations.jl:183-217).  what: bit0 mean, bit1 var. */
+int32_t gp_vfe_predict(gp_vfe* post, const gp_points* xs, const void* prior_mean_xs_or_null, int32_t what,
+                       void* mean_out, void* var_out);
+/* α = U \ m_ε (length M) and m_ε — cache fields of src/sparse_approximations.jl:73. */
+int32_t gp_vfe_get(gp_vfe* post, void* alpha_out_or_null, void* m_eps_out_or_null);
+int32_t gp_vfe_free(gp_vfe* post);
+
+/* ---- device-level building blocks (multi-process 2D block-cyclic driver) -------------------- */
+/* All pointers below are DEVICE pointers (fp64), row-major with the given leading dimension, i.e.
+ * a row-major lower factor L — memory-identical to Julia's column-major C.U.  Work is issued on the
+ * ctx main stream and NOT synchronised (the caller orders it against its RCCL traffic).
+ * m, n multiples of 128; k multiple of 16 (gemm) / 64 (trsm, potrf). */
+
+/* Fill local tiles of K + Σy.  rows: global indices row0 + i (i < m) mapped through the block-cyclic
+ * map (global tile-row of local 128-tile t is ((t / tb) * P + p) * tb + t % tb); same for columns with
+ * (Q, q).  x_dev is n_total×d in RowVecs layout (dimension-contiguous) already on the device;
+ * noise_dev has n_total entries (padding rows get identity).  */
+typedef struct {
+    int32_t P, p, Q, q; /* process grid and my coordinates                                */
+    int32_t tb;         /* 128-tiles per distribution block (NB / 128)                       */
+    int32_t lower;      /* 1: skip 128-tiles strictly above the global diagonal             */
+} gp_grid;
+
+int32_t gpd_assemble(gp_ctx* ctx, const gp_kernel* k, const double* x_dev, int64_t n_valid, int64_t n_pad,
+                     int32_t d, const double* noise_dev, const gp_grid* g, double* a_loc, int64_t lda,
+                     int64_t m_loc, int64_t n_loc);
+/* In-place lower Cholesky of the n×n diagonal block at a (rows/cols [0,n)), and of the m-n rows
+ * below it (X ← X L⁻ᵀ) when m > n.  info_dev: device int32, set to (col0 + failing column, 1-based)
+ * on the first non-positive pivot.  logdet_dev += Σ log L_ii over columns col0+i < n_valid. */
+int32_t gpd_potrf(gp_ctx* ctx, double* a, int64_t lda, int64_t m, int64_t n, int32_t* info_dev, int32_t col0,
+                  int64_t n_valid, double* logdet_dev);
+/* X (m×n) ← X · L⁻ᵀ with L the n×n lower factor (row-major, ldl). */
+int32_t gpd_trsm(gp_ctx* ctx, double* x, int64_t ldx, int64_t m, const double* l, int64_t ldl, int64_t n);
+/* C (m×n) -= A (m×k) · B (n×k)ᵀ.  With g != NULL and g->lower, 64×64 sub-tiles strictly above the
+ * global diagonal are skipped; row0/col0 = local absolute index of C's first row/column (mapped to
+ * global indices through g).  g == NULL: plain rectangular update. */
+int32_t gpd_gemm_nt(gp_ctx* ctx, double* c, int64_t ldc, const double* a, int64_t lda, const double* b,
+                    int64_t ldb, int64_t m, int64_t n, int64_t k, const gp_grid* g_or_null, int64_t row0,
+                    int64_t col0);
+/* nrhs vectors stored as rows r[s*ldr + i], i < np: forward (L z = r) or backward (Lᵀ a = r) solve in place. */
+int32_t gpd_trsv(gp_ctx* ctx, const double* l, int64_t ldl, int64_t np, double* r, int64_t ldr, int32_t nrhs,
+                 int32_t forward);
+/* out_dev[i] = Σ_{c<ncols} x[i*ldx + c]² for i < nrows. */
+int32_t gpd_rowsumsq(gp_ctx* ctx, const double* x, int64_t ldx, int64_t nrows, int64_t ncols, double* out_dev);
+int32_t gpd_sync(gp_ctx* ctx);
+
+/* ---- probes used by tools/gpu_diag.py and bench.py ------------------------------------------ */
+/* D(16×16) = A(16×4)·B(4×16), all row-major host arrays: checks the f64 MFMA lane maps. */
+int32_t gp_probe_mfma_f64(gp_ctx* ctx, const double* a_host, const double* b_host, double* d_host);
+/* measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on all CUs (the roofline's measured ceiling). */
+int32_t gp_bench_mfma_f64(gp_ctx* ctx, int32_t iters, double* tflops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMI355_H */

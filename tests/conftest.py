@@ -1,0 +1,44 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests never silently pass on a box without a GPU: they are skipped with a loud reason when
+    # deselected by "-m 'not gpu'", and ERROR (not skip) if explicitly selected without a device.
+    if _have_gpu():
+        return
+    for item in items:
+        if "gpu" in item.keywords and "gpu" not in (config.getoption("-m") or ""):
+            item.add_marker(pytest.mark.skip(reason="no GPU in this container (gpu tests run via gpurun)"))
+
+
+@pytest.fixture(scope="session")
+def agp():
+    import abstractgps_jl_amd as m
+
+    return m
+
+
+@pytest.fixture(scope="session")
+def ctx(agp):
+    return agp.default_context(0)

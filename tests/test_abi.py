@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gpmi355.h declares; argument
+validation works without a device (no compute calls here)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_exports_every_declared_symbol(agp):
+    lib = agp._lib.load()
+    declared = agp._lib.header_functions()
+    assert len(declared) >= 24
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(declared) == set(agp._lib.PROTOTYPES), set(declared) ^ set(agp._lib.PROTOTYPES)
+    assert lib.gp_abi_version() == 1
+
+
+def test_dead_handles_are_rejected_not_ub(agp):
+    lib = agp._lib.load()
+    bogus = C.c_void_p(0xDEADBEEF)
+    assert lib.gp_ctx_destroy(bogus) == -1
+    assert lib.gp_posterior_free(bogus) == -1
+    assert lib.gp_posterior_free(None) == -1
+    assert lib.gp_vfe_free(bogus) == -1
+    assert lib.gp_posterior_n(bogus) == -1
+    assert b"not a live" in lib.gp_last_error()
+
+
+def test_missing_library_fails_loudly(agp, monkeypatch, tmp_path):
+    monkeypatch.setenv("GPMI355_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(agp._lib, "_lib", None)
+    with pytest.raises(ImportError):
+        agp._lib.load()
+
+
+def test_marshal_layouts(agp):
+    """ColVecs (D×N column-major) / RowVecs (N×D column-major) reach the ABI in the documented layout
+    (reference src/finite_gp_projection.jl:32-37)."""
+    X = np.arange(12.0).reshape(4, 3)  # 4 points, D = 3
+    m = agp.api._Marshal(np.float64)
+    p = m.points(agp.RowVecs(X))
+    assert (p.n, p.d, p.layout) == (4, 3, 2)
+    buf = np.ctypeslib.as_array(C.cast(p.data, C.POINTER(C.c_double)), shape=(12,))
+    assert [buf[i + dd * 4] for i in range(4) for dd in range(3)] == list(X.ravel())
+    p = m.points(agp.ColVecs(X.T.copy()))
+    assert (p.n, p.d, p.layout) == (4, 3, 1)
+    buf = np.ctypeslib.as_array(C.cast(p.data, C.POINTER(C.c_double)), shape=(12,))
+    assert [buf[dd + i * 3] for i in range(4) for dd in range(3)] == list(X.ravel())
+    p = m.points(np.arange(5.0))
+    assert (p.n, p.d, p.layout) == (5, 1, 0)
+
+
+def test_api_errors_mirror_reference(agp):
+    f = agp.GP(agp.SqExponentialKernel())
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        agp.logpdf(f(np.zeros(4), 0.1), np.zeros(5))
+    with pytest.raises(TypeError):  # mean(f) without x — src/abstract_gp.jl:66-87
+        f.mean()
+    g = agp.GP(agp.SqExponentialKernel())
+    with pytest.raises(AssertionError):  # @assert vfe.fz.f === fx.f — src/sparse_approximations.jl:59
+        agp.posterior(agp.VFE(g(np.zeros(2))), f(np.zeros(4), 0.1), np.zeros(4))
+    k = 2.0 * agp.Matern32Kernel() @ agp.ScaleTransform(0.5)
+    assert (k.kind, k.variance, k.transform.s) == (2, 2.0, 0.5)
+    assert agp.with_lengthscale(agp.SqExponentialKernel(), 4.0).transform.s == 0.25

@@ -1,0 +1,190 @@
+"""GPU parity tests proper: the HIP path (through the C ABI / the API mirror) against the CPU oracle
+and the committed golden fixtures on the same seeded inputs.  Tolerances (fp64):
+K entries abs <= 1e-14·σ_k²; logpdf rel <= 1e-10; α rel(2-norm) <= 1e-8; predictive mean abs <= 1e-8,
+var abs <= 1e-9.  fp32: logpdf/ELBO rel <= 1e-4 against the fp64 oracle."""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
+
+
+def _golden(agp, path):
+    g = np.load(path)
+    kind, var = int(g["kind"]), float(g["variance"])
+    k = var * agp.Kernel(kind)
+    ok = None
+    if not np.isnan(g["scale"]).all():
+        if g["scale"].ndim == 0:
+            k = k @ agp.ScaleTransform(float(g["scale"]))
+            ok = float(g["scale"])
+        else:
+            k = k @ agp.ARDTransform(g["scale"])
+            ok = g["scale"]
+    mean = None if np.isnan(g["mean"]) else float(g["mean"])
+    s2 = float(g["sigma2"]) if g["sigma2"].ndim == 0 else g["sigma2"]
+    f = agp.GP(k) if mean is None else agp.GP(mean, k)
+    of = o.GP(o.Kernel(kind, var, ok), mean)
+    return g, f, f(g["x"], s2), of, o.FiniteGP(of, g["x"], s2)
+
+
+def _relnorm(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_kernelmatrix_vs_oracle(agp, path):
+    g, f, fx, of, ofx = _golden(agp, path)
+    K = agp.kernelmatrix(f.kernel, g["x"])
+    Ko = o.kernelmatrix(of.kernel, g["x"])
+    assert np.max(np.abs(K - Ko)) <= 1e-14 * of.kernel.variance
+    assert np.array_equal(K, K.T)  # exactly symmetric, like kernelmatrix(k, x)
+    Kc = agp.kernelmatrix(f.kernel, g["x"], g["xs"])
+    assert np.max(np.abs(Kc - o.kernelmatrix(of.kernel, g["x"], g["xs"]))) <= 1e-14 * of.kernel.variance
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_logpdf_posterior_vs_golden_and_oracle(agp, path):
+    g, f, fx, of, ofx = _golden(agp, path)
+    lp = agp.logpdf(fx, g["y"])
+    assert isinstance(lp, np.float64)
+    assert lp == pytest.approx(float(g["logpdf"]), rel=1e-10)
+    np.testing.assert_allclose(agp.logpdf(fx, g["Y"]), g["logpdf_Y"], rtol=1e-10)  # matrix Y: per column
+    post = agp.posterior(fx, g["y"])
+    assert post.logpdf_value == pytest.approx(float(g["logpdf"]), rel=1e-10)
+    assert _relnorm(post.data.alpha, g["alpha"]) <= 1e-8
+    np.testing.assert_allclose(post.data.delta, o.posterior(ofx, g["y"]).delta, atol=0)
+    # factor: C.U of the reference (column-major upper)
+    U = post.data.C.U
+    Uo = o.posterior(ofx, g["y"]).U
+    assert np.max(np.abs(U - Uo)) <= 1e-10
+    m, v = agp.mean_and_var(post(g["xs"], 0.0))
+    np.testing.assert_allclose(m, g["post_mean"], atol=1e-8)
+    np.testing.assert_allclose(v, g["post_var"], atol=1e-9)
+    np.testing.assert_allclose(post.cov(g["xs"]), g["post_cov"], atol=1e-9)
+    mm, cc = post.mean_and_cov(g["xs"])
+    np.testing.assert_allclose(mm, g["post_mean"], atol=1e-8)
+    np.testing.assert_allclose(np.diag(cc), g["post_var"], atol=1e-9)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_vfe_vs_golden(agp, path):
+    g, f, fx, of, ofx = _golden(agp, path)
+    vfe = agp.VFE(f(g["z"], float(g["jitter"])))
+    assert agp.elbo(vfe, fx, g["y"]) == pytest.approx(float(g["elbo"]), rel=1e-8)
+    assert agp.approx_log_evidence(agp.DTC(vfe.fz), fx, g["y"]) == pytest.approx(float(g["dtc"]), rel=1e-8)
+    ap = agp.posterior(vfe, fx, g["y"])
+    assert _relnorm(ap.data["alpha"], g["vfe_alpha"]) <= 1e-5  # α carries cond(K_zz) at jitter 1e-6
+    m, v = ap.mean_and_var(g["xs"])
+    np.testing.assert_allclose(m, g["vfe_mean"], atol=1e-7)
+    np.testing.assert_allclose(v, g["vfe_var"], atol=1e-7)
+
+
+@pytest.mark.parametrize("n,d,kind,layout", [(1000, 3, 0, "row"), (777, 8, 2, "col"), (2048, 1, 3, "vec"),
+                                             (4099, 3, 0, "row")])
+def test_mid_size_parity(agp, n, d, kind, layout):
+    """ragged N (padding), all input layouts, outer-panel loop + look-ahead (N > nb)."""
+    x, y = o.synth_inputs(n, d, 100 + n)
+    scale = 0.7
+    of = o.GP(o.Kernel(kind, 1.0, scale))
+    ref_lp, ref_post = o.logpdf_and_posterior(o.FiniteGP(of, x, 0.01), y)
+    xin = x if d == 1 else (agp.RowVecs(x) if layout == "row" else agp.ColVecs(x.T.copy()))
+    ctx = agp.default_context()
+    ctx.set_param("nb", 1024)
+    try:
+        f = agp.GP(agp.Kernel(kind) @ agp.ScaleTransform(scale))
+        post = agp.posterior(f(xin, 0.01), y)
+    finally:
+        ctx.set_param("nb", 2048)
+    assert post.logpdf_value == pytest.approx(ref_lp, rel=1e-10)
+    assert _relnorm(post.data.alpha, ref_post.alpha) <= 1e-8
+    xs = x[:130] + 0.05
+    m, v = post.mean_and_var(xs if d == 1 else agp.RowVecs(xs))
+    mo, vo = ref_post.mean_and_var(xs)
+    np.testing.assert_allclose(m, mo, atol=1e-8)
+    np.testing.assert_allclose(v, vo, atol=1e-9)
+
+
+def test_variants_agree(agp):
+    """MFMA gemm vs the VALU debug gemm, look-ahead on/off, recursive-only: same answer."""
+    x, y = o.synth_inputs(3000, 3, 9)
+    f = agp.GP(agp.SqExponentialKernel())
+    ctx = agp.default_context()
+    vals = []
+    try:
+        for nb, la, var in [(2048, 1, 0), (1024, 0, 0), (0, 0, 0), (1024, 1, 1)]:
+            ctx.set_param("nb", nb), ctx.set_param("lookahead", la), ctx.set_param("gemm_variant", var)
+            vals.append(float(agp.logpdf(f(agp.RowVecs(x), 0.01), y)))
+    finally:
+        ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("gemm_variant", 0)
+    ref = float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y))
+    for v in vals:
+        assert v == pytest.approx(ref, rel=1e-10)
+
+
+def test_posdef_exception(agp):
+    """Not-PD surfaces as PosDefException(info) like cholesky at src/finite_gp_projection.jl:308."""
+    x = np.zeros(300)
+    x[150:] = np.linspace(0, 1, 150)
+    f = agp.GP(agp.SqExponentialKernel())
+    with pytest.raises(agp.PosDefException) as e:
+        agp.logpdf(f(x, -0.5), np.zeros(300))  # K + (-0.5) I is indefinite
+    assert 1 <= e.value.info <= 300
+
+
+def test_float32_type_stability_and_accuracy(agp):
+    """Float32 in -> Float32 out (test/finite_gp_projection.jl:180-191); value within fp32 tolerance."""
+    x, y = o.synth_inputs(1500, 2, 11)
+    f = agp.GP(agp.Matern52Kernel())
+    lp32 = agp.logpdf(f(agp.RowVecs(x.astype(np.float32)), np.float32(0.1)), y.astype(np.float32))
+    assert isinstance(lp32, np.float32)
+    ref = o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.MATERN52)), x, 0.1), y)
+    assert float(lp32) == pytest.approx(ref, rel=1e-4)
+
+
+def test_interpolation_and_noise_vector(agp):
+    """test/exact_gpr_posterior.jl:14-22: posterior interpolates with tiny noise; vector noise accepted."""
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.uniform(-3, 3, 40))
+    y = np.sin(x)
+    post = agp.posterior(agp.GP(agp.Matern32Kernel())(x, 1e-12), y)
+    m, v = post.mean_and_var(x)
+    np.testing.assert_allclose(m, y, atol=1e-7)
+    np.testing.assert_allclose(v, 0, atol=1e-7)
+    s2 = 0.01 + 0.1 * rng.random(40)
+    lp = agp.logpdf(agp.GP(agp.Matern32Kernel())(x, s2), y)
+    assert lp == pytest.approx(o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.MATERN32)), x, s2), y), rel=1e-10)
+
+
+def test_elbo_z_equals_x_matches_logpdf(agp):
+    """src/util/TestUtils.jl:213-217: elbo(VFE(f(x, jitter)), fx, y) ≈ logpdf(fx, y), rtol = atol = 1e-5."""
+    x, y = o.synth_inputs(400, 1, 21)
+    f = agp.GP(agp.SqExponentialKernel())
+    fx = f(x, 0.1)
+    lp = agp.logpdf(fx, y)
+    assert agp.elbo(agp.VFE(f(x, 1e-7)), fx, y) == pytest.approx(lp, rel=1e-5, abs=1e-5)
+    z = np.linspace(-3, 3, 17)
+    assert agp.elbo(agp.VFE(f(z, 1e-9)), fx, y) < lp  # test/sparse_approximations.jl:99
+
+
+def test_vfe_fp32_streaming(agp):
+    """config-5 shape at reduced size: fp32 streamed SYRK + fp64 M×M side vs the fp64 oracle."""
+    rng = np.random.default_rng(5)
+    n, m = 20000, 256
+    X = rng.uniform(0, 4, (n, 3))
+    y = np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n)
+    z = X[rng.permutation(n)[:m]]
+    of = o.GP(o.Kernel(o.SE))
+    ref = o.elbo(of, z, 1e-4, o.FiniteGP(of, X, 0.1), y)
+    f = agp.GP(agp.SqExponentialKernel())
+    X32, y32, z32 = X.astype(np.float32), y.astype(np.float32), z.astype(np.float32)
+    got = agp.elbo(agp.VFE(f(agp.RowVecs(z32), 1e-4)), f(agp.RowVecs(X32), np.float32(0.1)), y32)
+    assert isinstance(got, np.float32)
+    assert float(got) == pytest.approx(ref, rel=1e-4)
+    got64 = agp.elbo(agp.VFE(f(agp.RowVecs(z), 1e-4)), f(agp.RowVecs(X), 0.1), y)
+    assert got64 == pytest.approx(ref, rel=1e-7)

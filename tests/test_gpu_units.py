@@ -1,0 +1,177 @@
+"""GPU: each HIP kernel family against a plain fp64 reference of the same op, through the C ABI's
+device-level entry points (gpd_*).  torch is used only for device memory / the reference matmul."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.fixture(scope="module")
+def lib(agp):
+    return agp._lib.load()
+
+
+@pytest.fixture(scope="module")
+def h(ctx):
+    return ctx.handle
+
+
+def _sync(lib, h):
+    from abstractgps_jl_amd._lib import check
+
+    check(lib.gpd_sync(h))
+
+
+def test_mfma_f64_lane_maps(lib, h):
+    """A=I-style check with ASYMMETRIC operands (cdna_hip_programming.md §3)."""
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((16, 4))
+    B = rng.standard_normal((4, 16))
+    D = np.zeros((16, 16))
+    assert lib.gp_probe_mfma_f64(h, A.ctypes.data, B.ctypes.data, D.ctypes.data) == 0
+    np.testing.assert_allclose(D, A @ B, rtol=1e-14, atol=1e-14)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 128, 64), (64, 64, 64), (192, 64, 128), (320, 448, 272),
+                                    (1024, 1024, 1024)])
+def test_gemm_nt_rect(lib, h, m, n, k):
+    from abstractgps_jl_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k)
+    ld = max(n, k) + 32
+    rows = max(m, n) + 128  # slack rows for the over-read contract
+    A = torch.randn(rows, ld, dtype=torch.float64, device="cuda", generator=g)
+    B = torch.randn(rows, ld, dtype=torch.float64, device="cuda", generator=g)
+    Cm = torch.randn(rows, ld, dtype=torch.float64, device="cuda", generator=g)
+    ref = Cm.clone()
+    ref[:m, :n] -= A[:m, :k] @ B[:n, :k].T
+    torch.cuda.synchronize()
+    check(lib.gpd_gemm_nt(h, P(Cm), ld, P(A), ld, P(B), ld, m, n, k, None, 0, 0))
+    _sync(lib, h)
+    err = (Cm - ref).abs().max().item()
+    assert err <= 1e-12 * max(1.0, k ** 0.5) * 10, err
+    # nothing outside the m×n window was touched
+    assert torch.equal(Cm[m:], ref[m:]) and torch.equal(Cm[:, n:], ref[:, n:])
+
+
+@pytest.mark.parametrize("m,n,off", [(256, 256, 0), (320, 192, 64), (512, 128, 128)])
+def test_gemm_nt_lower_skips_upper(lib, h, m, n, off):
+    """lower mode: 64×64 sub-tiles strictly above the diagonal are not updated; everything on/below is."""
+    from abstractgps_jl_amd._lib import check, gp_grid
+
+    k = 64
+    g = torch.Generator(device="cuda").manual_seed(m + n + off)
+    ld = n + 32
+    A = torch.randn(m + 128, k + 32, dtype=torch.float64, device="cuda", generator=g)
+    B = torch.randn(n + 128, k + 32, dtype=torch.float64, device="cuda", generator=g)
+    Cm = torch.zeros(m + 128, ld, dtype=torch.float64, device="cuda")
+    full = -(A[:m, :k] @ B[:n, :k].T)
+    grid = gp_grid(1, 0, 1, 0, 1, 1)
+    torch.cuda.synchronize()
+    check(lib.gpd_gemm_nt(h, P(Cm), ld, P(A), k + 32, P(B), k + 32, m, n, k, C.byref(grid), off, off))
+    _sync(lib, h)
+    r = torch.arange(m, device="cuda")[:, None] + off
+    c = torch.arange(n, device="cuda")[None, :] + off
+    need = c <= r
+    got = Cm[:m, :n]
+    assert (got - full)[need].abs().max().item() < 1e-11
+    skipped = (c // 64) > (r // 64)
+    assert got[skipped].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("n,extra", [(64, 0), (64, 192), (128, 64), (192, 128), (256, 0), (1024, 256)])
+def test_potrf_and_trsm(lib, h, n, extra):
+    from abstractgps_jl_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(n + extra)
+    m = n + extra
+    ld = n + 32
+    G = torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)
+    S = G @ G.T / n + torch.eye(n, dtype=torch.float64, device="cuda")
+    X = torch.randn(extra, n, dtype=torch.float64, device="cuda", generator=g)
+    A = torch.full((m + 128, ld), float("nan"), dtype=torch.float64, device="cuda")
+    A[:n, :n] = S
+    A[n:m, :n] = X
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    logdet = torch.zeros(1, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    check(lib.gpd_potrf(h, P(A), ld, m, n, P(info), 0, n, P(logdet)))
+    _sync(lib, h)
+    L = torch.linalg.cholesky(S)
+    assert info.item() == 0
+    got = torch.tril(A[:n, :n])
+    assert (got - L).abs().max().item() < 1e-11
+    assert abs(logdet.item() - torch.log(torch.diagonal(L)).sum().item()) < 1e-10
+    if extra:
+        ref = torch.linalg.solve_triangular(L, X.T, upper=False).T  # X L⁻ᵀ
+        assert (A[n:m, :n] - ref).abs().max().item() < 1e-10
+
+
+def test_potrf_reports_first_bad_pivot(lib, h):
+    from abstractgps_jl_amd._lib import check
+
+    n, ld = 256, 288
+    A = torch.zeros(n + 128, ld, dtype=torch.float64, device="cuda")
+    A[:n, :n] = torch.eye(n, dtype=torch.float64, device="cuda")
+    A[130, 130] = -2.0
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    check(lib.gpd_potrf(h, P(A), ld, n, n, P(info), 0, n, None))
+    _sync(lib, h)
+    assert info.item() == 131  # LAPACK-style 1-based leading-minor order
+
+
+@pytest.mark.parametrize("m,n", [(64, 64), (192, 256), (384, 1088)])
+def test_trsm_rec(lib, h, m, n):
+    from abstractgps_jl_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(m + n)
+    G = torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)
+    L = torch.linalg.cholesky(G @ G.T / n + torch.eye(n, dtype=torch.float64, device="cuda"))
+    ld = n + 32
+    Lp = torch.zeros(n + 128, ld, dtype=torch.float64, device="cuda")
+    Lp[:n, :n] = L
+    X = torch.randn(m + 128, ld, dtype=torch.float64, device="cuda", generator=g)
+    ref = torch.linalg.solve_triangular(L, X[:m, :n].T, upper=False).T
+    torch.cuda.synchronize()
+    check(lib.gpd_trsm(h, P(X), ld, m, P(Lp), ld, n))
+    _sync(lib, h)
+    assert (X[:m, :n] - ref).abs().max().item() < 1e-10
+
+
+@pytest.mark.parametrize("np_,nrhs", [(128, 1), (1024, 2), (2432, 1), (4096, 3)])
+def test_trsv_forward_backward(lib, h, np_, nrhs):
+    from abstractgps_jl_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(np_)
+    G = torch.randn(np_, np_, dtype=torch.float64, device="cuda", generator=g)
+    L = torch.linalg.cholesky(G @ G.T / np_ + torch.eye(np_, dtype=torch.float64, device="cuda"))
+    ld = np_ + 32
+    Lp = torch.full((np_, ld), float("nan"), dtype=torch.float64, device="cuda")
+    Lp[:, :np_] = torch.tril(L) + torch.triu(torch.full_like(L, float("nan")), 1)  # upper part must never be read
+    R = torch.randn(nrhs, np_, dtype=torch.float64, device="cuda", generator=g)
+    for fwd in (1, 0):
+        W = R.clone()
+        torch.cuda.synchronize()
+        check(lib.gpd_trsv(h, P(Lp), ld, np_, P(W), np_, nrhs, fwd))
+        _sync(lib, h)
+        ref = torch.linalg.solve_triangular(L if fwd else L.T, R.T, upper=not fwd).T
+        assert (W - ref).abs().max().item() < 1e-9 * max(1.0, ref.abs().max().item()), (np_, fwd)
+
+
+def test_rowsumsq(lib, h):
+    from abstractgps_jl_amd._lib import check
+
+    X = torch.randn(5, 1000, dtype=torch.float64, device="cuda")
+    out = torch.zeros(5, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    check(lib.gpd_rowsumsq(h, P(X), 1000, 5, 777, P(out)))
+    _sync(lib, h)
+    np.testing.assert_allclose(out.cpu().numpy(), (X[:, :777] ** 2).sum(1).cpu().numpy(), rtol=1e-13)

@@ -1,0 +1,151 @@
+"""CPU: pins the oracle (oracle/gp_oracle.py) against the identities the reference's own tests assert,
+using independent implementations, against a 60-digit mpmath evaluation, and against tests/golden/.
+Reference test file:line is cited per test (paths relative to the upstream repo)."""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.stats
+
+from oracle import gp_oracle as o
+from oracle import mp_check
+
+GOLDEN = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
+
+
+def _case(path):
+    g = np.load(path)
+    scale = None if np.isnan(g["scale"]).all() else (float(g["scale"]) if g["scale"].ndim == 0 else g["scale"])
+    mean = None if np.isnan(g["mean"]) else float(g["mean"])
+    f = o.GP(o.Kernel(int(g["kind"]), float(g["variance"]), scale), mean)
+    s2 = float(g["sigma2"]) if g["sigma2"].ndim == 0 else g["sigma2"]
+    return g, f, o.FiniteGP(f, g["x"], s2)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_golden_reproduces(path):
+    g, f, fx = _case(path)
+    assert o.logpdf(fx, g["y"]) == pytest.approx(float(g["logpdf"]), rel=1e-12)
+    np.testing.assert_allclose(o.logpdf(fx, g["Y"]), g["logpdf_Y"], rtol=1e-12)
+    post = o.posterior(fx, g["y"])
+    np.testing.assert_allclose(post.alpha, g["alpha"], rtol=1e-9, atol=1e-9)
+    m, v = post.mean_and_var(g["xs"])
+    np.testing.assert_allclose(m, g["post_mean"], atol=1e-10)
+    np.testing.assert_allclose(v, g["post_var"], atol=1e-10)
+    assert o.elbo(f, g["z"], float(g["jitter"]), fx, g["y"]) == pytest.approx(float(g["elbo"]), rel=1e-10)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_logpdf_vs_mvnormal(path):
+    """logpdf(fx, y) ≈ logpdf(MvNormal(mean, cov), y) — test/finite_gp_projection.jl:143; columns :147-150."""
+    g, f, fx = _case(path)
+    m, C = o.mean_and_cov(fx)
+    ref = scipy.stats.multivariate_normal(m, C, allow_singular=False).logpdf(g["y"])
+    assert o.logpdf(fx, g["y"]) == pytest.approx(ref, rel=1.5e-8)
+    lpY = o.logpdf(fx, g["Y"])
+    for s in range(g["Y"].shape[1]):
+        assert lpY[s] == pytest.approx(o.logpdf(fx, g["Y"][:, s]), rel=1e-12)
+
+
+def test_logpdf_vs_mpmath():
+    x, y = o.synth_inputs(20, 2, 7)
+    k = o.Kernel(o.MATERN52, 1.4, np.array([0.8, 1.3]))
+    s2 = 0.03
+    lp = o.logpdf(o.FiniteGP(o.GP(k, 0.2), x, s2), y)
+    lp_mp, a_mp = mp_check.logpdf_alpha(k.kind, k.variance, k.scale_vec(2).tolist(), x.tolist(), [s2] * 20, [0.2] * 20,
+                                        y.tolist())
+    assert lp == pytest.approx(lp_mp, rel=1e-12)
+    post = o.posterior(o.FiniteGP(o.GP(k, 0.2), x, s2), y)
+    np.testing.assert_allclose(post.alpha, a_mp, rtol=1e-9, atol=1e-10)
+
+
+def test_covmat_ops_identities():
+    """test/util/common_covmat_ops.jl:52-97 on a 5×5 SPD matrix."""
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((5, 5))
+    A = B @ B.T + np.eye(5)
+    U = o.cholesky_upper(A.copy())
+    np.testing.assert_allclose(U.T @ U, A, atol=1e-12)
+    X = rng.standard_normal((5, 3))
+    np.testing.assert_allclose(o.Xt_invA_X(U, X), X.T @ np.linalg.solve(A, X), atol=1e-12)  # :73
+    np.testing.assert_allclose(o.diag_Xt_invA_X(U, X), np.diag(X.T @ np.linalg.solve(A, X)), atol=1e-12)  # :92
+    assert o.tr_Xt_invA_X(U, X) == pytest.approx(np.trace(X.T @ np.linalg.solve(A, X)))
+    assert o.logdet_chol(U) == pytest.approx(np.linalg.slogdet(A)[1])
+
+
+def test_update_chol_matches_full():
+    """test/util/common_covmat_ops.jl:21-37 (atol 1e-5)."""
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((9, 9))
+    A = B @ B.T + 9 * np.eye(9)
+    U1 = o.cholesky_upper(A[:5, :5].copy())
+    U = o.update_chol(U1, A[:5, 5:], A[5:, 5:])
+    np.testing.assert_allclose(U, o.cholesky_upper(A.copy()), atol=1e-5)
+
+
+def test_posterior_interpolates():
+    """test/exact_gpr_posterior.jl:14-22: mean(f_post, x) ≈ y, var ≈ 0 with tiny noise."""
+    rng = np.random.default_rng(2)
+    x = np.sort(rng.uniform(-3, 3, 12))
+    y = np.sin(x)
+    post = o.posterior(o.FiniteGP(o.GP(o.Kernel(o.MATERN32)), x, 1e-12), y)
+    m, v = post.mean_and_var(x)
+    np.testing.assert_allclose(m, y, atol=1e-8)
+    np.testing.assert_allclose(v, 0, atol=1e-8)
+
+
+def test_sequential_conditioning_equals_batch():
+    """test/exact_gpr_posterior.jl:29-43 (atol 1e-5 on C.U, α, δ)."""
+    x, y = o.synth_inputs(40, 1, 3)
+    f = o.GP(o.Kernel(o.SE))
+    batch = o.posterior(o.FiniteGP(f, x, 0.1), y)
+    p1 = o.posterior(o.FiniteGP(f, x[:25], 0.1), y[:25])
+    p2 = o.posterior(o.FiniteGP(p1, x[25:], 0.1), y[25:])
+    np.testing.assert_allclose(p2.U, batch.U, atol=1e-5)
+    np.testing.assert_allclose(p2.alpha, batch.alpha, atol=1e-5)
+    np.testing.assert_allclose(p2.delta, batch.delta, atol=1e-5)
+
+
+def test_vfe_z_equals_x_matches_exact():
+    """test/sparse_approximations.jl:20-25, :94; src/util/TestUtils.jl:213-217 (rtol=atol=1e-5)."""
+    x, y = o.synth_inputs(60, 1, 4)
+    f = o.GP(o.Kernel(o.SE))
+    fx = o.FiniteGP(f, x, 0.1)
+    exact = o.posterior(fx, y)
+    ap = o.vfe_posterior(f, x, 1e-9, fx, y)
+    xs = np.linspace(-2, 2, 100)
+    np.testing.assert_allclose(ap.mean(xs), exact.mean(xs), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(ap.cov(xs), exact.cov(xs), atol=1e-5, rtol=1e-5)
+    lp = o.logpdf(fx, y)
+    assert o.elbo(f, x, 1e-9, fx, y) == pytest.approx(lp, rel=1e-5, abs=1e-5)
+    assert o.dtc_log_evidence(f, x, 1e-9, fx, y) == pytest.approx(lp, rel=1e-5, abs=1e-5)
+
+
+def test_elbo_below_logpdf_and_dtc_doctest():
+    """elbo(z≠x) < logpdf — test/sparse_approximations.jl:99; DTC doctest src/sparse_approximations.jl:263-276."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(300)
+    f = o.GP(o.Kernel(o.MATERN52))
+    K = o.kernelmatrix(f.kernel, x) + 0.1 * np.eye(300)
+    y = np.linalg.cholesky(K) @ rng.standard_normal(300)
+    fx = o.FiniteGP(f, x, 0.1)
+    lp = o.logpdf(fx, y)
+    assert o.elbo(f, np.linspace(-5, 5, 13), 1e-12, fx, y) < lp
+    assert o.dtc_log_evidence(f, np.linspace(-5, 5, 256), 1e-10, fx, y) == pytest.approx(lp, rel=1e-6, abs=1e-6)
+
+
+def test_posdef_exception_info():
+    """cholesky throws PosDefException(info) — src/finite_gp_projection.jl:308."""
+    A = np.eye(4)
+    A[2, 2] = -1.0
+    with pytest.raises(o.PosDefException) as e:
+        o.cholesky_upper(A)
+    assert e.value.info == 3
+
+
+def test_float32_type_stability():
+    """logpdf(fx, y) isa T — test/finite_gp_projection.jl:180-191."""
+    x, y = o.synth_inputs(30, 1, 6, dtype=np.float32)
+    lp = o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, np.float32(0.1)), y, dtype=np.float32)
+    assert lp.dtype == np.float32
