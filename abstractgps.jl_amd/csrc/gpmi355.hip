@@ -176,13 +176,12 @@ static int32_t ctx_scal(gp_ctx* c, long n) {
 // launches
 // ------------------------------------------------------------------------------------------------
 static double lower_count(long M, long N, long row0, long col0) {
-    // number of (r, c) in [row0,row0+M) × [col0,col0+N) with c <= r
-    double cnt = 0;
-    for (long r = row0; r < row0 + M; ++r) {
-        long hi = std::min(col0 + N - 1, r);
-        if (hi >= col0) cnt += (double)(hi - col0 + 1);
-    }
-    return cnt;
+    // number of (r, c) in [row0,row0+M) × [col0,col0+N) with c <= r  (closed form)
+    const long a = row0 - col0 + 1;  // count in the first row before clamping to [0, N]
+    const long i1 = std::min(std::max(1 - a, 0L), M);           // rows contributing 0
+    const long i2 = std::max(i1, std::min(std::max(N - a, 0L), M));  // rows from i2 on contribute N
+    const double mid = (double)(i2 - i1) * (double)a + 0.5 * (double)(i1 + i2 - 1) * (double)(i2 - i1);
+    return mid + (double)(M - i2) * (double)N;
 }
 
 template <typename T>
