@@ -79,6 +79,7 @@ struct gp_ctx {
     std::vector<GemmRec> gemm_recs;
     hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
     int* info_dev = nullptr;
+    void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
     double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
     long scal_cap = 0;
     int refs = 1;
@@ -148,6 +149,7 @@ static void ctx_unref(gp_ctx* c) {
     for (auto e : c->ev_phase)
         if (e) (void)hipEventDestroy(e);
     if (c->info_dev) (void)hipFree(c->info_dev);
+    if (c->lt_ws) (void)hipFree(c->lt_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
@@ -186,7 +188,7 @@ static double lower_count(long M, long N, long row0, long col0) {
 
 template <typename T>
 static int32_t launch_gemm(gp_ctx* c, hipStream_t s, T* C, long ldc, const T* A, long lda, const T* B, long ldb,
-                           long M, long N, long K, GridMap g) {
+                           long M, long N, long K, GridMap g, bool kmajor = false) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     gp_ctx::GemmRec rec{};
     const bool timed = c->time_kernels != 0;
@@ -199,12 +201,20 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, T* C, long ldc, const T* A,
     }
     if (c->gemm_variant == 0) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
-        hipLaunchKernelGGL(gemm_nt_sub_kernel<T>, grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
-                           (int)K, g);
+        if (kmajor)
+            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
+                               (int)N, (int)K, g);
+        else
+            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, false>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
+                               (int)N, (int)K, g);
     } else {
         dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16));
-        hipLaunchKernelGGL(gemm_nt_sub_ref_kernel<T>, grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
-                           (int)K, g);
+        if (kmajor)
+            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, true>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
+                               (int)N, (int)K, g);
+        else
+            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, false>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb,
+                               (int)M, (int)N, (int)K, g);
     }
     HIPCHK(hipGetLastError());
     if (timed) {
@@ -236,13 +246,15 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
                          long gcol0, long n_valid, double* logdet_dev) {
     if (n <= 64) {
         T* d = A + j0 * lda + j0;
-        hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(64), 0, s, d, lda, info_dev, (int)(gcol0 + j0),
-                           (int)n_valid, logdet_dev);
-        HIPCHK(hipGetLastError());
+        if (!c->lt_ws) HIPCHK(hipMalloc(&c->lt_ws, sizeof(double) * 64 * 64));
         const long mrows = mtot - j0 - 64;
+        T* lt = mrows > 0 ? (T*)c->lt_ws : (T*)nullptr;
+        hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(64), 0, s, d, lda, info_dev, (int)(gcol0 + j0),
+                           (int)n_valid, logdet_dev, lt);
+        HIPCHK(hipGetLastError());
         if (mrows > 0) {
-            hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((mrows + 255) / 256)), dim3(256), 0, s,
-                               A + (j0 + 64) * lda + j0, lda, (int)mrows, d, lda);
+            hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((mrows + 63) / 64)), dim3(64), 0, s,
+                               A + (j0 + 64) * lda + j0, lda, (int)mrows, d, lda, (const T*)lt);
             HIPCHK(hipGetLastError());
         }
         return 0;
@@ -259,8 +271,8 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
 template <typename T>
 static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
     if (n <= 64) {
-        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, X, ldx, (int)M, L,
-                           ldl);
+        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, X, ldx, (int)M, L, ldl,
+                           (const T*)nullptr);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -424,7 +436,7 @@ template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k,
     GridMap g = plain_map(1, 0, 0);
     dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
     hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, A, ld, xs_dev, ldx, xs_dev, ldx, d, k->kind,
-                       (T)k->variance, noise_dev, n, n, 1, g, (const T*)nullptr);
+                       (T)k->variance, noise_dev, n, n, 1, g, (const T*)nullptr, (const T*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -610,7 +622,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
                 dim3 grid((unsigned)(np / 128), (unsigned)(rows / 128));
                 hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, X, ldx, (const T*)xs_v, nsp,
                                    (const T*)post->xs, np, d, post->kind, (T)post->variance, (const T*)nullptr, ns, n,
-                                   0, g, (const T*)nullptr);
+                                   0, g, (const T*)nullptr, (const T*)nullptr);
                 HIPCHK(hipGetLastError());
                 RC(trsm_rec<T>(c, c->sm, X, ldx, rows, A, ld, np));
                 if (what & 2) {
@@ -633,7 +645,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
                 dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
                 hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, Cm, ldc, (const T*)xs_v, nsp,
                                    (const T*)xs_v, nsp, d, post->kind, (T)post->variance, (const T*)nullptr, ns, ns,
-                                   0, g, (const T*)nullptr);
+                                   0, g, (const T*)nullptr, (const T*)nullptr);
                 HIPCHK(hipGetLastError());
                 RC(launch_gemm<T>(c, c->sm, Cm, ldc, X, ldx, X, ldx, nsp, nsp, np, plain_map(0, 0, 0)));
                 // symmetric: row-major == column-major
@@ -763,7 +775,7 @@ int32_t gp_kernelmatrix(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
             dim3 grid((unsigned)(np / 128), (unsigned)(mp / 128));
             hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, (T*)K_v, ld, (const T*)(y ? xr_v : xc_v),
                                y ? mp : np, (const T*)xc_v, np, x->d, k->kind, (T)k->variance, (const T*)nullptr, m, n,
-                               0, g, (const T*)nullptr);
+                               0, g, (const T*)nullptr, (const T*)nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpy2DAsync(out, sizeof(T) * n, K_v, sizeof(T) * ld, sizeof(T) * n, m, hipMemcpyDeviceToHost,
                                     c->sm));
@@ -999,15 +1011,19 @@ int32_t gp_bench_mfma_f64(gp_ctx* c, int32_t iters, double* tflops_out) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
-    const int blocks = 256 * 2;
-    hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(blocks), dim3(256), 0, c->sm, buf, 16);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount;  // one 1024-thread block per CU
+    const size_t smem = 96 * 1024;
+    HIPCHK(hipFuncSetAttribute((const void*)mfma_rate_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(blocks), dim3(1024), smem, c->sm, buf, 64);
     HIPCHK(hipEventRecord(a, c->sm));
-    hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(blocks), dim3(256), 0, c->sm, buf, iters);
+    hipLaunchKernelGGL(mfma_rate_f64_kernel, dim3(blocks), dim3(1024), smem, c->sm, buf, iters);
     HIPCHK(hipEventRecord(b, c->sm));
     HIPCHK(hipStreamSynchronize(c->sm));
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    const double flops = (double)blocks * 16.0 * (double)iters * 4.0 * 2.0 * 16 * 16 * 4;
     *tflops_out = flops / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
@@ -1038,7 +1054,7 @@ int32_t gpd_assemble(gp_ctx* c, const gp_kernel* k, const double* x_dev, int64_t
     dim3 grid((unsigned)(n_loc / 128), (unsigned)(m_loc / 128));
     if (grid.x == 0 || grid.y == 0) return 0;
     hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, c->sm, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d,
-                       k->kind, k->variance, noise_dev, n_valid, n_valid, 1, m, (const double*)nullptr);
+                       k->kind, k->variance, noise_dev, n_valid, n_valid, 1, m, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1070,6 +1086,15 @@ int32_t gpd_gemm_nt(gp_ctx* c, double* cm, int64_t ldc, const double* a, int64_t
     return launch_gemm<double>(c, c->sm, cm, ldc, a, lda, b, ldb, m, n, k, to_map(g, row0, col0));
 }
 
+int32_t gpd_gemm_tn(gp_ctx* c, double* cm, int64_t ldc, const double* a, int64_t lda, const double* b, int64_t ldb,
+                    int64_t m, int64_t n, int64_t k, int32_t lower) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (m % 64 || n % 64 || k % 16) return set_arg_err(8, "m, n multiples of 64 and k multiple of 16 required");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return launch_gemm<double>(c, c->sm, cm, ldc, a, lda, b, ldb, m, n, k, plain_map(lower != 0, 0, 0), true);
+}
+
 int32_t gpd_trsv(gp_ctx* c, const double* lmat, int64_t ldl, int64_t np, double* r, int64_t ldr, int32_t nrhs,
                  int32_t forward) {
     if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
@@ -1077,6 +1102,17 @@ int32_t gpd_trsv(gp_ctx* c, const double* lmat, int64_t ldl, int64_t np, double*
     std::lock_guard<std::mutex> l(c->mu);
     HIPCHK(hipSetDevice(c->device));
     return trsv<double>(c, c->sm, lmat, ldl, np, r, ldr, nrhs, forward != 0);
+}
+
+int32_t gpd_gemv_t(gp_ctx* c, const double* lmat, int64_t ldl, int64_t nrows, int64_t ncols, const double* a, double* r) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (nrows <= 0 || ncols <= 0) return 0;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(gemv_t_kernel<double>, dim3((unsigned)((ncols + 255) / 256), (unsigned)((nrows + 63) / 64)), dim3(256),
+                       0, c->sm, lmat, ldl, nrows, ncols, a, r);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int32_t gpd_rowsumsq(gp_ctx* c, const double* x, int64_t ldx, int64_t nrows, int64_t ncols, double* out_dev) {

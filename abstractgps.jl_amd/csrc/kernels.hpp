@@ -76,7 +76,7 @@ __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_swz(int c) { return (c & 3) | ((c & 4) ? 12 : 0); }
 
-template <typename T>
+template <typename T, bool KM>
 __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, long ldc, const T* __restrict__ A,
                                                               long lda, const T* __restrict__ B, long ldb, int M,
                                                               int N, int K, GridMap g) {
@@ -101,12 +101,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, 
     bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
     if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
 
-    // staging map: thread -> (chunk lp, rows lr + 32 i)
-    const int lp = tid & 7, lr = tid >> 3;
+    // staging map.  NT (KM=false): operands are [rows][k] with k contiguous; thread -> (chunk lp, rows lr + 32 i),
+    // one 16-B global load = one LDS chunk.  KM=true: operands are k-major, A[k][m] / B[k][n] with m / n
+    // contiguous (C -= AᵀB, e.g. the SYRK over data points of the VFE path); thread -> (chunk lp = tid>>5,
+    // VEC consecutive rows starting at (lq + 32 i)·VEC); VEC 16-B loads (k rows lp·VEC + r) are transposed
+    // VEC×VEC in registers into VEC LDS chunks.  Either way 4 chunks per operand per thread.
+    constexpr int NPASS = KM ? 128 / (32 * VEC) : 4;
+    constexpr int NLD = KM ? VEC : 1;
+    const int lp = KM ? (tid >> 5) : (tid & 7);
+    const int lr = KM ? (tid & 31) : (tid >> 3);
     const int fsw = lds_swz(lp);
-    const T* Ag = A + (long)(m0 + lr) * lda + lp * VEC;
-    const T* Bg = B + (long)(n0 + lr) * ldb + lp * VEC;
-    chunk_t ra[4], rb[4];
+    const T* Ag = KM ? A + (long)(lp * VEC) * lda + m0 + lr * VEC : A + (long)(m0 + lr) * lda + lp * VEC;
+    const T* Bg = KM ? B + (long)(lp * VEC) * ldb + n0 + lr * VEC : B + (long)(n0 + lr) * ldb + lp * VEC;
+    chunk_t ra[NPASS][NLD], rb[NPASS][NLD];
+    auto gload = [&](long kt) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) {
+                if constexpr (KM) {
+                    ra[i][r] = *reinterpret_cast<const chunk_t*>(Ag + (kt * BK + r) * lda + 32 * VEC * i);
+                    rb[i][r] = *reinterpret_cast<const chunk_t*>(Bg + (kt * BK + r) * ldb + 32 * VEC * i);
+                } else {
+                    ra[i][r] = *reinterpret_cast<const chunk_t*>(Ag + (long)(32 * i) * lda + kt * BK);
+                    rb[i][r] = *reinterpret_cast<const chunk_t*>(Bg + (long)(32 * i) * ldb + kt * BK);
+                }
+            }
+    };
 
     acc_t acc[4][4];
 #pragma unroll
@@ -116,30 +137,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, 
 
     const int li = lane & 15, lg = lane >> 4;
     const int nk = K / BK;
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            if constexpr (KM) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    chunk_t ca, cb;
+#pragma unroll
+                    for (int r = 0; r < VEC; ++r) {
+                        ca[r] = ra[i][r][e];
+                        cb[r] = rb[i][r][e];
+                    }
+                    As[buf][lp][((lr + 32 * i) * VEC + e) ^ fsw] = ca;
+                    Bs[buf][lp][((lr + 32 * i) * VEC + e) ^ fsw] = cb;
+                }
+            } else {
+                As[buf][lp][(lr + 32 * i) ^ fsw] = ra[i][0];
+                Bs[buf][lp][(lr + 32 * i) ^ fsw] = rb[i][0];
+            }
+        }
+    };
 
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const chunk_t*>(Ag + (long)(32 * i) * lda);
-        rb[i] = *reinterpret_cast<const chunk_t*>(Bg + (long)(32 * i) * ldb);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        As[0][lp][(lr + 32 * i) ^ fsw] = ra[i];
-        Bs[0][lp][(lr + 32 * i) ^ fsw] = rb[i];
-    }
+    gload(0);
+    sstore(0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
-        if (more) {
-            const long ko = (long)(kt + 1) * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const chunk_t*>(Ag + (long)(32 * i) * lda + ko);
-                rb[i] = *reinterpret_cast<const chunk_t*>(Bg + (long)(32 * i) * ldb + ko);
-            }
-        }
+        if (more) gload(kt + 1);
         if (active) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -159,13 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, 
                         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[mt][v], b[nt][v], acc[mt][nt]);
             }
         }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                As[cur ^ 1][lp][(lr + 32 * i) ^ fsw] = ra[i];
-                Bs[cur ^ 1][lp][(lr + 32 * i) ^ fsw] = rb[i];
-            }
-        }
+        if (more) sstore(cur ^ 1);
         __syncthreads();
     }
 
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, 
 }
 
 // Debug reference (gemm_variant = 1): same contract, plain VALU, one thread per C element.
-template <typename T>
+template <typename T, bool KM>
 __global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* __restrict__ C, long ldc, const T* __restrict__ A,
                                                                long lda, const T* __restrict__ B, long ldb, int M,
                                                                int N, int K, GridMap g) {
@@ -198,7 +219,8 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* __restrict__ C,
         if ((gc / 64) * 64 > (gr / 64) * 64 + 63) return;
     }
     T s = 0;
-    for (int k = 0; k < K; ++k) s += A[(long)row * lda + k] * B[(long)col * ldb + k];
+    for (int k = 0; k < K; ++k)
+        s += KM ? A[(long)k * lda + row] * B[(long)k * ldb + col] : A[(long)row * lda + k] * B[(long)col * ldb + k];
     C[(long)row * ldc + col] -= s;
 }
 
@@ -208,7 +230,8 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* __restrict__ C,
 //   128×128 tile per block; wave w owns rows w, w+4, ...; lane l owns columns 2l, 2l+1 so every
 //   store instruction writes one contiguous 1 KiB (f64) row segment.
 //   Padding (global index >= n_valid): identity when sym, zero otherwise.
-//   colscale (nullable): column j of the result is multiplied by colscale[j] (VFE: K_zx Σy^-1/2).
+//   colscale / rowscale (nullable): column j / row i of the result is multiplied by colscale[j] / rowscale[i]
+//   (VFE: Σy^-1/2 K_xz).
 // ------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T kappa(int kind, T d2) {
     if (kind == 0) return exp(T(-0.5) * d2);
@@ -226,7 +249,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
                                                     const T* __restrict__ xc, long ldxc, int d, int kind, T variance,
                                                     const T* __restrict__ noise, long nr_valid, long nc_valid, int sym,
-                                                    GridMap g, const T* __restrict__ colscale) {
+                                                    GridMap g, const T* __restrict__ colscale,
+                                                    const T* __restrict__ rowscale) {
     using pair_t = typename Tr<T>::pair_t;
     constexpr int DC = 16;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
@@ -282,6 +306,11 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
                 if (gj0 < nc_valid) v0 *= colscale[gj0];
                 if (gj1 < nc_valid) v1 *= colscale[gj1];
             }
+            if (rowscale != nullptr) {
+                const T rs = rowscale[gi];
+                v0 *= rs;
+                v1 *= rs;
+            }
         }
         pair_t o;
         o.x = v0;
@@ -297,9 +326,23 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
 //   (1-based) if a pivot is not > 0 (LAPACK dpotrf info), untouched otherwise.
 //   logdet_acc += Σ_c log L_cc over columns with global index < n_valid.
 // ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T fast_rsqrt(T x);
+template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
+    double r = __builtin_amdgcn_rsq(x);       // v_rsq_f64 estimate
+    r = r * fma(-0.5 * x * r, r, 1.5);        // two Newton steps -> full fp64 precision
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    r = r * fmaf(-0.5f * x * r, r, 1.5f);
+    return r;
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long lda, int* __restrict__ info, int col0,
-                                                       int n_valid, double* __restrict__ logdet_acc) {
+                                                       int n_valid, double* __restrict__ logdet_acc,
+                                                       T* __restrict__ lt_ws) {
     using chunk_t = typename Tr<T>::chunk_t;
     constexpr int VEC = Tr<T>::VEC;
     __shared__ __attribute__((aligned(16))) T colb[2][64];
@@ -313,15 +356,19 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
         for (int e = 0; e < VEC; ++e) a[VEC * t + e] = v[e];
     }
     int bad = 0;
-    T mydiag = T(1);
+    T mydiag = T(1), myrinv = T(1);
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         const T piv = __shfl(a[c], c, 64);  // pivot from lane c
         if (!(piv > T(0)) && bad == 0) bad = c + 1;
-        const T dd = sqrt(piv);
-        const T v = (r == c) ? dd : a[c] / dd;
+        const T ri = fast_rsqrt<T>(piv);     // 1 / L_cc
+        const T dd = piv * ri;               // L_cc
+        const T v = (r == c) ? dd : a[c] * ri;
         a[c] = v;
-        if (r == c) mydiag = dd;
+        if (r == c) {
+            mydiag = dd;
+            myrinv = ri;
+        }
         T* cb = colb[c & 1];
         cb[r] = v;
         __syncthreads();
@@ -332,6 +379,10 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
 #pragma unroll
     for (int t = 0; t < 64; ++t)
         if (t <= r) wrow[t] = a[t];
+    if (lt_ws != nullptr) {  // Lᵀ for trsm_64: lt[c][r] = L[r][c] (r > c), 1/L_cc on the diagonal, 0 above
+#pragma unroll
+        for (int c = 0; c < 64; ++c) lt_ws[c * 64 + r] = (c < r) ? a[c] : ((c == r) ? myrinv : T(0));
+    }
     double ldsum = (col0 + r < n_valid) ? log((double)mydiag) : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ldsum += __shfl_xor(ldsum, o, 64);
@@ -342,26 +393,39 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
 }
 
 // ------------------------------------------------------------------------------------------------
-// trsm_64: X[M×64] ← X · L⁻ᵀ, L 64×64 lower (row-major).  One thread per row of X (row in
-//   registers), Lᵀ in LDS so the column of L needed after x_c is final is a contiguous broadcast.
-//   M multiple of 64; blocks of 256 rows.
+// trsm_64: X[M×64] ← X · L⁻ᵀ, L 64×64 lower (row-major).  One lane per row of X (row in registers),
+//   one wave (64 rows) per block so that M = 65 536 rows spread as 4 waves per CU.  Lᵀ sits in LDS so the
+//   column of L needed after x_c is final is one contiguous broadcast read.  lt_pre (nullable): the
+//   transposed tile with reciprocal diagonal that potf2_64 just wrote (linear copy); otherwise it is
+//   built here from L.  M multiple of 64.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void trsm_64_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L,
-                                                       long ldl) {
-    __shared__ __attribute__((aligned(16))) T Lt[64][64];  // Lt[c][t] = L[t][c]
-    __shared__ T rdiag[64];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int t = e >> 6, c = e & 63;  // coalesced read of row t
-        Lt[c][t] = L[(long)t * ldl + c];
-    }
-    if (tid < 64) rdiag[tid] = T(1) / L[(long)tid * ldl + tid];
-    __syncthreads();
-    const int row = blockIdx.x * 256 + tid;
-    if (row >= M) return;
+__global__ __launch_bounds__(64) void trsm_64_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L,
+                                                      long ldl, const T* __restrict__ lt_pre) {
     using chunk_t = typename Tr<T>::chunk_t;
     constexpr int VEC = Tr<T>::VEC;
+    __shared__ __attribute__((aligned(16))) T Lt[64][64];  // Lt[c][t] = L[t][c]; Lt[c][c] = 1/L[c][c]
+    const int tid = threadIdx.x;
+    if (lt_pre != nullptr) {
+        const chunk_t* src = reinterpret_cast<const chunk_t*>(lt_pre);
+        chunk_t* dst = reinterpret_cast<chunk_t*>(&Lt[0][0]);
+#pragma unroll 8
+        for (int e = tid; e < 64 * 64 / VEC; e += 64) dst[e] = src[e];
+    } else {
+        const chunk_t* lrow = reinterpret_cast<const chunk_t*>(L + (long)tid * ldl);
+#pragma unroll
+        for (int t = 0; t < 64 / VEC; ++t) {
+            const chunk_t v = lrow[t];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int c = VEC * t + e;
+                Lt[c][tid] = (c == tid) ? T(1) / v[e] : v[e];
+            }
+        }
+    }
+    __syncthreads();
+    const int row = blockIdx.x * 64 + tid;
+    if (row >= M) return;
     chunk_t* xr = reinterpret_cast<chunk_t*>(X + (long)row * ldx);
     T x[64];
 #pragma unroll
@@ -372,7 +436,7 @@ __global__ __launch_bounds__(256) void trsm_64_kernel(T* __restrict__ X, long ld
     }
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
-        const T v = x[c] * rdiag[c];
+        const T v = x[c] * Lt[c][c];
         x[c] = v;
 #pragma unroll
         for (int t = c + 1; t < 64; ++t) x[t] = fma(-v, Lt[c][t], x[t]);
@@ -568,9 +632,21 @@ __global__ __launch_bounds__(256) void diag_shift_trace_kernel(double* __restric
     if (threadIdx.x == 0 && out) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n) {
+__global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, double scale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = (TD)src[i];
+    if (i < n) dst[i] = (TD)(scale * (double)src[i]);
+}
+// r[j] -= Σ_{i<nrows} L[i][j] a[i]  for j < ncols.  grid (ceil(ncols/256), ceil(nrows/64)); one atomic per (block, column)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_t_kernel(const T* __restrict__ L, long ldl, long nrows, long ncols,
+                                                      const T* __restrict__ a, T* __restrict__ r) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i0 = (long)blockIdx.y * 64;
+    if (j >= ncols) return;
+    const long i1 = (i0 + 64 < nrows) ? i0 + 64 : nrows;
+    T acc = 0;
+    for (long i = i0; i < i1; ++i) acc = fma(L[i * ldl + j], a[i], acc);
+    atomicAdd(r + j, -acc);
 }
 
 // MFMA layout / rate probe: D = A·B for one 16×16×4 tile (A row-major 16×4, B row-major 4×16).
@@ -580,18 +656,23 @@ __global__ void mfma_probe_f64_kernel(const double* A, const double* B, double* 
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], c, 0, 0, 0);
     for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
 }
-// Peak-rate microbenchmark: 4 waves per block, 8 independent accumulators, iters back-to-back MFMAs.
-__global__ __launch_bounds__(256) void mfma_rate_f64_kernel(double* out, int iters) {
-    d4_t acc[8];
-    for (int i = 0; i < 8; ++i) acc[i] = (d4_t)((double)i);
+// Peak-rate microbenchmark: one 1024-thread block per CU (a large dynamic-LDS request pins residency to
+// 1 block/CU), i.e. 4 waves per SIMD, 4 independent accumulators per wave, iters back-to-back MFMAs.
+__global__ __launch_bounds__(1024) void mfma_rate_f64_kernel(double* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rate_smem[];
+    d4_t acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4_t)((double)i);
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0;
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (s == 12345.678) out[0] = s;  // keep live
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) {
+        out[0] = s;  // keep live
+        rate_smem[threadIdx.x] = 1;
+    }
 }
 
 }  // namespace gpmi

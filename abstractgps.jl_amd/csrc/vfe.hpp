@@ -4,14 +4,15 @@
 //            approx_log_evidence / elbo              :248-254 (VFE), :282-286 (DTC), :289-305
 //            predictive mean / var                   :183-185, :192-195, :212-217
 //
-// Formulation (S = Σy^-1/2 diagonal, L_z L_zᵀ = K_zz + jitter·I, so U = L_zᵀ):
-//   the reference forms B = U⁻ᵀ (S K_xz)ᵀ (M×N, a TRSM over the long N dimension) and D = B Bᵀ + I.
-//   Here the N-long pass is ONE streamed SYRK:  G = (K_zx S)(K_zx S)ᵀ  accumulated over column chunks
-//   of W = K_zx S (kmat with a column scale → MFMA gemm_nt, dtype T = f32 or f64), and the triangular
-//   work moves to the small M×M side in fp64:  D = I + L_z⁻¹ G L_z⁻ᵀ  (two right-solves around a
-//   transpose).  This halves the N·M² flops and never holds an N×M matrix (one M×chunk tile is live).
-//   Vectors: v = K_zx S² δ (kvec), c = L_z⁻¹ v (= B b_y), w = L_D⁻¹ c, m_ε = L_D⁻ᵀ w, α = L_z⁻ᵀ m_ε.
-//   ‖A‖²_F = tr(D) − M (trace term of the ELBO, :251).
+// Formulation (S = Σy^-1/2 diagonal, L_z L_zᵀ = K_zz + jitter·I, so U = L_zᵀ), the reference's own:
+//   B = U⁻ᵀ (S K_xz)ᵀ,  D = B Bᵀ + I = Λ_ε,  c = B b_y,  m_ε = Λ_ε \ c,  α = U \ m_ε.
+//   The N-long pass is streamed in chunks of CH data points and never holds an N×M matrix:
+//     Xc  = S_c K(x_c, z)          kmat with a row scale                (CH × M, dtype T)
+//     Xc ← Xc L_z⁻ᵀ = B_cᵀ          trsm_rec (MFMA gemm inside)
+//     D_acc −= Xcᵀ Xc               MFMA gemm, k-major operands (SYRK over the data points)
+//     c_acc −= Xcᵀ b_c              gemv_t
+//   (T = f32 or f64).  The M×M side (K_zz, both Choleskys, all vector solves) is always fp64: in fp32 mode
+//   L_z is rounded to fp32 for the streamed TRSM only.  ‖A‖²_F = tr(B Bᵀ) = −tr(D_acc) (ELBO trace term, :251).
 #pragma once
 
 struct gp_vfe {
@@ -38,8 +39,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     const int d = x->d;
     const long CH = 8192;                       // columns (data points) per streamed chunk
     const long npad = round_up(n, CH);
-    const long ld = mp + c->ldpad;              // M×M matrices
-    const long ldw = CH + c->ldpad;             // W chunk
+    const long ld = mp + c->ldpad;              // M×M matrices and the CH×M chunk
     const T* y = (const T*)yv;
     const T* mean = (const T*)mean_or_null;
 
@@ -55,44 +55,46 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     scale_points<T>(k, x, npad, xs_h);
     scale_points<T>(k, z, mp, zsT_h);
     std::vector<double> zsD_h(zsT_h.begin(), zsT_h.end());
-    std::vector<T> cs_h((size_t)npad, T(0)), t_h((size_t)npad, T(0));  // s_i = σ_i⁻¹ ; t_i = s_i² δ_i
+    std::vector<T> rs_h((size_t)npad, T(0)), b_h((size_t)npad, T(0));  // s_i = σ_i⁻¹ ; b_i = s_i δ_i  (b_y, :66)
     double logdet_sy = 0, dd = 0, tr_kff = 0;
     for (long i = 0; i < n; ++i) {
         const double s2 = noise->kind == 0 ? noise->s : (double)((const T*)noise->diag)[i];
         if (!(s2 > 0)) return 1 + (int32_t)i;  // chol(Σy) fails at i (reference :61 / :296)
         const double delta = (double)(T)(y[i] - (mean ? mean[i] : T(0)));
-        cs_h[i] = (T)(1.0 / std::sqrt(s2));
-        t_h[i] = (T)(delta / s2);
+        const double si = 1.0 / std::sqrt(s2);
+        rs_h[i] = (T)si;
+        b_h[i] = (T)(delta * si);
         logdet_sy += std::log(s2);
-        dd += delta * delta / s2;
+        dd += (double)b_h[i] * (double)b_h[i];
         tr_kff += k->variance / s2;  // tr_Cf_invΣy :307-313
     }
     std::vector<double> jit_h((size_t)mp, 0.0);
     for (long i = 0; i < m; ++i) jit_h[i] = jitter;
 
     const size_t xs_b = sizeof(T) * xs_h.size(), zsT_b = sizeof(T) * zsT_h.size(), zsD_b = sizeof(double) * zsD_h.size();
-    const size_t cs_b = sizeof(T) * (size_t)npad, G_b = sizeof(T) * (size_t)(mp + 128) * ld;
-    const size_t W_b = sizeof(T) * (size_t)(mp + 128) * ldw, L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
+    const size_t rs_b = sizeof(T) * (size_t)npad, D_b = sizeof(T) * (size_t)(mp + 128) * ld;
+    const size_t X_b = sizeof(T) * (size_t)(CH + 128) * ld, L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
     const size_t vT_b = sizeof(T) * (size_t)mp, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
-    void *xs_v = 0, *zsT_v = 0, *zsD_v = 0, *cs_v = 0, *t_v = 0, *G_v = 0, *W_v = 0, *Lz_v = 0, *Ld_v = 0, *Y_v = 0, *vT_v = 0,
+    void *xs_v = 0, *zsT_v = 0, *zsD_v = 0, *rs_v = 0, *b_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *LzT_v = 0, *cT_v = 0,
          *vec_v = 0, *jit_v = 0;
+    constexpr bool is_f64 = sizeof(T) == 8;
     RC(ctx_alloc(c, xs_b, &xs_v));
     RC(ctx_alloc(c, zsT_b, &zsT_v));
     RC(ctx_alloc(c, zsD_b, &zsD_v));
-    RC(ctx_alloc(c, cs_b, &cs_v));
-    RC(ctx_alloc(c, cs_b, &t_v));
-    RC(ctx_alloc(c, G_b, &G_v));
-    RC(ctx_alloc(c, W_b, &W_v));
+    RC(ctx_alloc(c, rs_b, &rs_v));
+    RC(ctx_alloc(c, rs_b, &b_v));
+    RC(ctx_alloc(c, D_b, &D_v));
+    RC(ctx_alloc(c, X_b, &X_v));
     RC(ctx_alloc(c, L_b, &Lz_v));
     RC(ctx_alloc(c, L_b, &Ld_v));
-    RC(ctx_alloc(c, L_b, &Y_v));
-    RC(ctx_alloc(c, vT_b, &vT_v));
+    if (!is_f64) RC(ctx_alloc(c, D_b, &LzT_v));
+    RC(ctx_alloc(c, vT_b, &cT_v));
     RC(ctx_alloc(c, vD_b, &vec_v));
     RC(ctx_alloc(c, jit_b, &jit_v));
     double* Lz = (double*)Lz_v;
     double* Ld = (double*)Ld_v;
-    double* Yb = (double*)Y_v;
-    double* vec = (double*)vec_v;  // rows: [0] v→c , [1] w→m_ε , [2] α , [3] spare
+    double* vec = (double*)vec_v;  // rows: [0] c , [1] w→m_ε , [2] α , [3] spare
+    const T* LzT = is_f64 ? (const T*)Lz_v : (const T*)LzT_v;
     double scal_h[16] = {0};
     int info_h = 0;
     hipStream_t s = c->sm;
@@ -102,61 +104,62 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), xs_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(zsT_v, zsT_h.data(), zsT_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(zsD_v, zsD_h.data(), zsD_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(cs_v, cs_h.data(), cs_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(t_v, t_h.data(), cs_b, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(rs_v, rs_h.data(), rs_b, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b_v, b_h.data(), rs_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(jit_v, jit_h.data(), jit_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), s));
         HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * 16, s));
-        HIPCHK(hipMemsetAsync(G_v, 0, G_b, s));
+        HIPCHK(hipMemsetAsync(D_v, 0, D_b, s));
+        HIPCHK(hipMemsetAsync(cT_v, 0, vT_b, s));
         HIPCHK(hipMemsetAsync(vec_v, 0, vD_b, s));
-        // ---- streamed SYRK over the N data points: G_acc -= W Wᵀ, W = K(z, x_chunk) · S_chunk
-        for (long c0 = 0; c0 < npad; c0 += CH) {
-            GridMap g = plain_map(0, 0, c0);
-            dim3 grid((unsigned)(CH / 128), (unsigned)(mp / 128));
-            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, (T*)W_v, ldw, (const T*)zsT_v, mp, (const T*)xs_v,
-                               npad, d, k->kind, (T)k->variance, (const T*)nullptr, m, n, 0, g, (const T*)cs_v);
-            HIPCHK(hipGetLastError());
-            RC(launch_gemm<T>(c, s, (T*)G_v, ld, (const T*)W_v, ldw, (const T*)W_v, ldw, mp, mp, CH, plain_map(1, 0, 0)));
-        }
-        // v = K_zx S² δ
-        hipLaunchKernelGGL(kvec_kernel<T>, dim3((unsigned)m), dim3(256), 0, s, (const T*)zsT_v, mp, (const T*)xs_v, npad, d,
-                           k->kind, (T)k->variance, n, (const T*)t_v, (T*)vT_v);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((convert_kernel<T, double>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const T*)vT_v, vec,
-                           m);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev_phase[1], s));
-        // ---- M×M side, fp64.  L_z = chol(K_zz + jitter I)
+        // ---- L_z = chol(K_zz + jitter I), fp64                                                    :62
         {
             GridMap g = plain_map(1, 0, 0);
             dim3 grid((unsigned)(mp / 128), (unsigned)(mp / 128));
             hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Lz, ld, (const double*)zsD_v, mp,
                                (const double*)zsD_v, mp, d, k->kind, k->variance, (const double*)jit_v, m, m, 1, g,
-                               (const double*)nullptr);
+                               (const double*)nullptr, (const double*)nullptr);
             HIPCHK(hipGetLastError());
         }
         RC(potrf_full<double>(c, Lz, ld, mp, mp, c->info_dev, m, c->scal_dev + 0));
-        // G (symmetric, fp64) -> Y = G L_z⁻ᵀ -> Yᵀ -> Z = Yᵀ L_z⁻ᵀ = L_z⁻¹ G L_z⁻ᵀ -> D = Z + I
+        if (!is_f64) {
+            const long cnt = (mp + 128) * ld;
+            hipLaunchKernelGGL((convert_kernel<double, T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, Lz, (T*)LzT_v,
+                               cnt, 1.0);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->ev_phase[1], s));
+        // ---- streamed pass over the N data points                                                :64-71
+        for (long c0 = 0; c0 < npad; c0 += CH) {
+            GridMap g = plain_map(0, c0, 0);
+            dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
+            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, (T*)X_v, ld, (const T*)xs_v, npad, (const T*)zsT_v, mp, d,
+                               k->kind, (T)k->variance, (const T*)nullptr, n, m, 0, g, (const T*)nullptr, (const T*)rs_v);
+            HIPCHK(hipGetLastError());
+            RC(trsm_rec<T>(c, s, (T*)X_v, ld, CH, LzT, ld, mp));                                   // B_cᵀ
+            RC(launch_gemm<T>(c, s, (T*)D_v, ld, (const T*)X_v, ld, (const T*)X_v, ld, mp, mp, CH, plain_map(1, 0, 0), true));
+            hipLaunchKernelGGL(gemv_t_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(CH / 64)), dim3(256), 0, s,
+                               (const T*)X_v, ld, CH, mp, (const T*)b_v + c0, (T*)cT_v);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL((convert_kernel<T, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s, (const T*)cT_v, vec,
+                           mp, -1.0);                                                              // c = B b_y
+        HIPCHK(hipGetLastError());
+        // ---- D = I + B Bᵀ (fp64, symmetric), Λ_ε = chol(D)                                       :68-69
         hipLaunchKernelGGL(neg_sym_to_f64_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s,
-                           (const T*)G_v, ld, Yb, ld, mp);
+                           (const T*)D_v, ld, Ld, ld, mp);
         HIPCHK(hipGetLastError());
-        RC(trsm_rec<double>(c, s, Yb, ld, mp, Lz, ld, mp));
-        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, s, Yb, ld, Ld,
-                           ld, mp);
-        HIPCHK(hipGetLastError());
-        RC(trsm_rec<double>(c, s, Ld, ld, mp, Lz, ld, mp));
         hipLaunchKernelGGL(diag_shift_trace_kernel, dim3(1), dim3(256), 0, s, Ld, ld, mp, m, 1.0, c->scal_dev + 2);
         HIPCHK(hipGetLastError());
         RC(potrf_full<double>(c, Ld, ld, mp, mp, c->info_dev + 0, mp, c->scal_dev + 1));
         // ---- vectors
-        RC(trsv<double>(c, s, Lz, ld, mp, vec, mp, 1, true));                     // c = L_z⁻¹ v
         HIPCHK(hipMemcpyAsync(vec + mp, vec, sizeof(double) * mp, hipMemcpyDeviceToDevice, s));
         RC(trsv<double>(c, s, Ld, ld, mp, vec + mp, mp, 1, true));                // w = L_D⁻¹ c
         hipLaunchKernelGGL(rowsumsq_kernel<double>, dim3(1), dim3(256), 0, s, vec + mp, mp, mp, c->scal_dev + 3);
         HIPCHK(hipGetLastError());
-        RC(trsv<double>(c, s, Ld, ld, mp, vec + mp, mp, 1, false));               // m_ε = L_D⁻ᵀ w
+        RC(trsv<double>(c, s, Ld, ld, mp, vec + mp, mp, 1, false));               // m_ε = L_D⁻ᵀ w      :71
         HIPCHK(hipMemcpyAsync(vec + 2 * mp, vec + mp, sizeof(double) * mp, hipMemcpyDeviceToDevice, s));
-        RC(trsv<double>(c, s, Lz, ld, mp, vec + 2 * mp, mp, 1, false));           // α = L_z⁻ᵀ m_ε
+        RC(trsv<double>(c, s, Lz, ld, mp, vec + 2 * mp, mp, 1, false));           // α = L_z⁻ᵀ m_ε      :73
         HIPCHK(hipEventRecord(c->ev_phase[2], s));
         HIPCHK(hipEventRecord(c->ev_phase[3], s));
         HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -164,9 +167,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         HIPCHK(hipStreamSynchronize(s));
         float ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[1]));
-        c->tm.assemble_ms = ms;  // streamed kmat + SYRK phase
+        c->tm.assemble_ms = ms;  // K_zz + its Cholesky
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[1], c->ev_phase[2]));
-        c->tm.potrf_ms = ms;
+        c->tm.potrf_ms = ms;     // streamed pass + M×M side
         c->tm.solve_ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[3]));
         c->tm.total_ms = ms;
@@ -186,12 +189,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     }
     ctx_release(c, xs_v, xs_b);
     ctx_release(c, zsT_v, zsT_b);
-    ctx_release(c, cs_v, cs_b);
-    ctx_release(c, t_v, cs_b);
-    ctx_release(c, G_v, G_b);
-    ctx_release(c, W_v, W_b);
-    ctx_release(c, Y_v, L_b);
-    ctx_release(c, vT_v, vT_b);
+    ctx_release(c, rs_v, rs_b);
+    ctx_release(c, b_v, rs_b);
+    ctx_release(c, D_v, D_b);
+    ctx_release(c, X_v, X_b);
+    ctx_release(c, LzT_v, D_b);
+    ctx_release(c, cT_v, vT_b);
     ctx_release(c, jit_v, jit_b);
     if (rc == 0 && info_h != 0) rc = info_h;
     if (rc != 0 || !out) {
@@ -260,7 +263,7 @@ static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, 
             dim3 grid((unsigned)(mp / 128), (unsigned)(nsp / 128));
             hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, X, ld, (const double*)xs_v, nsp,
                                (const double*)p->zs, mp, d, p->kind, p->variance, (const double*)nullptr, ns, m, 0, g,
-                               (const double*)nullptr);
+                               (const double*)nullptr, (const double*)nullptr);
             HIPCHK(hipGetLastError());
             RC(trsm_rec<double>(c, s, X, ld, nsp, (const double*)p->Lz, ld, mp));
             hipLaunchKernelGGL(rowsumsq_kernel<double>, dim3((unsigned)nsp), dim3(256), 0, s, X, ld, mp, o + nsp);

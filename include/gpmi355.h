@@ -177,9 +177,16 @@ int32_t gpd_trsm(gp_ctx* ctx, double* x, int64_t ldx, int64_t m, const double* l
 int32_t gpd_gemm_nt(gp_ctx* ctx, double* c, int64_t ldc, const double* a, int64_t lda, const double* b,
                     int64_t ldb, int64_t m, int64_t n, int64_t k, const gp_grid* g_or_null, int64_t row0,
                     int64_t col0);
+/* C (m×n) -= Aᵀ · B with k-major operands: A is k×m, B is k×n (row-major) — the SYRK over data points of
+ * the VFE path.  lower != 0: 64×64 sub-tiles strictly above the diagonal of C are skipped. */
+int32_t gpd_gemm_tn(gp_ctx* ctx, double* c, int64_t ldc, const double* a, int64_t lda, const double* b,
+                    int64_t ldb, int64_t m, int64_t n, int64_t k, int32_t lower);
 /* nrhs vectors stored as rows r[s*ldr + i], i < np: forward (L z = r) or backward (Lᵀ a = r) solve in place. */
 int32_t gpd_trsv(gp_ctx* ctx, const double* l, int64_t ldl, int64_t np, double* r, int64_t ldr, int32_t nrhs,
                  int32_t forward);
+/* r[j] -= Σ_{i<nrows} l[i*ldl + j] · a[i]  for j < ncols  (block row of Lᵀ times a vector; backward sweep). */
+int32_t gpd_gemv_t(gp_ctx* ctx, const double* l, int64_t ldl, int64_t nrows, int64_t ncols, const double* a,
+                   double* r);
 /* out_dev[i] = Σ_{c<ncols} x[i*ldx + c]² for i < nrows. */
 int32_t gpd_rowsumsq(gp_ctx* ctx, const double* x, int64_t ldx, int64_t nrows, int64_t ncols, double* out_dev);
 int32_t gpd_sync(gp_ctx* ctx);
