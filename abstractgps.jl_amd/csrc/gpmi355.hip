@@ -79,6 +79,8 @@ struct gp_ctx {
     std::vector<GemmRec> gemm_recs;
     hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
     int* info_dev = nullptr;
+    void* w_ws = nullptr;        // I − inv(L_jj) tiles for the MFMA triangular solve (trtri_64 output)
+    size_t w_ws_bytes = 0;
     void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
     double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
     long scal_cap = 0;
@@ -150,6 +152,7 @@ static void ctx_unref(gp_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->info_dev) (void)hipFree(c->info_dev);
     if (c->lt_ws) (void)hipFree(c->lt_ws);
+    if (c->w_ws) (void)hipFree(c->w_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
@@ -201,6 +204,15 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, T* C, long ldc, const T* A,
     }
     if (c->gemm_variant == 0) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+        if (g.lower && g.P == 1 && g.Q == 1 && g.row0 >= g.col0) {  // enumerate only the tiles on/below the diagonal
+            const long tm = (M + 127) / 128, tn = (N + 127) / 128, dt = (g.row0 - g.col0 + 127) / 128;
+            const long tri = std::min(tm, std::max(0L, tn - dt));
+            const long total = tri * (dt + 1) + tri * (tri - 1) / 2 + (tm - tri) * tn;
+            g.compact = 1;
+            g.tn = (int)tn;
+            g.dt = (int)dt;
+            grid = dim3((unsigned)total, 1);
+        }
         if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
@@ -231,6 +243,9 @@ static GridMap plain_map(int lower, long row0, long col0) {
     g.nb = 128;
     g.row0 = row0;
     g.col0 = col0;
+    g.compact = 0;
+    g.tn = 0;
+    g.dt = 0;
     return g;
 }
 
@@ -267,72 +282,94 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
     return 0;
 }
 
-// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n multiple of 64, M multiple of 64).
+// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n multiple of 64, M multiple of 64), all-MFMA:
+// W_j = I − inv(L_jj) for every 64×64 diagonal tile (trtri_64, batched), then recursively
+//   left half;  X_right −= X_left · L_21ᵀ;  right half;   base case X_j ← X_j − X_j W_jᵀ (in-place gemm).
 template <typename T>
-static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
-    if (n <= 64) {
-        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, X, ldx, (int)M, L, ldl,
-                           (const T*)nullptr);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
+static int32_t trsm_rec_w(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n, const T* W) {
+    if (n <= 64) return launch_gemm<T>(c, s, X, ldx, X, ldx, W, 64, M, 64, 64, plain_map(0, 0, 0));
     const long h = split_half(n);
-    RC(trsm_rec<T>(c, s, X, ldx, M, L, ldl, h));
+    RC(trsm_rec_w<T>(c, s, X, ldx, M, L, ldl, h, W));
     RC(launch_gemm<T>(c, s, X + h, ldx, X, ldx, L + h * ldl, ldl, M, n - h, h, plain_map(0, 0, 0)));
-    RC(trsm_rec<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h));
+    RC(trsm_rec_w<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h, W + (h / 64) * 4096));
     return 0;
 }
+template <typename T> static int32_t trtri_tiles(gp_ctx* c, hipStream_t s, const T* L, long ldl, long n, T** Wout) {
+    const size_t need = sizeof(T) * (size_t)(n / 64 + 2) * 4096;  // + slack tiles (B-operand over-read of gemm_nt)
+    if (c->w_ws_bytes < need) {
+        HIPCHK(hipStreamSynchronize(c->sm));
+        HIPCHK(hipStreamSynchronize(c->sp));
+        if (c->w_ws) (void)hipFree(c->w_ws);
+        c->w_ws_bytes = 0;
+        HIPCHK(hipMalloc(&c->w_ws, need));
+        HIPCHK(hipMemset(c->w_ws, 0, need));
+        c->w_ws_bytes = need;
+    }
+    hipLaunchKernelGGL(trtri_64_kernel<T>, dim3((unsigned)(n / 64)), dim3(64), 0, s, L, ldl, (T*)c->w_ws);
+    HIPCHK(hipGetLastError());
+    *Wout = (T*)c->w_ws;
+    return 0;
+}
+template <typename T>
+static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
+    if (M <= 0) return 0;
+    T* W = nullptr;
+    RC(trtri_tiles<T>(c, s, L, ldl, n, &W));
+    return trsm_rec_w<T>(c, s, X, ldx, M, L, ldl, n, W);
+}
 
-// Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows).  Right-looking
-// over panels of width nb with a one-panel look-ahead: the next panel is factored on the panel
-// stream while the rest of the trailing update still runs on the main stream.
+// Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows).  Right-looking over panels
+// of width nb.  Per panel k:  diag(k) = recursive Cholesky of the nb×nb diagonal block (fp64 VALU kernels —
+// issued on the main stream while no MFMA kernel runs: on gfx950 fp64 VALU work co-resident with fp64 MFMA
+// waves starves);  rows_below(k) = X ← X L_kk⁻ᵀ for all rows under it, all-MFMA (trsm_rec), on the panel
+// stream, overlapped with the bulk of the previous trailing update:
+//   main : diag(0) | U2(k−1) ............ | U1a(k) diag(k+1) U1b(k) | U2(k) ....
+//   panel:         | trtri(k) rows_below(k)|                         | trtri(k+1) rows_below(k+1)
+// U1a/U1b(k) = update of panel k+1's columns by panel k (diagonal block / rows below), U2(k) = the rest.
 template <typename T>
 static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
                           double* logdet_dev) {
     long nb = c->nb;
-    if (nb <= 0 || nb >= np) {
-        return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
-    }
-    nb = round_up(nb, 128);
+    if (nb <= 0) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    nb = std::min(round_up(nb, 128), np);
     const bool la = c->lookahead != 0;
     hipStream_t sP = la ? c->sp : c->sm;
-    hipEvent_t ev_u1 = nullptr, ev_panel = nullptr;
-    if (la) {
-        // panel stream starts after everything queued so far on the main stream (assembly)
-        RC(ctx_event(c, &ev_u1, false));
-        HIPCHK(hipEventRecord(ev_u1, c->sm));
-        HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
-    }
+    hipEvent_t ev_ready = nullptr, ev_panel = nullptr;
+    RC(potrf_rec<T>(c, c->sm, A, lda, 0, nb, nb, info_dev, 0, n_valid, logdet_dev));  // diag(0)
+    long kprev = -1, nbprev = 0;
     for (long k = 0; k < np; k += nb) {
-        const long nbk = std::min(nb, np - k);
-        RC(potrf_rec<T>(c, sP, A, lda, k, nbk, mtot, info_dev, 0, n_valid, logdet_dev));
-        const long k1 = k + nbk;
-        if (k1 >= np && mtot <= np) break;
-        if (la) {
-            RC(ctx_event(c, &ev_panel, false));
-            HIPCHK(hipEventRecord(ev_panel, sP));
-            HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
+        const long nbk = std::min(nb, np - k), k1 = k + nbk;
+        // ---- rows_below(k) on the panel stream
+        if (mtot > k1) {
+            if (la) {
+                RC(ctx_event(c, &ev_ready, false));
+                HIPCHK(hipEventRecord(ev_ready, c->sm));
+                HIPCHK(hipStreamWaitEvent(sP, ev_ready, 0));
+            }
+            RC(trsm_rec<T>(c, sP, A + k1 * lda + k, lda, mtot - k1, A + k * lda + k, lda, nbk));
+            if (la) {
+                RC(ctx_event(c, &ev_panel, false));
+                HIPCHK(hipEventRecord(ev_panel, sP));
+            }
         }
-        if (k1 >= np) break;  // RHS rows were already solved inside potrf_rec
-        const long nb1 = std::min(nb, np - k1);
-        // U1: next panel's columns, all rows below
-        RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, mtot - k1,
-                          nb1, nbk, plain_map(1, k1, k1)));
-        if (la) {
-            RC(ctx_event(c, &ev_u1, false));
-            HIPCHK(hipEventRecord(ev_u1, c->sm));
-            HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
+        // ---- meanwhile: the bulk of the previous panel's trailing update (columns right of panel k)
+        if (kprev >= 0 && k1 < np)
+            RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + kprev, lda, A + k1 * lda + kprev, lda,
+                              mtot - k1, np - k1, nbprev, plain_map(1, k1, k1)));
+        if (la && mtot > k1) HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
+        if (k1 < np) {
+            const long nb1 = std::min(nb, np - k1), k2 = k1 + nb1;
+            // U1a(k): diagonal block of panel k+1
+            RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, nb1, nb1,
+                              nbk, plain_map(1, k1, k1)));
+            RC(potrf_rec<T>(c, c->sm, A, lda, k1, nb1, k2, info_dev, 0, n_valid, logdet_dev));  // diag(k+1)
+            // U1b(k): rows below it
+            if (mtot > k2)
+                RC(launch_gemm<T>(c, c->sm, A + k2 * lda + k1, lda, A + k2 * lda + k, lda, A + k1 * lda + k, lda,
+                                  mtot - k2, nb1, nbk, plain_map(0, 0, 0)));
         }
-        // U2: the rest of the trailing matrix
-        const long k2 = k1 + nb1;
-        if (k2 < np)
-            RC(launch_gemm<T>(c, c->sm, A + k2 * lda + k2, lda, A + k2 * lda + k, lda, A + k2 * lda + k, lda,
-                              mtot - k2, np - k2, nbk, plain_map(1, k2, k2)));
-    }
-    if (la) {
-        RC(ctx_event(c, &ev_panel, false));
-        HIPCHK(hipEventRecord(ev_panel, sP));
-        HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
+        kprev = k;
+        nbprev = nbk;
     }
     return 0;
 }

@@ -57,7 +57,26 @@ struct GridMap {
     int P, p, Q, q;  // process grid / my coordinates (1,0,1,0 on a single GPU)
     long nb;         // distribution block in elements (multiple of 128); ignored when P=Q=1
     long row0, col0; // local absolute index of the region's first row / column
+    int compact;     // 1: 1-D grid enumerating only the tiles on/below the diagonal (single-GPU lower mode)
+    int tn, dt;      // compact: number of tile columns, diagonal offset in tiles (row tile i has min(tn, i+dt+1) tiles)
 };
+// compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
+__device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
+    const int tri = (g.tn - g.dt) > 0 ? (g.tn - g.dt) : 0;  // rows of the triangular part (may exceed the grid's rows)
+    const long tot_tri = (long)tri * (g.dt + 1) + (long)tri * (tri - 1) / 2;
+    if (b < tot_tri) {
+        const double q = 2.0 * g.dt + 1.0;
+        int i = (int)((-q + sqrt(q * q + 8.0 * (double)b)) * 0.5);
+        while ((long)i * (g.dt + 1) + (long)i * (i - 1) / 2 > b) --i;
+        while ((long)(i + 1) * (g.dt + 1) + (long)(i + 1) * i / 2 <= b) ++i;
+        bi = i;
+        bj = b - (int)((long)i * (g.dt + 1) + (long)i * (i - 1) / 2);
+    } else {
+        const long r = b - tot_tri;
+        bi = tri + (int)(r / g.tn);
+        bj = (int)(r % g.tn);
+    }
+}
 __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
     if (P == 1) return loc;
     return ((loc / nb) * P + p) * nb + (loc % nb);
@@ -77,16 +96,17 @@ __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
 __device__ __forceinline__ int lds_swz(int c) { return (c & 3) | ((c & 4) ? 12 : 0); }
 
 template <typename T, bool KM>
-__global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, long ldc, const T* __restrict__ A,
-                                                              long lda, const T* __restrict__ B, long ldb, int M,
-                                                              int N, int K, GridMap g) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb,
+                                                              int M, int N, int K, GridMap g) {
     using TR = Tr<T>;
     using chunk_t = typename TR::chunk_t;
     using acc_t = typename TR::acc_t;
     constexpr int VEC = TR::VEC;
     constexpr int BK = 8 * VEC;
 
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (g.compact) compact_tile(g, (int)blockIdx.x, bi, bj);
+    const int m0 = bi * 128, n0 = bj * 128;
     long gr0 = 0, gc0 = 0;
     if (g.lower) {
         gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
@@ -129,13 +149,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, 
             }
     };
 
-    acc_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t)(0);
-
     const int li = lane & 15, lg = lane >> 4;
+    // accumulators start at −C (the MFMA chain then yields A·Bᵀ − C; the epilogue stores the negation), so the
+    // C tile is read once up front, overlapped with the first operand loads, and the epilogue is store-only.
+    acc_t acc[4][4];
+    T* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[mt][nt][r] = active ? -Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] : T(0);
+
     const int nk = K / BK;
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -196,19 +222,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* __restrict__ C, 
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long row = m0 + wr * 64 + mt * 16 + TR::crow(lane, r);
-                    const long col = n0 + wc * 64 + nt * 16 + li;
-                    T* p = C + row * ldc + col;
-                    *p = *p - acc[mt][nt][r];
-                }
+                for (int r = 0; r < 4; ++r) Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = -acc[mt][nt][r];
     }
 }
 
 // Debug reference (gemm_variant = 1): same contract, plain VALU, one thread per C element.
 template <typename T, bool KM>
-__global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* __restrict__ C, long ldc, const T* __restrict__ A,
-                                                               long lda, const T* __restrict__ B, long ldb, int M,
+__global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
                                                                int N, int K, GridMap g) {
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const int row = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -448,6 +468,46 @@ __global__ __launch_bounds__(64) void trsm_64_kernel(T* __restrict__ X, long ldx
         for (int e = 0; e < VEC; ++e) v[e] = x[VEC * t + e];
         xr[t] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// trtri_64 (batched): W_j = I − inv(L_jj) for the 64×64 diagonal tiles j of a lower factor (one wave per tile).
+//   With it the 64-wide triangular solve becomes an in-place MFMA update  X_j ← X_j − X_j W_jᵀ = X_j L_jj⁻ᵀ
+//   (gemm_nt_sub with C = A = X_j, B = W_j), so no fp64 VALU kernel has to share SIMDs with the fp64 MFMA
+//   trailing update (on gfx950 both run on the same DP pipe and the VALU kernel starves).
+//   Lane i runs the substitution of trsm_64 on row e_i, i.e. ends up holding column i of inv(L).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void trtri_64_kernel(const T* __restrict__ L, long ldl, T* __restrict__ W) {
+    using chunk_t = typename Tr<T>::chunk_t;
+    constexpr int VEC = Tr<T>::VEC;
+    __shared__ __attribute__((aligned(16))) T Lt[64][64];
+    const int tid = threadIdx.x;
+    const T* Lj = L + (long)blockIdx.x * 64 * ldl + (long)blockIdx.x * 64;
+    const chunk_t* lrow = reinterpret_cast<const chunk_t*>(Lj + (long)tid * ldl);
+#pragma unroll
+    for (int t = 0; t < 64 / VEC; ++t) {
+        const chunk_t v = lrow[t];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = VEC * t + e;
+            Lt[c][tid] = (c == tid) ? T(1) / v[e] : v[e];
+        }
+    }
+    __syncthreads();
+    T x[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) x[t] = (t == tid) ? T(1) : T(0);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const T v = x[c] * Lt[c][c];
+        x[c] = v;
+#pragma unroll
+        for (int t = c + 1; t < 64; ++t) x[t] = fma(-v, Lt[c][t], x[t]);
+    }
+    T* Wj = W + (long)blockIdx.x * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) Wj[t * 64 + tid] = ((t == tid) ? T(1) : T(0)) - ((t >= tid) ? x[t] : T(0));
 }
 
 // ------------------------------------------------------------------------------------------------

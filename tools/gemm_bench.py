@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--shapes", default="8192x8192x2048,16384x16384x2048,32768x2048x2048,8192x8192x64")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--lower", type=int, default=0)
+    ap.add_argument("--lda", type=int, default=0, help="operand leading dimension (0: k + 32)")
     args = ap.parse_args()
     ctx = agp.Context(0)
     lib, h = ctx.lib, ctx.handle
@@ -27,7 +28,7 @@ def main():
     print(json.dumps({"mfma_f64_ceiling_tflops": c.value}), flush=True)
     for shp in args.shapes.split(","):
         m, n, k = [int(v) for v in shp.split("x")]
-        lda = k + 32
+        lda = args.lda or (k + 32)
         A = torch.randn(max(m, n) + 128, lda, dtype=torch.float64, device="cuda")
         Cm = torch.zeros(m + 128, n + 32, dtype=torch.float64, device="cuda")
         g = gp_grid(1, 0, 1, 0, 1, args.lower)
@@ -41,7 +42,7 @@ def main():
         check(lib.gpd_sync(h))
         dt = (time.perf_counter() - t0) / args.reps
         fl = 2.0 * m * n * k * (0.5 if args.lower else 1.0)
-        print(json.dumps({"m": m, "n": n, "k": k, "lower": args.lower, "ms": dt * 1e3, "tflops": fl / dt / 1e12}), flush=True)
+        print(json.dumps({"m": m, "n": n, "k": k, "lower": args.lower, "lda": lda, "ms": dt * 1e3, "tflops": fl / dt / 1e12}), flush=True)
 
 
 if __name__ == "__main__":
