@@ -67,6 +67,8 @@ struct gp_ctx {
     int lookahead = 1;
     int time_kernels = 0;
     int gemm_variant = 0;
+    int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
+    int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
     long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
     gp_timings tm{};
     std::vector<FreeBlock> pool;
@@ -310,9 +312,27 @@ template <typename T> static int32_t trtri_tiles(gp_ctx* c, hipStream_t s, const
     *Wout = (T*)c->w_ws;
     return 0;
 }
+// VALU base case (trsm_64, one lane per row): faster when nothing else runs, starves beside fp64 MFMA kernels.
 template <typename T>
-static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
+static int32_t trsm_rec_v(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
+    if (n <= 64) {
+        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, X, ldx, (int)M, L, ldl,
+                           (const T*)nullptr);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const long h = split_half(n);
+    RC(trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, h));
+    RC(launch_gemm<T>(c, s, X + h, ldx, X, ldx, L + h * ldl, ldl, M, n - h, h, plain_map(0, 0, 0)));
+    RC(trsm_rec_v<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h));
+    return 0;
+}
+template <typename T>
+static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n,
+                        int force_mfma = -1) {
     if (M <= 0) return 0;
+    const bool mfma = force_mfma >= 0 ? force_mfma != 0 : c->trsm_mfma != 0;
+    if (!mfma) return trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, n);
     T* W = nullptr;
     RC(trtri_tiles<T>(c, s, L, ldl, n, &W));
     return trsm_rec_w<T>(c, s, X, ldx, M, L, ldl, n, W);
@@ -327,10 +347,14 @@ static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const 
 //   panel:         | trtri(k) rows_below(k)|                         | trtri(k+1) rows_below(k+1)
 // U1a/U1b(k) = update of panel k+1's columns by panel k (diagonal block / rows below), U2(k) = the rest.
 template <typename T>
+static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid, double* logdet_dev);
+
+template <typename T>
 static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
                           double* logdet_dev) {
     long nb = c->nb;
     if (nb <= 0) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    if (c->sched == 0) return potrf_full_la<T>(c, A, lda, np, mtot, info_dev, n_valid, logdet_dev);
     nb = std::min(round_up(nb, 128), np);
     const bool la = c->lookahead != 0;
     hipStream_t sP = la ? c->sp : c->sm;
@@ -346,7 +370,7 @@ static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* in
                 HIPCHK(hipEventRecord(ev_ready, c->sm));
                 HIPCHK(hipStreamWaitEvent(sP, ev_ready, 0));
             }
-            RC(trsm_rec<T>(c, sP, A + k1 * lda + k, lda, mtot - k1, A + k * lda + k, lda, nbk));
+            RC(trsm_rec<T>(c, sP, A + k1 * lda + k, lda, mtot - k1, A + k * lda + k, lda, nbk, 1));
             if (la) {
                 RC(ctx_event(c, &ev_panel, false));
                 HIPCHK(hipEventRecord(ev_panel, sP));
@@ -370,6 +394,51 @@ static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* in
         }
         kprev = k;
         nbprev = nbk;
+    }
+    return 0;
+}
+
+// sched 0: right-looking over panels of width nb with a one-panel look-ahead: the whole next panel (recursive
+// Cholesky of its columns including every row below) is factored on the panel stream while the rest of the
+// trailing update still runs on the main stream.
+template <typename T>
+static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
+                             double* logdet_dev) {
+    long nb = c->nb;
+    if (nb >= np) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    nb = round_up(nb, 128);
+    const bool la = c->lookahead != 0;
+    hipStream_t sP = la ? c->sp : c->sm;
+    hipEvent_t ev_u1 = nullptr, ev_panel = nullptr;
+    if (la) {  // the panel stream starts after everything queued so far on the main stream (assembly)
+        RC(ctx_event(c, &ev_u1, false));
+        HIPCHK(hipEventRecord(ev_u1, c->sm));
+        HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
+    }
+    for (long k = 0; k < np; k += nb) {
+        const long nbk = std::min(nb, np - k);
+        RC(potrf_rec<T>(c, sP, A, lda, k, nbk, mtot, info_dev, 0, n_valid, logdet_dev));
+        const long k1 = k + nbk;
+        if (la) {
+            RC(ctx_event(c, &ev_panel, false));
+            HIPCHK(hipEventRecord(ev_panel, sP));
+            HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
+        }
+        if (k1 >= np) break;  // RHS rows were already solved inside potrf_rec
+        const long nb1 = std::min(nb, np - k1);
+        // U1: next panel's columns, all rows below
+        RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, mtot - k1,
+                          nb1, nbk, plain_map(1, k1, k1)));
+        if (la) {
+            RC(ctx_event(c, &ev_u1, false));
+            HIPCHK(hipEventRecord(ev_u1, c->sm));
+            HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
+        }
+        // U2: the rest of the trailing matrix
+        const long k2 = k1 + nb1;
+        if (k2 < np)
+            RC(launch_gemm<T>(c, c->sm, A + k2 * lda + k2, lda, A + k2 * lda + k, lda, A + k2 * lda + k, lda,
+                              mtot - k2, np - k2, nbk, plain_map(1, k2, k2)));
     }
     return 0;
 }
@@ -767,6 +836,8 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "lookahead")) c->lookahead = v != 0;
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
     else if (!strcmp(name, "gemm_variant")) c->gemm_variant = (int)v;
+    else if (!strcmp(name, "sched")) c->sched = (int)v;
+    else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
     else return set_arg_err(2, "unknown parameter");
     return 0;

@@ -632,6 +632,24 @@ __global__ __launch_bounds__(256) void rowsumsq_kernel(const T* __restrict__ X, 
     if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// out[0] += Σ_{row<nrows, c<ncols} X[row][c]²  accumulated in fp64 whatever T is (one block per row, one atomic each)
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_accum_kernel(const T* __restrict__ X, long ldx, long ncols,
+                                                           double* __restrict__ out) {
+    __shared__ double red[4];
+    const T* x = X + (long)blockIdx.x * ldx;
+    double acc = 0;
+    for (long c = threadIdx.x; c < ncols; c += 256) {
+        const double v = (double)x[c];
+        acc = fma(v, v, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 // out[s] = Σ_i variance κ(‖xs_s − x_i‖) α_i   (K_*x α fused with the kernel evaluation; one block per s)
 template <typename T>
 __global__ __launch_bounds__(256) void kvec_kernel(const T* __restrict__ xs, long ldxs, const T* __restrict__ x,

@@ -137,6 +137,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                                k->kind, (T)k->variance, (const T*)nullptr, n, m, 0, g, (const T*)nullptr, (const T*)rs_v);
             HIPCHK(hipGetLastError());
             RC(trsm_rec<T>(c, s, (T*)X_v, ld, CH, LzT, ld, mp));                                   // B_cᵀ
+            hipLaunchKernelGGL(sumsq_accum_kernel<T>, dim3((unsigned)CH), dim3(256), 0, s, (const T*)X_v, ld, mp,
+                               c->scal_dev + 4);                                                   // ‖A‖²_F in fp64
+            HIPCHK(hipGetLastError());
             RC(launch_gemm<T>(c, s, (T*)D_v, ld, (const T*)X_v, ld, (const T*)X_v, ld, mp, mp, CH, plain_map(1, 0, 0), true));
             hipLaunchKernelGGL(gemv_t_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(CH / 64)), dim3(256), 0, s,
                                (const T*)X_v, ld, CH, mp, (const T*)b_v + c0, (T*)cT_v);
@@ -206,7 +209,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     }
     // objective: dtc = -½ (N log2π + logdet Σy + logdet Λ_ε + ‖δ_s‖² − ‖Λ_ε.U⁻ᵀ A δ_s‖²)          :302-303
     //            elbo = dtc − ½ (tr(K_ff Σy⁻¹) − ‖A‖²_F),  ‖A‖²_F = tr(D − I)                      :251
-    const double logdet_lam = 2.0 * scal_h[1], trZ = scal_h[2], quad = scal_h[3];  // trZ = tr(D − I) = ‖A‖²_F
+    const double logdet_lam = 2.0 * scal_h[1], trZ = scal_h[4], quad = scal_h[3];  // trZ = ‖B‖²_F = ‖A‖²_F
     double obj = -0.5 * ((double)n * LOG2PI + logdet_sy + logdet_lam + dd - quad);
     if (approx == 0) obj -= 0.5 * (tr_kff - trZ);
     if (objective) *objective = obj;

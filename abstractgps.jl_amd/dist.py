@@ -49,7 +49,10 @@ class HipTileBackend:
 
         self._lib = _lib
         self.device = torch.device("cuda", device)
-        self.ctx = Context(device, stream=torch.cuda.current_stream(self.device).cuda_stream)
+        # a dedicated (non-null) stream shared by torch ops, the RCCL collectives and the library's main stream,
+        # so kernels, copies and broadcasts are ordered without host synchronisation
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx = Context(device, stream=self.stream.cuda_stream)
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
 
@@ -146,9 +149,10 @@ class BlockCyclicEngine:
             dist.broadcast(t, src=self._rank_of(src_p, q), group=g)
 
     def _reduce_col(self, t, dst_p, q):
+        """sum over process column q (8 KiB; an all-reduce so it also runs on gloo with device tensors)."""
         if self.P > 1 and q == self.q:
             ranks, g = self.col_groups[q]
-            dist.reduce(t, dst=self._rank_of(dst_p, q), op=dist.ReduceOp.SUM, group=g)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g)
 
     def _nlb_before(self, k, p, P):
         """number of global blocks i <= k with i ≡ p (mod P)"""
@@ -157,6 +161,13 @@ class BlockCyclicEngine:
     # ---- the pair --------------------------------------------------------------------------------
     def fit(self, kernel, x, sigma2, y, mean=None):
         """kernel: abstractgps api.Kernel; x: (N, D) array (RowVecs) or (N,) vector; sigma2 scalar or (N,)."""
+        stream = getattr(self.be, "stream", None)
+        if stream is None:
+            return self._fit(kernel, x, sigma2, y, mean)
+        with torch.cuda.stream(stream):
+            return self._fit(kernel, x, sigma2, y, mean)
+
+    def _fit(self, kernel, x, sigma2, y, mean=None):
         be, P, Q, p, q, NB = self.be, self.P, self.Q, self.p, self.q, self.nb
         X = np.asarray(x, dtype=np.float64)
         X = X[:, None] if X.ndim == 1 else X
@@ -217,8 +228,6 @@ class BlockCyclicEngine:
                         r0 = self._nlb_before(k, p, P) * NB   # my first local row with global block > k
                         if m_loc - r0 > 0:
                             be.trsm(_sub(A, r0, c0), ldl, m_loc - r0, Lkk, NB, NB)
-            if k == nblk - 1 and p_rhs != pk and False:
-                pass
             # ---- panel pieces to everyone (one per process row)
             rows_of = []
             for pp in range(P):
@@ -257,14 +266,14 @@ class BlockCyclicEngine:
 
         # ---- backward substitution  α = L⁻ᵀ z  (block sweep, last block first)
         alpha = be.zeros(npad)
-        acc = be.zeros(n_loc)                                  # my partial Σ_k L[k][j]ᵀ α_k per local column
+        acc = be.zeros(n_loc)                                  # my partial −Σ_k L[k][j]ᵀ α_k per local column
         rk = be.zeros(NB)
         for k in range(nblk - 1, -1, -1):
             pk, qk = k % P, k % Q
             lbk_r, lbk_c = k // P, k // Q
             if q == qk:
                 c0 = lbk_c * NB
-                rk.copy_(acc[c0:c0 + NB]).neg_()
+                rk.copy_(acc[c0:c0 + NB])
                 if p == p_rhs:
                     rk.add_(A[nlb_r * NB, c0:c0 + NB])        # z_k from the RHS row
                 self._reduce_col(rk, pk, qk)
@@ -273,7 +282,7 @@ class BlockCyclicEngine:
                     be.trsv(_sub(A, r0, c0), ldl, NB, rk, NB, 1, False)
             self._bcast_world(rk, self._rank_of(pk, qk))
             alpha[k * NB:(k + 1) * NB].copy_(rk)
-            if p == pk:                                        # my block row k: acc_j += L[k][j]ᵀ α_k for local j < k
+            if p == pk:                                        # my block row k: acc_j −= L[k][j]ᵀ α_k for local j < k
                 ncb = self._nlb_before(k - 1, q, Q) if k > 0 else 0
                 if ncb > 0:
                     be.gemv_t(_sub(A, lbk_r * NB, 0), ldl, NB, ncb * NB, rk, acc)

@@ -111,17 +111,21 @@ def test_mid_size_parity(agp, n, d, kind, layout):
 
 
 def test_variants_agree(agp):
-    """MFMA gemm vs the VALU debug gemm, look-ahead on/off, recursive-only: same answer."""
+    """MFMA gemm vs the VALU debug gemm, look-ahead on/off, recursive-only, both panel schedules, VALU vs
+    all-MFMA triangular solves: same answer."""
     x, y = o.synth_inputs(3000, 3, 9)
     f = agp.GP(agp.SqExponentialKernel())
     ctx = agp.default_context()
     vals = []
     try:
-        for nb, la, var in [(2048, 1, 0), (1024, 0, 0), (0, 0, 0), (1024, 1, 1)]:
+        for nb, la, var, sched, tm in [(2048, 1, 0, 0, 0), (1024, 0, 0, 0, 0), (0, 0, 0, 0, 0), (1024, 1, 1, 0, 0),
+                                       (1024, 1, 0, 1, 0), (512, 0, 0, 1, 1), (1024, 1, 0, 0, 1)]:
             ctx.set_param("nb", nb), ctx.set_param("lookahead", la), ctx.set_param("gemm_variant", var)
+            ctx.set_param("sched", sched), ctx.set_param("trsm_mfma", tm)
             vals.append(float(agp.logpdf(f(agp.RowVecs(x), 0.01), y)))
     finally:
         ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("gemm_variant", 0)
+        ctx.set_param("sched", 0), ctx.set_param("trsm_mfma", 0)
     ref = float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y))
     for v in vals:
         assert v == pytest.approx(ref, rel=1e-10)
