@@ -17,6 +17,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace gpmi;
@@ -69,6 +70,9 @@ struct gp_ctx {
     int gemm_variant = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
+    int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
+    int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
+    long xcd_min_tiles = 256;
     long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
     gp_timings tm{};
     std::vector<FreeBlock> pool;
@@ -191,8 +195,8 @@ static double lower_count(long M, long N, long row0, long col0) {
     return mid + (double)(M - i2) * (double)N;
 }
 
-template <typename T>
-static int32_t launch_gemm(gp_ctx* c, hipStream_t s, T* C, long ldc, const T* A, long lda, const T* B, long ldb,
+template <typename T, typename CT = T>
+static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A, long lda, const T* B, long ldb,
                            long M, long N, long K, GridMap g, bool kmajor = false) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     gp_ctx::GemmRec rec{};
@@ -206,28 +210,46 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, T* C, long ldc, const T* A,
     }
     if (c->gemm_variant == 0) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
-        if (g.lower && g.P == 1 && g.Q == 1 && g.row0 >= g.col0) {  // enumerate only the tiles on/below the diagonal
-            const long tm = (M + 127) / 128, tn = (N + 127) / 128, dt = (g.row0 - g.col0 + 127) / 128;
+        const long tm = (M + 127) / 128, tn = (N + 127) / 128;
+        const bool single_lower = g.lower && g.P == 1 && g.Q == 1 && g.row0 >= g.col0;
+        const long dt = single_lower ? (g.row0 - g.col0 + 127) / 128 : 0;
+        g.tm = (int)tm;
+        g.tn = (int)tn;
+        g.dt = (int)dt;
+        if (c->xcd_swizzle && tm * tn >= c->xcd_min_tiles) {  // XCD-aware 8×8 super-tile order (kernels.hpp xcd_tile)
+            const long tms = (tm + 7) / 8, tns = (tn + 7) / 8, dts = (dt + 7) / 8;
+            long nsuper;
+            if (single_lower) {
+                const long tri = std::min(tms, std::max(0L, tns - dts));
+                nsuper = tri * (dts + 1) + tri * (tri - 1) / 2 + (tms - tri) * tns;
+                g.compact = 3;
+            } else {
+                nsuper = tms * tns;
+                g.compact = 2;
+            }
+            grid = dim3((unsigned)(round_up(nsuper, 8) * 64), 1);
+        } else if (single_lower) {  // enumerate only the tiles on/below the diagonal
             const long tri = std::min(tm, std::max(0L, tn - dt));
             const long total = tri * (dt + 1) + tri * (tri - 1) / 2 + (tm - tri) * tn;
             g.compact = 1;
-            g.tn = (int)tn;
-            g.dt = (int)dt;
             grid = dim3((unsigned)total, 1);
         }
         if (kmajor)
-            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
+            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
+        else if (c->gemm_dma && std::is_same<T, CT>::value)
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                               (int)K, g);
         else
-            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, false>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
+            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, false, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
     } else {
         dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16));
         if (kmajor)
-            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, true>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
+            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
         else
-            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, false>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb,
+            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, false, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb,
                                (int)M, (int)N, (int)K, g);
     }
     HIPCHK(hipGetLastError());
@@ -248,6 +270,7 @@ static GridMap plain_map(int lower, long row0, long col0) {
     g.compact = 0;
     g.tn = 0;
     g.dt = 0;
+    g.tm = 0;
     return g;
 }
 
@@ -837,6 +860,9 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
     else if (!strcmp(name, "gemm_variant")) c->gemm_variant = (int)v;
     else if (!strcmp(name, "sched")) c->sched = (int)v;
+    else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
+    else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
+    else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
     else return set_arg_err(2, "unknown parameter");

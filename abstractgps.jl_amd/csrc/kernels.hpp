@@ -15,6 +15,12 @@
 //   kvec_kernel        K_*x α without materialising K_*x                    src/exact_gpr_posterior.jl:60-62
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef GPMI_GEMM_SCHED
+#define GPMI_GEMM_SCHED 1  // explicit MFMA / LDS interleave of the gemm k loop (sched_group_barrier)
+#endif
+#ifndef GPMI_ABL
+#define GPMI_ABL 0  // ablation switches of tools/gemm_ablate.hip (timing experiments only; 0 in the product build)
+#endif
 #include <stdint.h>
 
 namespace gpmi {
@@ -58,7 +64,9 @@ struct GridMap {
     long nb;         // distribution block in elements (multiple of 128); ignored when P=Q=1
     long row0, col0; // local absolute index of the region's first row / column
     int compact;     // 1: 1-D grid enumerating only the tiles on/below the diagonal (single-GPU lower mode)
+                     // 2 / 3: XCD-aware super-tile order (rectangular / lower trapezoid), see xcd_tile()
     int tn, dt;      // compact: number of tile columns, diagonal offset in tiles (row tile i has min(tn, i+dt+1) tiles)
+    int tm;          // number of tile rows (modes 2, 3)
 };
 // compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
 __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
@@ -76,6 +84,29 @@ __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, i
         bi = tri + (int)(r / g.tn);
         bj = (int)(r % g.tn);
     }
+}
+// XCD-aware order (modes 2, 3).  Workgroup b is dispatched to XCD b % 8, whose 32 CUs hold 64 of these workgroups at a
+// time; each XCD has its own 4 MiB L2.  So the 64 consecutive workgroups of one XCD are mapped onto one 8×8 "super-tile"
+// of 128×128 tiles: they share 8 A row-panels and 8 B row-panels, i.e. every operand tile fetched into that L2 is reused
+// 8×, instead of the B panels being streamed once per workgroup as in a row-major order.  Super-tiles are enumerated
+// row-major (mode 2) or over the lower trapezoid (mode 3, super-tile units); tiles outside the matrix return false.
+__device__ __forceinline__ bool xcd_tile(const GridMap& g, int b, int& bi, int& bj) {
+    const int x = b & 7, q = b >> 3;
+    const int S = (q >> 6) * 8 + x, t = q & 63;
+    int si, sj;
+    if (g.compact == 2) {
+        const int tns = (g.tn + 7) >> 3;
+        si = S / tns;
+        sj = S - si * tns;
+    } else {
+        GridMap gs = g;
+        gs.tn = (g.tn + 7) >> 3;
+        gs.dt = (g.dt + 7) >> 3;
+        compact_tile(gs, S, si, sj);
+    }
+    bi = si * 8 + (t >> 3);
+    bj = sj * 8 + (t & 7);
+    return bi < g.tm && bj < g.tn;
 }
 __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
     if (P == 1) return loc;
@@ -95,17 +126,25 @@ __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_swz(int c) { return (c & 3) | ((c & 4) ? 12 : 0); }
 
-template <typename T, bool KM>
-__global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb,
+//   CT = double with T = float ("mixed"): C is fp64; the fp32 MFMA chain is flushed into fp64 accumulators every
+//   FLUSH k-steps (K = 256), so long reductions (the VFE SYRK over N data points) keep fp64-grade sums while the
+//   operands stream in fp32.
+template <typename T, bool KM, typename CT = T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb,
                                                               int M, int N, int K, GridMap g) {
     using TR = Tr<T>;
+    constexpr bool MIX = !__is_same(T, CT);
+    constexpr int FLUSH = 8;
     using chunk_t = typename TR::chunk_t;
     using acc_t = typename TR::acc_t;
     constexpr int VEC = TR::VEC;
     constexpr int BK = 8 * VEC;
 
     int bi = blockIdx.y, bj = blockIdx.x;
-    if (g.compact) compact_tile(g, (int)blockIdx.x, bi, bj);
+    if (g.compact == 1) compact_tile(g, (int)blockIdx.x, bi, bj);
+    else if (g.compact >= 2) {
+        if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
+    }
     const int m0 = bi * 128, n0 = bj * 128;
     long gr0 = 0, gc0 = 0;
     if (g.lower) {
@@ -153,14 +192,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* C, long ldc, con
     // accumulators start at −C (the MFMA chain then yields A·Bᵀ − C; the epilogue stores the negation), so the
     // C tile is read once up front, overlapped with the first operand loads, and the epilogue is store-only.
     acc_t acc[4][4];
-    T* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
+    d4_t acc64[MIX ? 4 : 1][MIX ? 4 : 1];
+    CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
+    const CT* const Cr = active ? Cw : C + li;  // waves that store nothing preload from the (always valid) first tile:
+                                                // unconditional loads, no per-element branch
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[mt][nt][r] = active ? -Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] : T(0);
+            for (int r = 0; r < 4; ++r) {
+                const CT c0 = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
+                if constexpr (MIX) {
+                    acc64[mt][nt][r] = c0;
+                    acc[mt][nt][r] = T(0);
+                } else {
+                    acc[mt][nt][r] = c0;
+                }
+            }
 
     const int nk = K / BK;
     auto sstore = [&](int buf) {
@@ -189,31 +238,216 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* C, long ldc, con
     sstore(0);
     __syncthreads();
 
+    // Branch-free loop body (one basic block, so the MFMA / LDS / VMEM interleave below is what gets emitted):
+    //   global loads of tile kt+1 (the last iteration re-loads tile nk−1 and stores it into the idle buffer),
+    //   first half of the MFMAs, then the LDS stores of tile kt+1 spread between the MFMAs of the second half — a
+    //   ds_write_b128 costs ≈13 issue cycles, a v_mfma_f64_16x16x4 occupies the pipe for 64 — and one barrier.
+    //   Waves whose 64×64 sub-tile is not stored (above the diagonal / past the edge) still run the MFMAs.
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) gload(kt + 1);
-        if (active) {
+#if !(GPMI_ABL & 1)
+        gload((kt + 1 < nk) ? kt + 1 : kt);
+#endif
+        chunk_t a[2][4], b[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = 4 * h + lg;
-                const int fc = lds_swz(c);
-                chunk_t a[4], b[4];
+        for (int h = 0; h < 2; ++h) {
+            const int c = 4 * h + lg;
+            const int fc = lds_swz(c);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = As[cur][c][(wr * 64 + t * 16 + li) ^ fc];
-                    b[t] = Bs[cur][c][(wc * 64 + t * 16 + li) ^ fc];
-                }
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[mt][v], b[nt][v], acc[mt][nt]);
+            for (int t = 0; t < 4; ++t) {
+                a[h][t] = As[cur][c][(wr * 64 + t * 16 + li) ^ fc];
+                b[h][t] = Bs[cur][c][(wc * 64 + t * 16 + li) ^ fc];
             }
         }
-        if (more) sstore(cur ^ 1);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[0][mt][v], b[0][nt][v], acc[mt][nt]);
+#if !(GPMI_ABL & 2)
+        sstore(cur ^ 1);
+#endif
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[1][mt][v], b[1][nt][v], acc[mt][nt]);
+#if GPMI_GEMM_SCHED
+        // emitted order: 8 LDS reads, 16·VEC−4 MFMA, 8 LDS reads (second-half fragments), 4 MFMA, then
+        // {1 LDS store, 2·VEC MFMA} × 8 (NT staging: 8 stores per iteration)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC - 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x200, KM ? VEC : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * VEC, 0);
+        }
+#endif
+        if constexpr (MIX) {
+            if ((kt % FLUSH) == FLUSH - 1) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc64[mt][nt][r] += (double)acc[mt][nt][r];
+                            acc[mt][nt][r] = T(0);
+                        }
+            }
+        }
+#if !(GPMI_ABL & 4)
         __syncthreads();
+#endif
+    }
+
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    CT v;
+                    if constexpr (MIX) v = -(acc64[mt][nt][r] + (double)acc[mt][nt][r]);
+                    else v = -acc[mt][nt][r];
+                    Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = v;
+                }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_dma: same contract as gemm_nt_sub<T, false> (C[M×N] -= A[M×K] · B[N×K]ᵀ, row-major, k contiguous), operand tiles
+//   moved global -> LDS by the LDS-DMA path (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass — in the
+//   register-staged kernel the 8 ds_write_b128 + lgkmcnt(0) + barrier tail of every k step cost ≈10 % of the MFMA pipe
+//   (tools/gemm_ablate.hip).
+//   LDS image per operand and buffer: 128 rows × 128 B, row-major (BK = 16 f64 / 32 f32 = 8 chunks of 16 B).  One
+//   wave-instruction fills 1 KiB = 8 whole rows: lane l writes slot l (the DMA destination is base + 16·lane) and
+//   FETCHES chunk (l&7) ^ swz(row) of global row (l>>3), swz(r) = (r>>1)&7 — the XOR lives on the source address.
+//   Fragment reads use the same involution: lane (li, lg) wants chunk c = 4h+lg of row r -> slot c ^ swz(r); for each
+//   16-lane ds_read_b128 group {0-3,12-15,20-27},... this visits all 16 (row parity, slot) pairs: conflict-free.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <typename T, typename CT = T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
+                                                              int N, int K, GridMap g) {
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    using acc_t = typename TR::acc_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int BK = 8 * VEC;
+
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (g.compact == 1) compact_tile(g, (int)blockIdx.x, bi, bj);
+    else if (g.compact >= 2) {
+        if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
+    }
+    const int m0 = bi * 128, n0 = bj * 128;
+    long gr0 = 0, gc0 = 0;
+    if (g.lower) {
+        gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
+        gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
+        if (gc0 > gr0 + 127) return;  // whole tile above the diagonal (block-uniform)
+    }
+    __shared__ __attribute__((aligned(1024))) chunk_t As[2][128 * 8];
+    __shared__ __attribute__((aligned(1024))) chunk_t Bs[2][128 * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
+    if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
+
+    // DMA map: instruction i of wave w covers rows 8·(4i+w) .. +8; lane -> row 8·(4i+w) + (lane>>3), slot lane&7
+    const int drow = lane >> 3;
+    const T* Ag[4];
+    const T* Bg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * (4 * i + w) + drow;
+        const int cch = (lane & 7) ^ ((r >> 1) & 7);
+        Ag[i] = A + (long)(m0 + r) * lda + cch * VEC;
+        Bg[i] = B + (long)(n0 + r) * ldb + cch * VEC;
+    }
+    // The DMA is issued from inline asm: hipcc (ROCm 7.2) otherwise drains vmcnt(0) in front of the next ds_read of the
+    // OTHER buffer (it cannot tell the two apart), which serialises the prefetch.  The only consumer-side wait is the
+    // explicit vmcnt(0) in front of the step's barrier below.
+    const unsigned ldsA = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&As[0][0];
+    const unsigned ldsB = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&Bs[0][0];
+    auto dma1 = [&](const T* src, unsigned dst) {
+        unsigned keep;
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(d)
+                     : "memory");
+    };
+    auto dma = [&](int buf, long kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+            dma1(Bg[i] + kt * BK, ldsB + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+        }
+    };
+    auto dma_wait_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    const int li = lane & 15, lg = lane >> 4;
+    acc_t acc[4][4];
+    CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
+    const CT* const Cr = active ? Cw : C + li;
+    dma(0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
+
+    // fragment slots: row wr·64 + t·16 + li, chunk 4h+lg -> slot (row·8) + ((4h+lg) ^ swz(li))
+    const int sw = (li >> 1) & 7;
+    const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
+    const int nk = K / BK;
+    dma_wait_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        dma(cur ^ 1, (kt + 1 < nk) ? kt + 1 : kt);  // the last step re-fetches its own tile into the idle buffer
+        chunk_t a[2][4], b[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sl = (4 * h + lg) ^ sw;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[h][t] = As[cur][fa + t * 128 + sl];
+                b[h][t] = Bs[cur][fb + t * 128 + sl];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[h][mt][v], b[h][nt][v], acc[mt][nt]);
+#if GPMI_GEMM_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC - 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC + 8, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this step in front of the vmcnt(0) + barrier
+        dma_wait_barrier();
     }
 
     if (active) {
@@ -227,8 +461,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(T* C, long ldc, con
 }
 
 // Debug reference (gemm_variant = 1): same contract, plain VALU, one thread per C element.
-template <typename T, bool KM>
-__global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
+template <typename T, bool KM, typename CT = T>
+__global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
                                                                int N, int K, GridMap g) {
     const int col = blockIdx.x * 16 + (threadIdx.x & 15);
     const int row = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -238,7 +472,7 @@ __global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(T* C, long ldc, co
         // mirror the MFMA kernel's coverage: it updates whole 64×64 wave tiles touching the diagonal
         if ((gc / 64) * 64 > (gr / 64) * 64 + 63) return;
     }
-    T s = 0;
+    CT s = 0;
     for (int k = 0; k < K; ++k)
         s += KM ? A[(long)k * lda + row] * B[(long)k * ldb + col] : A[(long)row * lda + k] * B[(long)col * ldb + k];
     C[(long)row * ldc + col] -= s;
@@ -715,15 +949,15 @@ __global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src
     if (i < n) dst[i] = (TD)(scale * (double)src[i]);
 }
 // r[j] -= Σ_{i<nrows} L[i][j] a[i]  for j < ncols.  grid (ceil(ncols/256), ceil(nrows/64)); one atomic per (block, column)
-template <typename T>
+template <typename T, typename RT = T>
 __global__ __launch_bounds__(256) void gemv_t_kernel(const T* __restrict__ L, long ldl, long nrows, long ncols,
-                                                      const T* __restrict__ a, T* __restrict__ r) {
+                                                      const T* __restrict__ a, RT* __restrict__ r) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     const long i0 = (long)blockIdx.y * 64;
     if (j >= ncols) return;
     const long i1 = (i0 + 64 < nrows) ? i0 + 64 : nrows;
-    T acc = 0;
-    for (long i = i0; i < i1; ++i) acc = fma(L[i * ldl + j], a[i], acc);
+    RT acc = 0;
+    for (long i = i0; i < i1; ++i) acc = fma((RT)L[i * ldl + j], (RT)a[i], acc);
     atomicAdd(r + j, -acc);
 }
 

@@ -11,8 +11,10 @@
 //     Xc ← Xc L_z⁻ᵀ = B_cᵀ          trsm_rec (MFMA gemm inside)
 //     D_acc −= Xcᵀ Xc               MFMA gemm, k-major operands (SYRK over the data points)
 //     c_acc −= Xcᵀ b_c              gemv_t
-//   (T = f32 or f64).  The M×M side (K_zz, both Choleskys, all vector solves) is always fp64: in fp32 mode
-//   L_z is rounded to fp32 for the streamed TRSM only.  ‖A‖²_F = tr(B Bᵀ) = −tr(D_acc) (ELBO trace term, :251).
+//   (T = f32 or f64).  The M×M side (K_zz, both Choleskys, all vector solves) is always fp64, and so are the
+//   accumulators of the N-long reductions (D_acc, c_acc, ‖B‖²_F): in fp32 mode the operands stream in fp32 through
+//   the fp32 MFMA, whose chain is flushed into fp64 every 256 data points; L_z is rounded to fp32 for the streamed
+//   TRSM only.  ‖A‖²_F = tr(B Bᵀ) = −tr(D_acc) (ELBO trace term, :251).
 #pragma once
 
 struct gp_vfe {
@@ -72,9 +74,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     for (long i = 0; i < m; ++i) jit_h[i] = jitter;
 
     const size_t xs_b = sizeof(T) * xs_h.size(), zsT_b = sizeof(T) * zsT_h.size(), zsD_b = sizeof(double) * zsD_h.size();
-    const size_t rs_b = sizeof(T) * (size_t)npad, D_b = sizeof(T) * (size_t)(mp + 128) * ld;
+    const size_t rs_b = sizeof(T) * (size_t)npad, D_b = sizeof(double) * (size_t)(mp + 128) * ld;
     const size_t X_b = sizeof(T) * (size_t)(CH + 128) * ld, L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
-    const size_t vT_b = sizeof(T) * (size_t)mp, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
+    const size_t vT_b = sizeof(double) * (size_t)mp, LT_b = sizeof(T) * (size_t)(mp + 128) * ld, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
     void *xs_v = 0, *zsT_v = 0, *zsD_v = 0, *rs_v = 0, *b_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *LzT_v = 0, *cT_v = 0,
          *vec_v = 0, *jit_v = 0;
     constexpr bool is_f64 = sizeof(T) == 8;
@@ -87,7 +89,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(ctx_alloc(c, X_b, &X_v));
     RC(ctx_alloc(c, L_b, &Lz_v));
     RC(ctx_alloc(c, L_b, &Ld_v));
-    if (!is_f64) RC(ctx_alloc(c, D_b, &LzT_v));
+    if (!is_f64) RC(ctx_alloc(c, LT_b, &LzT_v));
     RC(ctx_alloc(c, vT_b, &cT_v));
     RC(ctx_alloc(c, vD_b, &vec_v));
     RC(ctx_alloc(c, jit_b, &jit_v));
@@ -140,17 +142,17 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             hipLaunchKernelGGL(sumsq_accum_kernel<T>, dim3((unsigned)CH), dim3(256), 0, s, (const T*)X_v, ld, mp,
                                c->scal_dev + 4);                                                   // ‖A‖²_F in fp64
             HIPCHK(hipGetLastError());
-            RC(launch_gemm<T>(c, s, (T*)D_v, ld, (const T*)X_v, ld, (const T*)X_v, ld, mp, mp, CH, plain_map(1, 0, 0), true));
-            hipLaunchKernelGGL(gemv_t_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(CH / 64)), dim3(256), 0, s,
-                               (const T*)X_v, ld, CH, mp, (const T*)b_v + c0, (T*)cT_v);
+            RC((launch_gemm<T, double>(c, s, (double*)D_v, ld, (const T*)X_v, ld, (const T*)X_v, ld, mp, mp, CH, plain_map(1, 0, 0), true)));
+            hipLaunchKernelGGL((gemv_t_kernel<T, double>), dim3((unsigned)((mp + 255) / 256), (unsigned)(CH / 64)), dim3(256), 0, s,
+                               (const T*)X_v, ld, CH, mp, (const T*)b_v + c0, (double*)cT_v);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL((convert_kernel<T, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s, (const T*)cT_v, vec,
-                           mp, -1.0);                                                              // c = B b_y
+        hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s,
+                           (const double*)cT_v, vec, mp, -1.0);                                                              // c = B b_y
         HIPCHK(hipGetLastError());
         // ---- D = I + B Bᵀ (fp64, symmetric), Λ_ε = chol(D)                                       :68-69
-        hipLaunchKernelGGL(neg_sym_to_f64_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s,
-                           (const T*)D_v, ld, Ld, ld, mp);
+        hipLaunchKernelGGL(neg_sym_to_f64_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s,
+                           (const double*)D_v, ld, Ld, ld, mp);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(diag_shift_trace_kernel, dim3(1), dim3(256), 0, s, Ld, ld, mp, m, 1.0, c->scal_dev + 2);
         HIPCHK(hipGetLastError());
@@ -196,7 +198,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     ctx_release(c, b_v, rs_b);
     ctx_release(c, D_v, D_b);
     ctx_release(c, X_v, X_b);
-    ctx_release(c, LzT_v, D_b);
+    ctx_release(c, LzT_v, LT_b);
     ctx_release(c, cT_v, vT_b);
     ctx_release(c, jit_v, jit_b);
     if (rc == 0 && info_h != 0) rc = info_h;

@@ -40,7 +40,7 @@ def test_mfma_f64_lane_maps(lib, h):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 128, 64), (64, 64, 64), (192, 64, 128), (320, 448, 272),
-                                    (1024, 1024, 1024)])
+                                    (1024, 1024, 1024), (2176, 2304, 48), (4224, 1152, 32)])
 def test_gemm_nt_rect(lib, h, m, n, k):
     from abstractgps_jl_amd._lib import check
 
@@ -61,13 +61,16 @@ def test_gemm_nt_rect(lib, h, m, n, k):
     assert torch.equal(Cm[m:], ref[m:]) and torch.equal(Cm[:, n:], ref[:, n:])
 
 
-@pytest.mark.parametrize("m,n,off", [(256, 256, 0), (320, 192, 64), (512, 128, 128)])
-def test_gemm_nt_lower_skips_upper(lib, h, m, n, off):
-    """lower mode: 64×64 sub-tiles strictly above the diagonal are not updated; everything on/below is."""
+@pytest.mark.parametrize("m,n,off,coff", [(256, 256, 0, 0), (320, 192, 64, 64), (512, 128, 128, 128),
+                                          (2304, 2304, 0, 0), (2432, 2176, 384, 128), (3200, 2560, 1152, 0),
+                                          (2048, 2048, 64, 64)])
+def test_gemm_nt_lower_skips_upper(lib, h, m, n, off, coff):
+    """lower mode: 64×64 sub-tiles strictly above the diagonal are not updated; everything on/below is.
+    The large cases run in the XCD-aware super-tile order (≥ 256 tiles), also as a trapezoid (row0 > col0)."""
     from abstractgps_jl_amd._lib import check, gp_grid
 
     k = 64
-    g = torch.Generator(device="cuda").manual_seed(m + n + off)
+    g = torch.Generator(device="cuda").manual_seed(m + n + off + coff)
     ld = n + 32
     A = torch.randn(m + 128, k + 32, dtype=torch.float64, device="cuda", generator=g)
     B = torch.randn(n + 128, k + 32, dtype=torch.float64, device="cuda", generator=g)
@@ -75,15 +78,16 @@ def test_gemm_nt_lower_skips_upper(lib, h, m, n, off):
     full = -(A[:m, :k] @ B[:n, :k].T)
     grid = gp_grid(1, 0, 1, 0, 1, 1)
     torch.cuda.synchronize()
-    check(lib.gpd_gemm_nt(h, P(Cm), ld, P(A), k + 32, P(B), k + 32, m, n, k, C.byref(grid), off, off))
+    check(lib.gpd_gemm_nt(h, P(Cm), ld, P(A), k + 32, P(B), k + 32, m, n, k, C.byref(grid), off, coff))
     _sync(lib, h)
     r = torch.arange(m, device="cuda")[:, None] + off
-    c = torch.arange(n, device="cuda")[None, :] + off
+    c = torch.arange(n, device="cuda")[None, :] + coff
     need = c <= r
     got = Cm[:m, :n]
     assert (got - full)[need].abs().max().item() < 1e-11
     skipped = (c // 64) > (r // 64)
-    assert got[skipped].abs().max().item() == 0.0
+    if skipped.any():
+        assert got[skipped].abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("n,extra", [(64, 0), (64, 192), (128, 64), (192, 128), (256, 0), (1024, 256)])
