@@ -830,11 +830,21 @@ int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null) {
         delete c;
         return set_hip_err(e, "hipStreamCreateWithPriority", __LINE__);
     }
-    if (const char* s = getenv("GPMI_NB")) c->nb = atol(s);
-    if (const char* s = getenv("GPMI_LOOKAHEAD")) c->lookahead = atoi(s);
-    if (const char* s = getenv("GPMI_LDPAD")) c->ldpad = round_up(std::max(0L, atol(s)), 16);
     reg_add(c);
     *out = c;
+    // GPMI_PARAMS="name=value,name=value": tuning overrides for experiments (same names as gp_ctx_set_param)
+    if (const char* s = getenv("GPMI_PARAMS")) {
+        std::string all(s);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t e = all.find(',', pos);
+            if (e == std::string::npos) e = all.size();
+            const std::string kv = all.substr(pos, e - pos);
+            const size_t q = kv.find('=');
+            if (q != std::string::npos) (void)gp_ctx_set_param(c, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1));
+            pos = e + 1;
+        }
+    }
     return 0;
 }
 

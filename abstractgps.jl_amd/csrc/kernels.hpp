@@ -593,14 +593,32 @@ template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) {
     return r;
 }
 
+template <typename T> __device__ __forceinline__ T lane_bcast(T v, int srclane);  // srclane must be a compile-time constant
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int srclane) {
+    const long bits = __builtin_bit_cast(long, v);
+    const int lo = __builtin_amdgcn_readlane((int)bits, srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), srclane);
+    return __builtin_bit_cast(double, ((long)hi << 32) | (long)(unsigned)lo);
+}
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int srclane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
+}
+
+// Blocked by PB = 8 columns.  Inside a block every cross-lane value (pivot, the multipliers L[t][c] of the block's
+// own columns) travels by v_readlane with a constant lane index — the serial chain per column is
+// readlane -> rsqrt -> scale -> readlane -> fma, no LDS round trip; the finished 8 columns are parked in LDS as
+// colb[t][k] and applied to the columns right of the block as one rank-8 update (8 consecutive doubles per
+// broadcast read, i.e. ds_read_b128 ×4 per target column instead of 8 separate reads).
 template <typename T>
 __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long lda, int* __restrict__ info, int col0,
                                                        int n_valid, double* __restrict__ logdet_acc,
                                                        T* __restrict__ lt_ws) {
     using chunk_t = typename Tr<T>::chunk_t;
     constexpr int VEC = Tr<T>::VEC;
-    __shared__ __attribute__((aligned(16))) T colb[2][64];
+    constexpr int PB = 8;
+    __shared__ __attribute__((aligned(16))) T colb[64][PB];
     const int r = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);  // look-ahead: this wave shares SIMDs with fp64-MFMA gemm waves and must win issue slots
     T a[64];
     const chunk_t* row = reinterpret_cast<const chunk_t*>(A + (long)r * lda);
 #pragma unroll
@@ -612,22 +630,42 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
     int bad = 0;
     T mydiag = T(1), myrinv = T(1);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        const T piv = __shfl(a[c], c, 64);  // pivot from lane c
-        if (!(piv > T(0)) && bad == 0) bad = c + 1;
-        const T ri = fast_rsqrt<T>(piv);     // 1 / L_cc
-        const T dd = piv * ri;               // L_cc
-        const T v = (r == c) ? dd : a[c] * ri;
-        a[c] = v;
-        if (r == c) {
-            mydiag = dd;
-            myrinv = ri;
-        }
-        T* cb = colb[c & 1];
-        cb[r] = v;
-        __syncthreads();
+    for (int c0 = 0; c0 < 64; c0 += PB) {
 #pragma unroll
-        for (int t = c + 1; t < 64; ++t) a[t] = fma(-v, cb[t], a[t]);
+        for (int k = 0; k < PB; ++k) {
+            const int c = c0 + k;
+            const T piv = lane_bcast<T>(a[c], c);
+            if (!(piv > T(0)) && bad == 0) bad = c + 1;
+            const T ri = fast_rsqrt<T>(piv);  // 1 / L_cc
+            const T dd = piv * ri;            // L_cc
+            const T v = (r == c) ? dd : a[c] * ri;
+            a[c] = v;
+            if (r == c) {
+                mydiag = dd;
+                myrinv = ri;
+            }
+            colb[r][k] = v;
+#pragma unroll
+            for (int t = c + 1; t < c0 + PB; ++t) a[t] = fma(-v, lane_bcast<T>(v, t), a[t]);
+        }
+        if (c0 + PB < 64) {
+            __syncthreads();
+#pragma unroll
+            for (int t = c0 + PB; t < 64; ++t) {
+                T cb[PB];
+#pragma unroll
+                for (int q = 0; q < PB / VEC; ++q) {
+                    const chunk_t cv = *reinterpret_cast<const chunk_t*>(&colb[t][q * VEC]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) cb[q * VEC + e] = cv[e];
+                }
+                T s = a[t];
+#pragma unroll
+                for (int k = 0; k < PB; ++k) s = fma(-a[c0 + k], cb[k], s);
+                a[t] = s;
+            }
+            __syncthreads();
+        }
     }
     T* wrow = A + (long)r * lda;
 #pragma unroll
@@ -660,6 +698,7 @@ __global__ __launch_bounds__(64) void trsm_64_kernel(T* __restrict__ X, long ldx
     constexpr int VEC = Tr<T>::VEC;
     __shared__ __attribute__((aligned(16))) T Lt[64][64];  // Lt[c][t] = L[t][c]; Lt[c][c] = 1/L[c][c]
     const int tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
     if (lt_pre != nullptr) {
         const chunk_t* src = reinterpret_cast<const chunk_t*>(lt_pre);
         chunk_t* dst = reinterpret_cast<chunk_t*>(&Lt[0][0]);

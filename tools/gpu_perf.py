@@ -43,8 +43,12 @@ def main():
     ap.add_argument("--sizes", default="4096,16384")
     ap.add_argument("--nbs", default="0,1024,2048,4096")
     ap.add_argument("--big", type=int, default=0)
+    ap.add_argument("--params", default="", help="comma list name=value applied to the ctx (e.g. sched=1,trsm_mfma=1)")
     args = ap.parse_args()
     ctx = agp.Context(0)
+    for kv in [t for t in args.params.split(",") if t]:
+        k, v = kv.split("=")
+        ctx.set_param(k, int(v))
     c = agp._lib.C.c_double()
     agp._lib.check(ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, agp._lib.C.byref(c)))
     print(json.dumps({"mfma_f64_ceiling_tflops": c.value}), flush=True)
