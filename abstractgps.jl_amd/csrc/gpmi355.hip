@@ -70,6 +70,7 @@ struct gp_ctx {
     int gemm_variant = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
+    int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
     int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;
@@ -85,6 +86,7 @@ struct gp_ctx {
     std::vector<GemmRec> gemm_recs;
     hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
     int* info_dev = nullptr;
+    int* ticket_dev = nullptr;   // load tickets of panel64_kernel ([0]: main stream, [32]: panel stream)
     void* w_ws = nullptr;        // I − inv(L_jj) tiles for the MFMA triangular solve (trtri_64 output)
     size_t w_ws_bytes = 0;
     void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
@@ -157,6 +159,7 @@ static void ctx_unref(gp_ctx* c) {
     for (auto e : c->ev_phase)
         if (e) (void)hipEventDestroy(e);
     if (c->info_dev) (void)hipFree(c->info_dev);
+    if (c->ticket_dev) (void)hipFree(c->ticket_dev);
     if (c->lt_ws) (void)hipFree(c->lt_ws);
     if (c->w_ws) (void)hipFree(c->w_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
@@ -284,6 +287,18 @@ static long split_half(long n) {  // largest multiple of 64 that is <= n/2 (>= 6
 template <typename T>
 static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long n, long mtot, int* info_dev,
                          long gcol0, long n_valid, double* logdet_dev) {
+    if (n <= 64 && c->panel_fused) {  // one launch: tile Cholesky (replicated per workgroup) + X L⁻ᵀ of all rows below
+        const long mrows = mtot - j0 - 64;
+        const unsigned nblk = (unsigned)std::max(1L, (mrows + 127) / 128);
+        if (!c->ticket_dev) {
+            HIPCHK(hipMalloc((void**)&c->ticket_dev, sizeof(int) * 64));
+            HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
+        }
+        hipLaunchKernelGGL(panel64_kernel<T>, dim3(nblk), dim3(256), 0, s, A + j0 * lda + j0, lda, (int)mrows, info_dev,
+                           (int)(gcol0 + j0), (int)n_valid, logdet_dev, c->ticket_dev + (s == c->sp ? 32 : 0));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (n <= 64) {
         T* d = A + j0 * lda + j0;
         if (!c->lt_ws) HIPCHK(hipMalloc(&c->lt_ws, sizeof(double) * 64 * 64));
@@ -872,6 +887,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "sched")) c->sched = (int)v;
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
+    else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);

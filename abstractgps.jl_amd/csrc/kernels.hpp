@@ -685,6 +685,178 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
 }
 
 // ------------------------------------------------------------------------------------------------
+// panel64: ONE launch per 64-column leaf of the panel factorisation — Cholesky of the 64×64 diagonal tile AND
+//   X ← X L⁻ᵀ for every row below it (replaces potf2_64 + trsm_64 and their dependent-launch gap).
+//   grid = ceil(mrows / 128) workgroups (at least 1) of 4 waves; workgroup b owns rows [64 + 128 b, +128) under the
+//   tile.  EVERY workgroup factors the diagonal tile itself, redundantly and bit-identically, in LDS — the serial
+//   chain costs latency, not throughput, so replicating it is free and removes the global hand-off.  The input tile
+//   must stay intact until every workgroup has read it (late workgroups start after early ones retire), so each
+//   workgroup ticks `ticket` after its load and the LAST one to load is the one that stores the factor, Σ log L_ii
+//   and the LAPACK info (and re-arms the ticket for the next launch on the stream).
+//   The tile is processed in 16-column blocks: wave 0 factors the 16×16 diagonal block in registers (lane = row, all
+//   cross-lane traffic by v_readlane) and, in the same instruction stream, builds its inverse (lane = column of
+//   inv(L16); forward substitution fed by the same readlanes — it fills the latency holes of the pivot chain).  Every
+//   other operation is a 16×16×16 product P·Qᵀ on the fp64/fp32 MFMA with both operands read row-wise from LDS:
+//     block TRSM   B_ij ← B_ij · Inv_jᵀ          (tile rows below the block and the workgroup's X rows)
+//     block update B_ik ← B_ik − B_ij · B_kjᵀ     (k > j)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
+                                                       int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket) {
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    using acc_t = typename TR::acc_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int LD = 65, LI = 17;
+    __shared__ T Ds[64 * LD];
+    __shared__ T Xs[128 * LD];
+    __shared__ T Inv[4][16 * LI];
+    __shared__ int writer_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    int xrows = mrows - (int)blockIdx.x * 128;
+    xrows = xrows < 0 ? 0 : (xrows > 128 ? 128 : xrows);
+    T* const Xg = A + (long)(64 + (long)blockIdx.x * 128) * lda;
+
+    for (int e = tid; e < 64 * (64 / VEC); e += 256) {
+        const int row = e / (64 / VEC), cc = e % (64 / VEC);
+        const chunk_t v = *reinterpret_cast<const chunk_t*>(A + (long)row * lda + cc * VEC);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = v[q];
+    }
+    for (int e = tid; e < 128 * (64 / VEC); e += 256) {
+        const int row = e / (64 / VEC), cc = e % (64 / VEC);
+        chunk_t v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = T(0);
+        if (row < xrows) v = *reinterpret_cast<const chunk_t*>(Xg + (long)row * lda + cc * VEC);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = v[q];
+    }
+    __syncthreads();  // every load of the input tile by this workgroup has completed (values are in LDS)
+    if (tid == 0) writer_s = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+
+    int bad = 0;
+    T mydiag[4] = {T(1), T(1), T(1), T(1)};  // L_cc of column 16j + li (lanes < 16 of wave 0); log() is taken once, by the writer
+    const int nxt = xrows >> 4;  // 16-row tiles of X owned by this workgroup
+    // P·Qᵀ fragment: lane supplies P[li][4m + lg] and Q[li][4m + lg]
+    auto mma16 = [&](acc_t d, const T* P, int ldp, const T* Q, int ldq, bool neg) -> acc_t {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            T a = P[li * ldp + 4 * m + lg];
+            const T b = Q[li * ldq + 4 * m + lg];
+            if (neg) a = -a;
+            d = TR::mfma(a, b, d);
+        }
+        return d;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (w == 0) {  // 16×16 diagonal block: L16 and inv(L16)
+            T a[16], x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = Ds[(16 * j + li) * LD + 16 * j + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const T piv = lane_bcast<T>(a[c], c);
+                if (!(piv > T(0)) && bad == 0) bad = 16 * j + c + 1;
+                const T ri = fast_rsqrt<T>(piv);
+                const T dd = piv * ri;
+                const T v = (li == c) ? dd : a[c] * ri;
+                a[c] = v;
+#pragma unroll
+                for (int t = c + 1; t < 16; ++t) a[t] = fma(-v, lane_bcast<T>(v, t), a[t]);
+                T sacc = (li == c) ? T(1) : T(0);
+#pragma unroll
+                for (int k = 0; k < c; ++k) sacc = fma(-lane_bcast<T>(a[k], c), x[k], sacc);
+                x[c] = sacc * ri;
+                if (li == c) mydiag[j] = dd;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c <= li) Ds[(16 * j + li) * LD + 16 * j + c] = a[c];
+                    Inv[j][c * LI + li] = x[c];
+                }
+            }
+        }
+        __syncthreads();
+        // block TRSM: tasks 0..2-j: tile blocks (j+1+q, j); then the X row tiles
+        {
+            const int ntile = 3 - j;
+            for (int q = w; q < ntile + nxt; q += 4) {
+                T* P = (q < ntile) ? &Ds[(16 * (j + 1 + q)) * LD + 16 * j] : &Xs[(16 * (q - ntile)) * LD + 16 * j];
+                acc_t d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = T(0);
+                d = mma16(d, P, LD, &Inv[j][0], LI, false);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[TR::crow(lane, r) * LD + li] = d[r];
+            }
+        }
+        __syncthreads();
+        // block updates: tile pairs (i, k), j < k <= i <= 3, then (X row tile, k), k = j+1..3
+        if (j < 3) {
+            const int nk = 3 - j;
+            const int npair = nk * (nk + 1) / 2;
+            for (int q = w; q < npair + nxt * nk; q += 4) {
+                T* Cb;
+                const T* P;
+                const T* Q;
+                if (q < npair) {
+                    int i = 0, rem = q;  // enumerate (i, k): i = j+1..3, k = j+1..i
+                    while (rem > i) {
+                        rem -= i + 1;
+                        ++i;
+                    }
+                    const int bi = j + 1 + i, bk = j + 1 + rem;
+                    Cb = &Ds[(16 * bi) * LD + 16 * bk];
+                    P = &Ds[(16 * bi) * LD + 16 * j];
+                    Q = &Ds[(16 * bk) * LD + 16 * j];
+                } else {
+                    const int qq = q - npair, rt = qq / nk, bk = j + 1 + qq % nk;
+                    Cb = &Xs[(16 * rt) * LD + 16 * bk];
+                    P = &Xs[(16 * rt) * LD + 16 * j];
+                    Q = &Ds[(16 * bk) * LD + 16 * j];
+                }
+                acc_t d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = Cb[TR::crow(lane, r) * LD + li];
+                d = mma16(d, P, LD, Q, LD, true);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cb[TR::crow(lane, r) * LD + li] = d[r];
+            }
+            __syncthreads();
+        }
+    }
+
+    // write back
+    for (int e = tid; e < xrows * 64; e += 256) {
+        const int row = e >> 6, c = e & 63;
+        Xg[(long)row * lda + c] = Xs[row * LD + c];
+    }
+    if (writer_s) {  // (the barriers of the block loop made writer_s visible)
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int row = e >> 6, c = e & 63;
+            if (c <= row) A[(long)row * lda + c] = Ds[row * LD + c];
+        }
+        if (w == 0) {
+            double logd = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane < 16 && col0 + 16 * j + lane < n_valid) logd += log((double)mydiag[j]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) logd += __shfl_xor(logd, o, 64);
+            if (lane == 0) {
+                if (logdet_acc) atomicAdd(logdet_acc, logd);
+                if (bad && info && *info == 0) *info = col0 + bad;
+                *ticket = 0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // trsm_64: X[M×64] ← X · L⁻ᵀ, L 64×64 lower (row-major).  One lane per row of X (row in registers),
 //   one wave (64 rows) per block so that M = 65 536 rows spread as 4 waves per CU.  Lᵀ sits in LDS so the
 //   column of L needed after x_c is final is one contiguous broadcast read.  lt_pre (nullable): the

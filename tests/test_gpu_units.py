@@ -90,7 +90,8 @@ def test_gemm_nt_lower_skips_upper(lib, h, m, n, off, coff):
         assert got[skipped].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("n,extra", [(64, 0), (64, 192), (128, 64), (192, 128), (256, 0), (1024, 256)])
+@pytest.mark.parametrize("n,extra", [(64, 0), (64, 192), (128, 64), (192, 128), (256, 0), (1024, 256),
+                                      (64, 128 * 700), (128, 128 * 300 + 64)])  # > 256 workgroups: late starters
 def test_potrf_and_trsm(lib, h, n, extra):
     from abstractgps_jl_amd._lib import check
 
