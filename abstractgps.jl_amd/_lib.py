@@ -68,6 +68,7 @@ PROTOTYPES = {
     "gpd_gemv_t": (i32, [vp, vp, i64, i64, i64, vp, vp]),
     "gpd_rowsumsq": (i32, [vp, vp, i64, i64, i64, vp]),
     "gpd_sync": (i32, [vp]),
+    "gpd_gemm_time": (i32, [vp, C.POINTER(dbl), C.POINTER(i64)]),
     "gp_probe_mfma_f64": (i32, [vp, vp, vp, vp]),
     "gp_bench_mfma_f64": (i32, [vp, i32, C.POINTER(dbl)]),
 }

@@ -1285,6 +1285,24 @@ int32_t gpd_rowsumsq(gp_ctx* c, const double* x, int64_t ldx, int64_t nrows, int
     return 0;
 }
 
+int32_t gpd_gemm_time(gp_ctx* c, double* ms_out, int64_t* launches_out) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->sm));
+    double tot = 0;
+    for (auto& r : c->gemm_recs) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms;
+    }
+    if (ms_out) *ms_out = tot;
+    if (launches_out) *launches_out = (int64_t)c->gemm_recs.size();
+    c->gemm_recs.clear();
+    c->ev_used = 0;
+    return 0;
+}
+
 int32_t gpd_sync(gp_ctx* c) {
     if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
     HIPCHK(hipSetDevice(c->device));

@@ -104,6 +104,15 @@ class HipTileBackend:
         self._lib.check(self.lib.gpd_sync(self.h))
         torch.cuda.synchronize(self.device)
 
+    def time_kernels(self, on: bool):
+        self.ctx.set_param("time_kernels", 1 if on else 0)
+
+    def gemm_time(self):
+        """(Σ ms, launches) of the MFMA update launches since the last call (needs time_kernels)."""
+        ms, cnt = C.c_double(), C.c_int64()
+        self._lib.check(self.lib.gpd_gemm_time(self.h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
 
 def _sub(t: torch.Tensor, r0: int, c0: int) -> torch.Tensor:
     """View of the 2-D row-major tensor t starting at (r0, c0) (same leading dimension)."""
@@ -116,6 +125,7 @@ class BlockCyclicEngine:
     def __init__(self, device: int = 0, nb: int = 1024, backend=None, grid: Optional[tuple[int, int]] = None):
         if nb % 128:
             raise ValueError("nb must be a multiple of 128")
+        self.coll = dist.is_initialized()   # issue the collectives whenever a process group exists (also world 1: API check)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.P, self.Q = grid or choose_grid(self.world)
@@ -139,7 +149,7 @@ class BlockCyclicEngine:
         return p * self.Q + q
 
     def _bcast_world(self, t, src):
-        if self.world > 1:
+        if self.coll:
             dist.broadcast(t, src=src)
 
     def _bcast_col(self, t, src_p, q):
@@ -169,6 +179,7 @@ class BlockCyclicEngine:
 
     def _fit(self, kernel, x, sigma2, y, mean=None):
         be, P, Q, p, q, NB = self.be, self.P, self.Q, self.p, self.q, self.nb
+        self.gemm_flops = 0.0
         X = np.asarray(x, dtype=np.float64)
         X = X[:, None] if X.ndim == 1 else X
         n, d = X.shape
@@ -207,14 +218,23 @@ class BlockCyclicEngine:
             A[nlb_r * NB, :n_loc] = be.from_numpy(dloc)
 
         max_rows = nlb_r * NB + RHS_ROWS
-        Pbuf = [be.empty(max_rows, NB) for _ in range(P)]     # panel piece of each process row
+        # two sets of panel buffers: panel k+1 is factored and travels while the bulk of update k still runs
+        Pbufs = [[be.empty(max_rows, NB) for _ in range(P)] for _ in range(2)]
         Bbuf = be.empty(n_loc + 128, NB)                      # B operand gathered in my local column order
         Lkk = be.empty(NB, NB)
 
-        for k in range(nblk):
+        def rows_below(k):
+            """per process row pp: (first local row below block k, number of local rows from there incl. RHS rows)"""
+            out = []
+            for pp in range(P):
+                r0p = self._nlb_before(k, pp, P) * NB
+                out.append((r0p, nlb_r * NB + (RHS_ROWS if pp == p_rhs else 0) - r0p))
+            return out
+
+        def panel(k, Pbuf):
+            """factor block column k on its owners, copy my piece into Pbuf[p]; returns the async broadcast handles"""
             pk, qk = k % P, k % Q
             lbk_r, lbk_c = k // P, k // Q                     # local block indices on the owners
-            # ---- panel: factor + solve on process column qk
             if q == qk:
                 c0 = lbk_c * NB
                 if p == pk:
@@ -228,36 +248,63 @@ class BlockCyclicEngine:
                         r0 = self._nlb_before(k, p, P) * NB   # my first local row with global block > k
                         if m_loc - r0 > 0:
                             be.trsm(_sub(A, r0, c0), ldl, m_loc - r0, Lkk, NB, NB)
-            # ---- panel pieces to everyone (one per process row)
-            rows_of = []
-            for pp in range(P):
-                r0p = self._nlb_before(k, pp, P) * NB         # first local row (on process row pp) below block k
-                mp = nlb_r * NB + (RHS_ROWS if pp == p_rhs else 0) - r0p
-                rows_of.append((r0p, mp))
+            works = []
+            for pp, (r0p, mp) in enumerate(rows_below(k)):    # one piece per process row, to everyone
                 if mp <= 0:
                     continue
                 piece = Pbuf[pp][:mp]
                 if p == pp and q == qk:
                     piece.copy_(A[r0p:r0p + mp, lbk_c * NB:(lbk_c + 1) * NB])
-                self._bcast_world(piece, self._rank_of(pp, qk))
-            # ---- local trailing update
+                if self.coll:
+                    works.append(dist.broadcast(piece, src=self._rank_of(pp, qk), async_op=True))
+            return works
+
+        def update(k, Pbuf, lj_lo, lj_hi):
+            """A[rows below k, local block columns lj_lo..lj_hi) -= panel_k(rows) · panel_k(cols)ᵀ (lower part only)"""
+            ncols = (lj_hi - lj_lo) * NB
+            rows = rows_below(k)
+            r0, mrows = rows[p]
+            if ncols <= 0 or mrows <= 0:
+                return
+            for lj in range(lj_lo, lj_hi):                    # B operand: panel rows of global block gj, my column order
+                gj = lj * Q + q
+                pp = gj % P
+                off = (gj // P) * NB - rows[pp][0]
+                Bbuf[(lj - lj_lo) * NB:(lj - lj_lo + 1) * NB].copy_(Pbuf[pp][off:off + NB])
+            be.gemm_nt(_sub(A, r0, lj_lo * NB), ldl, Pbuf[p], NB, Bbuf, NB, mrows, ncols, NB, grid, r0, lj_lo * NB)
+            # algorithmic flops of this launch: local elements on/below the global diagonal × 2·NB
+            cnt = 0
+            for lj in range(lj_lo, lj_hi):
+                gj = lj * Q + q
+                for li_ in range(r0 // NB, nlb_r):
+                    gi = li_ * P + p
+                    cnt += NB * NB if gi > gj else (NB * (NB + 1) // 2 if gi == gj else 0)
+                if p == p_rhs:
+                    cnt += RHS_ROWS * NB
+            self.gemm_flops += 2.0 * NB * cnt
+
+        for w_ in panel(0, Pbufs[0]):
+            w_.wait()
+        for k in range(nblk):
+            cur, nxt = Pbufs[k % 2], Pbufs[(k + 1) % 2]
             lj0 = self._nlb_before(k, q, Q)                   # my first local block column with global index > k
-            ncols = (nlb_c - lj0) * NB
-            r0, mrows = rows_of[p]
-            if ncols > 0 and mrows > 0:
-                for lj in range(lj0, nlb_c):                  # B operand: panel rows of global block gj, my column order
-                    gj = lj * Q + q
-                    pp = gj % P
-                    off = (gj // P) * NB - rows_of[pp][0]
-                    Bbuf[(lj - lj0) * NB:(lj - lj0 + 1) * NB].copy_(Pbuf[pp][off:off + NB])
-                be.gemm_nt(_sub(A, r0, lj0 * NB), ldl, Pbuf[p], NB, Bbuf, NB, mrows, ncols, NB, grid, r0, lj0 * NB)
+            works = []
+            lj_rest = lj0
+            if k + 1 < nblk:
+                if q == (k + 1) % Q:                          # look-ahead: bring block column k+1 up to date first ...
+                    update(k, cur, lj0, lj0 + 1)
+                    lj_rest = lj0 + 1
+                works = panel(k + 1, nxt)                     # ... factor it and put it on the wire (asynchronous)
+            update(k, cur, lj_rest, nlb_c)                    # the bulk of the trailing update overlaps the transfers
+            for w_ in works:
+                w_.wait()
 
         # ---- scalars: logdet (diag owners), ‖z‖² (RHS row pieces), info
         if p == p_rhs:
             be.rowsumsq(_sub(A, nlb_r * NB, 0), ldl, 1, n_loc, scal[1:2])
         red = torch.stack([scal[0], scal[1]])
         info_f = info.to(torch.float64)
-        if self.world > 1:
+        if self.coll:
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
             dist.all_reduce(info_f, op=dist.ReduceOp.MAX)
         logdet_half, sq = float(red[0].item()), float(red[1].item())
@@ -287,5 +334,6 @@ class BlockCyclicEngine:
                 if ncb > 0:
                     be.gemv_t(_sub(A, lbk_r * NB, 0), ldl, NB, ncb * NB, rk, acc)
         be.sync()
-        out = {"logpdf": logpdf, "info": info_v, "alpha": alpha[:n].cpu().numpy(), "grid": (P, Q), "nb": NB}
+        out = {"logpdf": logpdf, "info": info_v, "alpha": alpha[:n].cpu().numpy(), "grid": (P, Q), "nb": NB,
+               "gemm_flops": self.gemm_flops}
         return out

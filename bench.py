@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--nb", type=int, default=0, help="outer panel width override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity properties")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-process block-cyclic driver even with one rank (exercises the RCCL calls)")
     args = ap.parse_args()
 
     import torch
@@ -86,10 +88,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -104,12 +110,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     extra = {}
-    if world == 1:
+    if not use_dist:
         ctx = agp.Context(local_rank)
         if args.nb:
             ctx.set_param("nb", args.nb)
@@ -148,7 +154,7 @@ def main():
         agp._lib.check(ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, agp._lib.C.byref(mfma_ceiling)))
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "gemm_nt_sub_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update)",
+                    "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands)",
                     "launches_per_step": gemm_launches / max(args.steps, 1),
                     "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                     "flops_per_launch_avg": gemm_flops / max(gemm_launches, 1),
@@ -169,20 +175,32 @@ def main():
         eng = gdist.BlockCyclicEngine(local_rank, nb=args.nb or 1024)
         for _ in range(args.warmup):
             eng.fit(kernel, x, sigma2, y)
+        eng.be.time_kernels(True)
+        eng.be.gemm_time()
         barrier()
         t0 = time.perf_counter()
+        gflops = 0.0
         for _ in range(args.steps):
             res = eng.fit(kernel, x, sigma2, y)
+            gflops += res["gemm_flops"]
         barrier()
         dt = time.perf_counter() - t0
+        gms, glaunch = eng.be.gemm_time()
+        eng.be.time_kernels(False)
         tdev = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tdev, op=dist.ReduceOp.MAX)
         dt = float(tdev.item())
         logpdf_val = res["logpdf"]
-        ach = res.get("gemm_tflops", 0.0)
+        ach = gflops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
         roofline = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "gemm_nt_sub_kernel<double> (per-rank local trailing update)"}
+                    "kernel": "gemm_nt_dma_kernel<double> (rank 0's local trailing updates under the block-cyclic predicate)",
+                    "launches_per_step": glaunch / max(args.steps, 1), "avg_launch_ms": gms / max(glaunch, 1)}
+        if not args.no_check:  # (K + σ²I) α = δ on a sample of rows, recomputed on the host from the inputs
+            idx = np.linspace(0, n - 1, 64).astype(int)
+            Krows = o.kernelmatrix(o.Kernel(o.SE), x[idx], x)
+            resid = Krows @ res["alpha"] + sigma2 * res["alpha"][idx] - y[idx]
+            extra["check_residual_max"] = float(np.max(np.abs(resid)))
         parallelism = f"2D block-cyclic {eng.P}x{eng.Q}, nb={eng.nb}"
         scaling = "strong"
 
@@ -204,10 +222,10 @@ def main():
     }
     line.update(extra)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not use_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, d)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

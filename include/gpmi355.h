@@ -190,6 +190,10 @@ int32_t gpd_gemv_t(gp_ctx* ctx, const double* l, int64_t ldl, int64_t nrows, int
 /* out_dev[i] = Σ_{c<ncols} x[i*ldx + c]² for i < nrows. */
 int32_t gpd_rowsumsq(gp_ctx* ctx, const double* x, int64_t ldx, int64_t nrows, int64_t ncols, double* out_dev);
 int32_t gpd_sync(gp_ctx* ctx);
+/* With parameter "time_kernels" = 1 every gpd_gemm_nt / gpd_gemm_tn launch is bracketed by HIP events on the ctx
+ * stream.  This synchronises the stream, returns the summed launch durations (ms) and the launch count since the
+ * previous call, and clears the records (the caller knows the algorithmic flops of its own launches). */
+int32_t gpd_gemm_time(gp_ctx* ctx, double* ms_out, int64_t* launches_out);
 
 /* ---- probes used by tools/gpu_diag.py and bench.py ------------------------------------------ */
 /* D(16×16) = A(16×4)·B(4×16), all row-major host arrays: checks the f64 MFMA lane maps. */

@@ -28,6 +28,12 @@ class NumpyTileBackend:
     def sync(self):
         pass
 
+    def time_kernels(self, on):
+        pass
+
+    def gemm_time(self):
+        return 0.0, 0
+
     def assemble(self, kernel_desc, x_dev, n_valid, n_pad, d, noise_dev, grid, a_loc, lda, m_loc, n_loc):
         kind, variance, _ = kernel_desc
         P, p, Q, q, tb, lower = grid
