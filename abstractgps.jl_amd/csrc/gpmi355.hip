@@ -292,7 +292,9 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
         const unsigned nblk = (unsigned)std::max(1L, (mrows + 127) / 128);
         if (!c->ticket_dev) {
             HIPCHK(hipMalloc((void**)&c->ticket_dev, sizeof(int) * 64));
+            // null-stream memsets are not ordered against the (non-blocking) ctx streams: zero it and wait
             HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
+            HIPCHK(hipDeviceSynchronize());
         }
         hipLaunchKernelGGL(panel64_kernel<T>, dim3(nblk), dim3(256), 0, s, A + j0 * lda + j0, lda, (int)mrows, info_dev,
                            (int)(gcol0 + j0), (int)n_valid, logdet_dev, c->ticket_dev + (s == c->sp ? 32 : 0));
@@ -342,7 +344,7 @@ template <typename T> static int32_t trtri_tiles(gp_ctx* c, hipStream_t s, const
         if (c->w_ws) (void)hipFree(c->w_ws);
         c->w_ws_bytes = 0;
         HIPCHK(hipMalloc(&c->w_ws, need));
-        HIPCHK(hipMemset(c->w_ws, 0, need));
+        HIPCHK(hipMemsetAsync(c->w_ws, 0, need, s));  // same stream as the trtri launch that follows
         c->w_ws_bytes = need;
     }
     hipLaunchKernelGGL(trtri_64_kernel<T>, dim3((unsigned)(n / 64)), dim3(64), 0, s, L, ldl, (T*)c->w_ws);
@@ -485,15 +487,17 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
 template <typename T>
 static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* R, long ldr, int nrhs, bool fwd) {
     const int NBV = 1024;
-    const size_t smem = sizeof(T) * (NBV + 64 * 65);
+    const size_t smem = sizeof(T) * (NBV + 64 * 65 + 16 * 64);
     const long nblk = (np + NBV - 1) / NBV;
+    T* W = nullptr;
+    RC(trtri_tiles<T>(c, s, L, ldl, np, &W));  // I − inv(L_jj) for every 64×64 diagonal tile, one batched launch
     for (long bb = 0; bb < nblk; ++bb) {
         const long b = fwd ? bb : (nblk - 1 - bb);
         const long b0 = b * NBV;
         const int nbv = (int)std::min<long>(NBV, np - b0);  // multiple of 64 (np is a multiple of 128)
         if (fwd) {
             hipLaunchKernelGGL((trsv_diag_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr,
-                               nrhs);
+                               nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
             const long lo = b0 + nbv;
             if (lo < np) {
@@ -503,7 +507,7 @@ static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* 
             }
         } else {
             hipLaunchKernelGGL((trsv_diag_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr,
-                               nrhs);
+                               nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
             if (b0 > 0) {
                 hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((b0 + 255) / 256), (unsigned)(nbv / 64)),

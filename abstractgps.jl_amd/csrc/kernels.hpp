@@ -962,13 +962,19 @@ __global__ __launch_bounds__(64) void trtri_64_kernel(const T* __restrict__ L, l
 //   trsv_upd_fwd : r[i] -= Σ_j L[i][b0+j] z[b0+j]   rows i >= b0+nbv          (one wave per row)
 //   trsv_upd_bwd : r[j] -= Σ_i L[b0+i][j] a[b0+i]   columns j < b0            (atomics over row chunks)
 // ------------------------------------------------------------------------------------------------
+// The 64-wide steps use the precomputed tiles W_j = I − inv(L_jj) (trtri_64, one batched launch per solve): the step is
+// a 64×64 GEMV  x = r − W r  (forward) / x = r − Wᵀ r  (backward) spread over the 16 waves — no 64-step substitution
+// chain on the critical path.
 template <typename T, bool FWD>
 __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
-                                                          T* __restrict__ R, long ldr, int nrhs) {
+                                                          T* __restrict__ R, long ldr, int nrhs,
+                                                          const T* __restrict__ W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* rv = reinterpret_cast<T*>(smem_raw);  // [nbv] current rhs / solution
-    T* Ls = rv + nbv;                        // [64][65] diagonal sub-tile
+    T* Ws = rv + nbv;                        // [64][65] W tile of the current step
+    T* red = Ws + 64 * 65;                   // [16][64] partial sums
     const int tid = threadIdx.x;
+    const int t = tid & 63, part = tid >> 6;
     const int ns = nbv / 64;
     for (int s = 0; s < nrhs; ++s) {
         T* r = R + (long)s * ldr + b0;
@@ -977,28 +983,24 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
         for (int ss = 0; ss < ns; ++ss) {
             const int sb = FWD ? ss : (ns - 1 - ss);
             const int s0 = sb * 64;
-            // stage the 64×64 diagonal sub-tile
-            for (int e = tid; e < 64 * 64; e += 1024) {
-                const int t = e >> 6, c = e & 63;
-                Ls[t * 65 + c] = L[(b0 + s0 + t) * ldl + b0 + s0 + c];
+            const T* Wt = W + ((b0 >> 6) + sb) * 4096;
+            for (int e = tid; e < 64 * 64; e += 1024) Ws[(e >> 6) * 65 + (e & 63)] = Wt[e];
+            __syncthreads();
+            {
+                T acc = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * part + i;
+                    acc = fma(FWD ? Ws[t * 65 + c] : Ws[c * 65 + t], rv[s0 + c], acc);
+                }
+                red[part * 64 + t] = acc;
             }
             __syncthreads();
-            if (tid < 64) {  // one wave: substitution, lane t owns rv[s0+t]
-                T v = rv[s0 + tid];
-                if (FWD) {
-                    for (int c = 0; c < 64; ++c) {
-                        const T zc = __shfl(v, c, 64) / Ls[c * 65 + c];
-                        if (tid == c) v = zc;
-                        if (tid > c) v = fma(-Ls[tid * 65 + c], zc, v);
-                    }
-                } else {
-                    for (int c = 63; c >= 0; --c) {
-                        const T zc = __shfl(v, c, 64) / Ls[c * 65 + c];
-                        if (tid == c) v = zc;
-                        if (tid < c) v = fma(-Ls[c * 65 + tid], zc, v);
-                    }
-                }
-                rv[s0 + tid] = v;
+            if (tid < 64) {
+                T acc = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc += red[q * 64 + tid];
+                rv[s0 + tid] -= acc;
             }
             __syncthreads();
             // update the not-yet-solved part of this diagonal block
@@ -1012,6 +1014,7 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
             } else {
                 for (int j = tid; j < s0; j += 1024) {
                     T acc = 0;
+#pragma unroll 8
                     for (int c = 0; c < 64; ++c) acc = fma(L[(b0 + s0 + c) * ldl + b0 + j], rv[s0 + c], acc);
                     rv[j] -= acc;
                 }
