@@ -29,7 +29,7 @@ class gp_noise(C.Structure):
 class gp_timings(C.Structure):
     _fields_ = [("assemble_ms", C.c_double), ("potrf_ms", C.c_double), ("solve_ms", C.c_double),
                 ("total_ms", C.c_double), ("gemm_ms", C.c_double), ("gemm_flops", C.c_double),
-                ("gemm_launches", C.c_int64), ("reserved", C.c_int64)]
+                ("gemm_launches", C.c_int64), ("gemm_bytes", C.c_double)]
 
 
 class gp_grid(C.Structure):

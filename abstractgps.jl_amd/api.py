@@ -215,7 +215,7 @@ class Context:
     def timings(self) -> dict:
         t = gp_timings()
         check(self.lib.gp_get_timings(self.handle, C.byref(t)))
-        return {f: getattr(t, f) for f, _ in gp_timings._fields_ if f != "reserved"}
+        return {f: getattr(t, f) for f, _ in gp_timings._fields_}
 
     def close(self):
         self._fin()

@@ -81,7 +81,7 @@ struct gp_ctx {
     size_t ev_used = 0;
     struct GemmRec {
         hipEvent_t a, b;
-        double flops;
+        double flops, bytes;
     };
     std::vector<GemmRec> gemm_recs;
     hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -207,8 +207,9 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
     if (timed) {
         RC(ctx_event(c, &rec.a, true));
         RC(ctx_event(c, &rec.b, true));
-        rec.flops = 2.0 * (double)K * ((g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0)
-                                                                          : (double)M * (double)N);
+        const double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
+        rec.flops = g.ktri ? (double)N * (double)M * (double)(M + 128) : 2.0 * (double)K * elems;
+        rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
         HIPCHK(hipEventRecord(rec.a, s));
     }
     if (c->gemm_variant == 0) {
@@ -240,7 +241,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
-        else if (c->gemm_dma && std::is_same<T, CT>::value)
+        else if ((c->gemm_dma || g.beta0 || g.ktri) && std::is_same<T, CT>::value)
             hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g);
         else
@@ -274,6 +275,8 @@ static GridMap plain_map(int lower, long row0, long col0) {
     g.tn = 0;
     g.dt = 0;
     g.tm = 0;
+    g.beta0 = 0;
+    g.ktri = 0;
     return g;
 }
 
@@ -687,11 +690,13 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
         c->tm.total_ms = ms;
         c->tm.gemm_ms = 0;
         c->tm.gemm_flops = 0;
+        c->tm.gemm_bytes = 0;
         c->tm.gemm_launches = (int64_t)c->gemm_recs.size();
         for (auto& r : c->gemm_recs) {
             HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
             c->tm.gemm_ms += ms;
             c->tm.gemm_flops += r.flops;
+            c->tm.gemm_bytes += r.bytes;
         }
         return 0;
     }();

@@ -67,6 +67,8 @@ struct GridMap {
                      // 2 / 3: XCD-aware super-tile order (rectangular / lower trapezoid), see xcd_tile()
     int tn, dt;      // compact: number of tile columns, diagonal offset in tiles (row tile i has min(tn, i+dt+1) tiles)
     int tm;          // number of tile rows (modes 2, 3)
+    int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
+    int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
 };
 // compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
 __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
@@ -406,17 +408,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
     const CT* const Cr = active ? Cw : C + li;
     dma(0, 0);
+    if (g.beta0) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = T(0);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
+    }
 
     // fragment slots: row wr·64 + t·16 + li, chunk 4h+lg -> slot (row·8) + ((4h+lg) ^ swz(li))
     const int sw = (li >> 1) & 7;
     const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
-    const int nk = K / BK;
+    int nk = K / BK;
+    if (g.ktri) nk = min(nk, (m0 + 128) / BK);
     dma_wait_barrier();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -1098,6 +1110,21 @@ __global__ __launch_bounds__(256) void sumsq_accum_kernel(const T* __restrict__ 
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// acc[row] -= Σ_{c<ncols} X[row][c] · b[c]   (fp64 accumulation; one block per row)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_sub_kernel(const T* __restrict__ X, long ldx, long ncols, const T* __restrict__ b,
+                                                          double* __restrict__ acc_out) {
+    __shared__ double red[4];
+    const T* x = X + (long)blockIdx.x * ldx;
+    double acc = 0;
+    for (long c = threadIdx.x; c < ncols; c += 256) acc = fma((double)x[c], (double)b[c], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) acc_out[blockIdx.x] -= red[0] + red[1] + red[2] + red[3];
+}
+
 // out[s] = Σ_i variance κ(‖xs_s − x_i‖) α_i   (K_*x α fused with the kernel evaluation; one block per s)
 template <typename T>
 __global__ __launch_bounds__(256) void kvec_kernel(const T* __restrict__ xs, long ldxs, const T* __restrict__ x,
@@ -1156,6 +1183,11 @@ __global__ __launch_bounds__(256) void diag_shift_trace_kernel(double* __restric
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0 && out) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+// A = I (n×n, leading dimension lda)
+__global__ __launch_bounds__(256) void identity_kernel(double* __restrict__ A, long lda, long n) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j < n) A[i * lda + j] = (i == j) ? 1.0 : 0.0;
 }
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, double scale) {

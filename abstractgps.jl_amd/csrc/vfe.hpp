@@ -6,11 +6,13 @@
 //
 // Formulation (S = Σy^-1/2 diagonal, L_z L_zᵀ = K_zz + jitter·I, so U = L_zᵀ), the reference's own:
 //   B = U⁻ᵀ (S K_xz)ᵀ,  D = B Bᵀ + I = Λ_ε,  c = B b_y,  m_ε = Λ_ε \ c,  α = U \ m_ε.
-//   The N-long pass is streamed in chunks of CH data points and never holds an N×M matrix:
-//     Xc  = S_c K(x_c, z)          kmat with a row scale                (CH × M, dtype T)
-//     Xc ← Xc L_z⁻ᵀ = B_cᵀ          trsm_rec (MFMA gemm inside)
-//     D_acc −= Xcᵀ Xc               MFMA gemm, k-major operands (SYRK over the data points)
-//     c_acc −= Xcᵀ b_c              gemv_t
+//   The N-long pass is streamed in chunks of CH data points and never holds an N×M matrix.  L_z is the same for
+//   every chunk, so its inverse is formed once (fp64: I·L_z⁻ᵀ by the blocked TRSM, transposed, rounded to T) and the
+//   per-chunk triangular solve becomes ONE MFMA GEMM with a triangular k range (no 64-wide leaf chain per chunk):
+//     Xc  = S_c K(x_c, z)                   kmat with a row scale          (CH × M, dtype T)
+//     Y   = −inv(L_z) Xcᵀ = −B_c            gemm_nt_dma, beta0 + ktri      (M × CH, data points contiguous)
+//     D_acc −= Y Yᵀ                         MFMA gemm (NT), fp64 accumulation (SYRK over the data points)
+//     c_acc −= Y b_c                        rowdot_sub
 //   (T = f32 or f64).  The M×M side (K_zz, both Choleskys, all vector solves) is always fp64, and so are the
 //   accumulators of the N-long reductions (D_acc, c_acc, ‖B‖²_F): in fp32 mode the operands stream in fp32 through
 //   the fp32 MFMA, whose chain is flushed into fp64 every 256 data points; L_z is rounded to fp32 for the streamed
@@ -75,10 +77,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
 
     const size_t xs_b = sizeof(T) * xs_h.size(), zsT_b = sizeof(T) * zsT_h.size(), zsD_b = sizeof(double) * zsD_h.size();
     const size_t rs_b = sizeof(T) * (size_t)npad, D_b = sizeof(double) * (size_t)(mp + 128) * ld;
+    const long ldy = CH + c->ldpad;             // Y = −B_c (M × CH)
     const size_t X_b = sizeof(T) * (size_t)(CH + 128) * ld, L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
-    const size_t vT_b = sizeof(double) * (size_t)mp, LT_b = sizeof(T) * (size_t)(mp + 128) * ld, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
+    const size_t Y_b = sizeof(T) * (size_t)(mp + 128) * ldy, Li_b = sizeof(T) * (size_t)(mp + 128) * ld;
+    const size_t vT_b = sizeof(double) * (size_t)mp, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
     void *xs_v = 0, *zsT_v = 0, *zsD_v = 0, *rs_v = 0, *b_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *LzT_v = 0, *cT_v = 0,
-         *vec_v = 0, *jit_v = 0;
+         *vec_v = 0, *jit_v = 0, *Y_v = 0, *Li_v = 0, *I_v = 0;
     constexpr bool is_f64 = sizeof(T) == 8;
     RC(ctx_alloc(c, xs_b, &xs_v));
     RC(ctx_alloc(c, zsT_b, &zsT_v));
@@ -89,14 +93,15 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(ctx_alloc(c, X_b, &X_v));
     RC(ctx_alloc(c, L_b, &Lz_v));
     RC(ctx_alloc(c, L_b, &Ld_v));
-    if (!is_f64) RC(ctx_alloc(c, LT_b, &LzT_v));
+    RC(ctx_alloc(c, Y_b, &Y_v));
+    RC(ctx_alloc(c, Li_b, &Li_v));
+    RC(ctx_alloc(c, L_b, &I_v));
     RC(ctx_alloc(c, vT_b, &cT_v));
     RC(ctx_alloc(c, vD_b, &vec_v));
     RC(ctx_alloc(c, jit_b, &jit_v));
     double* Lz = (double*)Lz_v;
     double* Ld = (double*)Ld_v;
     double* vec = (double*)vec_v;  // rows: [0] c , [1] w→m_ε , [2] α , [3] spare
-    const T* LzT = is_f64 ? (const T*)Lz_v : (const T*)LzT_v;
     double scal_h[16] = {0};
     int info_h = 0;
     hipStream_t s = c->sm;
@@ -124,10 +129,18 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             HIPCHK(hipGetLastError());
         }
         RC(potrf_full<double>(c, Lz, ld, mp, mp, c->info_dev, m, c->scal_dev + 0));
-        if (!is_f64) {
-            const long cnt = (mp + 128) * ld;
-            hipLaunchKernelGGL((convert_kernel<double, T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, Lz, (T*)LzT_v,
-                               cnt, 1.0);
+        // ---- inv(L_z): W = I · L_z⁻ᵀ (upper), transposed into Ld's storage (free until the SYRK is done), rounded to T
+        {
+            double* Iw = (double*)I_v;
+            HIPCHK(hipMemsetAsync(I_v, 0, L_b, s));
+            hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
+            HIPCHK(hipGetLastError());
+            RC(trsm_rec<double>(c, s, Iw, ld, mp, Lz, ld, mp));
+            hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, s, Iw, ld, Ld, ld, mp);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(Li_v, 0, Li_b, s));
+            hipLaunchKernelGGL((convert_kernel<double, T>), dim3((unsigned)(((long)mp * ld + 255) / 256)), dim3(256), 0, s, Ld,
+                               (T*)Li_v, (long)mp * ld, 1.0);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev_phase[1], s));
@@ -138,17 +151,22 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, (T*)X_v, ld, (const T*)xs_v, npad, (const T*)zsT_v, mp, d,
                                k->kind, (T)k->variance, (const T*)nullptr, n, m, 0, g, (const T*)nullptr, (const T*)rs_v);
             HIPCHK(hipGetLastError());
-            RC(trsm_rec<T>(c, s, (T*)X_v, ld, CH, LzT, ld, mp));                                   // B_cᵀ
-            hipLaunchKernelGGL(sumsq_accum_kernel<T>, dim3((unsigned)CH), dim3(256), 0, s, (const T*)X_v, ld, mp,
+            {
+                GridMap gy = plain_map(0, 0, 0);
+                gy.beta0 = 1;
+                gy.ktri = 1;
+                RC(launch_gemm<T>(c, s, (T*)Y_v, ldy, (const T*)Li_v, ld, (const T*)X_v, ld, mp, CH, mp, gy));   // Y = −B_c
+            }
+            hipLaunchKernelGGL(sumsq_accum_kernel<T>, dim3((unsigned)mp), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
                                c->scal_dev + 4);                                                   // ‖A‖²_F in fp64
             HIPCHK(hipGetLastError());
-            RC((launch_gemm<T, double>(c, s, (double*)D_v, ld, (const T*)X_v, ld, (const T*)X_v, ld, mp, mp, CH, plain_map(1, 0, 0), true)));
-            hipLaunchKernelGGL((gemv_t_kernel<T, double>), dim3((unsigned)((mp + 255) / 256), (unsigned)(CH / 64)), dim3(256), 0, s,
-                               (const T*)X_v, ld, CH, mp, (const T*)b_v + c0, (double*)cT_v);
+            RC((launch_gemm<T, double>(c, s, (double*)D_v, ld, (const T*)Y_v, ldy, (const T*)Y_v, ldy, mp, mp, CH, plain_map(1, 0, 0))));
+            hipLaunchKernelGGL(rowdot_sub_kernel<T>, dim3((unsigned)mp), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
+                               (const T*)b_v + c0, (double*)cT_v);                                 // cT −= Y b_c = +B_c b_c
             HIPCHK(hipGetLastError());
         }
         hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s,
-                           (const double*)cT_v, vec, mp, -1.0);                                                              // c = B b_y
+                           (const double*)cT_v, vec, mp, 1.0);                                                              // c = B b_y
         HIPCHK(hipGetLastError());
         // ---- D = I + B Bᵀ (fp64, symmetric), Λ_ε = chol(D)                                       :68-69
         hipLaunchKernelGGL(neg_sym_to_f64_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s,
@@ -198,7 +216,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     ctx_release(c, b_v, rs_b);
     ctx_release(c, D_v, D_b);
     ctx_release(c, X_v, X_b);
-    ctx_release(c, LzT_v, LT_b);
+    ctx_release(c, Y_v, Y_b);
+    ctx_release(c, Li_v, Li_b);
+    ctx_release(c, I_v, L_b);
     ctx_release(c, cT_v, vT_b);
     ctx_release(c, jit_v, jit_b);
     if (rc == 0 && info_h != 0) rc = info_h;

@@ -66,6 +66,21 @@ def cpu_baseline(n_full: int, d: int):
     }
 
 
+def pmc_traffic(n: int) -> dict:
+    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over THIS command
+    (tools/gpu_pmc_bench.sh -> profiles/r1/pmc_bench_summary.json; FETCH_SIZE and WRITE_SIZE are reported in KiB and
+    FETCH_SIZE is doubled, the gfx950 correction for 16-B/lane streaming reads of MI355X_MICROARCH.md §HBM).
+    PMC cannot be sampled from inside the timed run, so this is null when the summary is absent or for another N."""
+    path = ROOT / "profiles" / "r1" / "pmc_bench_summary.json"
+    if n != 65536 or not path.exists():
+        return {"traffic": None}
+    s = json.loads(path.read_text())
+    rd = 2.0 * s["FETCH_SIZE"]["avg"] * 1024.0
+    wr = s["WRITE_SIZE"]["avg"] * 1024.0
+    return {"traffic": rd + wr, "traffic_detail": {"unit": "bytes per launch (average over the bench's MFMA GEMM launches)",
+                                                   "read": rd, "write": wr, "source": "profiles/r1/pmc_bench_summary.json"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +144,7 @@ def main():
         for _ in range(args.warmup):
             step().data.C.free()
         ctx.set_param("time_kernels", 1)
-        gemm_ms = gemm_flops = 0.0
+        gemm_ms = gemm_flops = gemm_bytes = 0.0
         gemm_launches = 0
         phases = {"assemble_ms": 0.0, "potrf_ms": 0.0, "solve_ms": 0.0}
         barrier()
@@ -142,6 +157,7 @@ def main():
             tm = ctx.timings()
             gemm_ms += tm["gemm_ms"]
             gemm_flops += tm["gemm_flops"]
+            gemm_bytes += tm.get("gemm_bytes", 0.0)
             gemm_launches += tm["gemm_launches"]
             for kname in phases:
                 phases[kname] += tm[kname] / args.steps
@@ -153,7 +169,8 @@ def main():
         mfma_ceiling = agp._lib.C.c_double()
         agp._lib.check(ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, agp._lib.C.byref(mfma_ceiling)))
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, **pmc_traffic(n),
+                    "algorithmic_bytes_per_launch_avg": gemm_bytes / max(gemm_launches, 1),
                     "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands)",
                     "launches_per_step": gemm_launches / max(args.steps, 1),
                     "avg_launch_ms": gemm_ms / max(gemm_launches, 1),

@@ -83,7 +83,7 @@ typedef struct {
     double gemm_ms;        /* Σ per-launch durations of gemm_nt_sub launches (time_kernels=1)  */
     double gemm_flops;     /* Σ algorithmic flops of those launches                               */
     int64_t gemm_launches;
-    int64_t reserved;
+    double gemm_bytes;     /* Σ algorithmic bytes of those launches: C read + C write + both operand panels once */
 } gp_timings;
 
 /* ---- context ------------------------------------------------------------------------------ */
