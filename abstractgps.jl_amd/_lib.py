@@ -53,6 +53,8 @@ PROTOTYPES = {
     "gp_posterior_fit": (i32, [vp, PK, PP, PN, vp, vp, C.POINTER(vp), vp, vp]),
     "gp_posterior_predict": (i32, [vp, PP, vp, i32, vp, vp, vp]),
     "gp_posterior_get_factor": (i32, [vp, vp]),
+    "gp_posterior_update": (i32, [vp, PP, PN, vp, C.POINTER(vp), vp, vp]),
+    "gp_posterior_factor_mul": (i32, [vp, vp, i32, vp]),
     "gp_posterior_n": (i64, [vp]),
     "gp_posterior_free": (i32, [vp]),
     "gp_vfe_fit": (i32, [vp, PK, PP, PP, PN, dbl, vp, vp, i32, C.POINTER(vp), vp]),

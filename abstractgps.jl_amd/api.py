@@ -462,8 +462,10 @@ def _posterior_exact(fx: FiniteGP, y) -> PosteriorGP:
     if y.ndim != 1:
         raise TypeError("posterior expects a vector of observations")
     f = fx.f
+    if isinstance(f, PosteriorGP):
+        return _posterior_sequential(fx, y)
     if not isinstance(f, GP):
-        raise NotImplementedError("sequential conditioning (posterior of a PosteriorGP) is not accelerated yet")
+        raise TypeError("posterior: unsupported GP type")
     ctx = f.context()
     dt = np.result_type(_input_dtype(fx.x), np.float32 if y.dtype == np.float32 else np.float64).type
     m = _Marshal(dt)
@@ -480,6 +482,54 @@ def _posterior_exact(fx: FiniteGP, y) -> PosteriorGP:
     check(ctx.lib.gp_posterior_fit(ctx.handle, C.byref(kk), C.byref(px), C.byref(nz), m.ptr(mean), yv.ctypes.data,
                                    C.byref(h), alpha.ctypes.data, lp.ctypes.data))
     return PosteriorGP(f, _PostData(alpha, _Factor(ctx, h, px.n, dt), fx.x, delta), lp[0])
+
+
+def _posterior_sequential(fx: FiniteGP, y) -> PosteriorGP:
+    """posterior(fx::FiniteGP{<:PosteriorGP}, y) — src/exact_gpr_posterior.jl:46-56: the device-resident factor is
+    extended by update_chol (src/util/common_covmat_ops.jl:38-42) instead of being recomputed."""
+    post = fx.f
+    prior = post.prior
+    fac = post.data.C
+    dt = fac.dtype
+    m = _Marshal(dt)
+    px = m.points(fx.x)
+    nz = m.noise(fx.sigma2, px.n)
+    m2 = _mean_vector(prior.mean_fn, fx.x, dt)
+    d2 = m.arr(y) - m2 if m2 is not None else m.arr(y).copy()          # δ2 = y - m2           (:48-49)
+    delta = m.arr(np.concatenate([post.data.delta, d2]))                # δ = vcat(δ_old, δ2)  (:52)
+    n = delta.shape[0]
+    alpha = np.empty(n, dtype=dt)
+    lp = np.empty(1, dtype=dt)
+    h = C.c_void_p()
+    check(fac.ctx.lib.gp_posterior_update(fac.handle, C.byref(px), C.byref(nz), delta.ctypes.data, C.byref(h),
+                                          alpha.ctypes.data, lp.ctypes.data))
+    x_all, _ = _stack_inputs(post.data.x, fx.x)                         # x = vcat(x_old, x2)  (:54)
+    return PosteriorGP(prior, _PostData(alpha, _Factor(fac.ctx, h, n, dt), x_all, delta), lp[0])
+
+
+def rand(fx: FiniteGP, N: Optional[int] = None, rng=None, xi=None):
+    """rand([rng,] fx[, N]) — src/finite_gp_projection.jl:233-240: m .+ C.U' * randn(rng, n, N).  The factor and the
+    triangular product run on the device; the standard normals are drawn on the host (`rng`: numpy Generator) or passed
+    in as `xi` (n × N) for reproducible parity checks."""
+    f = fx.f
+    n = len(fx)
+    if isinstance(f, GP):
+        post0 = _posterior_exact(fx, np.zeros(n, dtype=_input_dtype(fx.x)))   # factor of cov(fx) = K + Σy
+        fac, dt = post0.data.C, post0.data.C.dtype
+        mvec = f.mean(fx.x)
+    elif isinstance(f, PosteriorGP):
+        raise NotImplementedError("rand of a posterior FiniteGP: use mean_and_cov + host Cholesky (small N*)")
+    else:
+        raise TypeError("rand: unsupported GP type")
+    ncols = 1 if N is None else int(N)
+    if xi is None:
+        rng = rng or np.random.default_rng()
+        xi = rng.standard_normal((n, ncols))
+    xi = np.asfortranarray(np.asarray(xi, dtype=dt).reshape(n, ncols))
+    out = np.empty((n, ncols), dtype=dt, order="F")
+    check(fac.ctx.lib.gp_posterior_factor_mul(fac.handle, xi.ctypes.data, ncols, out.ctypes.data))
+    out += np.asarray(mvec, dtype=dt)[:, None]
+    return out[:, 0] if N is None else out
 
 
 def _logpdf_posterior(fx: FiniteGP, y):

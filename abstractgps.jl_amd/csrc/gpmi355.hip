@@ -580,6 +580,7 @@ struct gp_post {
     size_t xs_bytes;  // scaled train inputs [d][np]
     void* alpha;
     size_t alpha_bytes;  // [np]
+    double logdet_half;  // Σ log L_ii
 };
 
 template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k, const T* xs_dev, long ldx, int d,
@@ -636,6 +637,7 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
     RC(ctx_alloc(c, nz_bytes, &noise_v));
     RC(ctx_alloc(c, nz_bytes, &alpha_v));
     T* A = (T*)A_v;
+    double logdet_half_out = 0;
     auto cleanup = [&](bool keep) {
         ctx_release(c, noise_v, nz_bytes);
         if (!keep) {
@@ -676,6 +678,7 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
         HIPCHK(hipStreamSynchronize(c->sm));
         out.info = info_h;
         out.logpdf.resize(ncols);
+        logdet_half_out = scal_h[0];
         const double logdet = 2.0 * scal_h[0];
         for (int s = 0; s < ncols; ++s) out.logpdf[s] = -0.5 * ((double)n * LOG2PI + logdet + scal_h[8 + s]);
         // timings
@@ -719,6 +722,7 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
     post->A = A_v; post->A_bytes = A_bytes;
     post->xs = xs_v; post->xs_bytes = xs_bytes;
     post->alpha = alpha_v; post->alpha_bytes = nz_bytes;
+    post->logdet_half = logdet_half_out;
     return 0;
 }
 
@@ -814,6 +818,151 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
     ctx_release(c, m_v, m_bytes);
     ctx_release(c, X_v, X_bytes);
     ctx_release(c, C_v, C_bytes);
+    return rc;
+}
+
+// Sequential conditioning: bordered Cholesky on the device (reference src/exact_gpr_posterior.jl:46-56,
+// src/util/common_covmat_ops.jl:38-42).
+template <typename T>
+static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post* post,
+                           void* alpha_out, double* logpdf_out) {
+    gp_ctx* c = old->ctx;
+    const long n1 = old->n, np1 = old->np, ld1 = old->ld;
+    const long n2 = x2->n, n2p = round_up(n2, 128);
+    const long n = n1 + n2, np = round_up(n, 128), ld = np + c->ldpad, mtot = np + 128;
+    const int d = old->d;
+    gp_kernel k{};
+    k.kind = old->kind; k.dtype = old->dtype; k.variance = old->variance; k.nscale = old->nscale;
+    k.scale = old->scale.empty() ? nullptr : old->scale.data();
+    hipStream_t s = c->sm;
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    if (!c->info_dev) HIPCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    RC(ctx_scal(c, 16));
+
+    std::vector<T> x2s_h;
+    scale_points<T>(&k, x2, n2p, x2s_h);  // [d][n2p]
+    std::vector<T> noise_h((size_t)n2p, T(0));
+    for (long i = 0; i < n2; ++i) noise_h[i] = noise2->kind == 0 ? (T)noise2->s : ((const T*)noise2->diag)[i];
+    std::vector<T> delta_h((size_t)np, T(0));
+    memcpy(delta_h.data(), delta_all, sizeof(T) * (size_t)n);
+
+    void *A_v = 0, *xs_v = 0, *alpha_v = 0, *X_v = 0, *S_v = 0, *x2_v = 0, *nz_v = 0;
+    const long ldx = np1 + c->ldpad, lds = n2p + c->ldpad;
+    const size_t A_b = sizeof(T) * (size_t)(mtot + 128) * ld, xs_b = sizeof(T) * (size_t)d * np, v_b = sizeof(T) * (size_t)np;
+    const size_t X_b = sizeof(T) * (size_t)(n2p + 128) * ldx, S_b = sizeof(T) * (size_t)(n2p + 128) * lds;
+    const size_t x2_b = sizeof(T) * (size_t)d * n2p, nz_b = sizeof(T) * (size_t)n2p;
+    RC(ctx_alloc(c, A_b, &A_v));
+    RC(ctx_alloc(c, xs_b, &xs_v));
+    RC(ctx_alloc(c, v_b, &alpha_v));
+    RC(ctx_alloc(c, X_b, &X_v));
+    RC(ctx_alloc(c, S_b, &S_v));
+    RC(ctx_alloc(c, x2_b, &x2_v));
+    RC(ctx_alloc(c, nz_b, &nz_v));
+    T* A = (T*)A_v;
+    T* X = (T*)X_v;
+    T* S = (T*)S_v;
+    const T* A1 = (const T*)old->A;
+    int info_h = 0;
+    double scal_h[16] = {0};
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipMemcpyAsync(x2_v, x2s_h.data(), x2_b, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(nz_v, noise_h.data(), nz_b, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), s));
+        HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * 16, s));
+        // combined scaled inputs [d][np]: old block, then the new points
+        HIPCHK(hipMemsetAsync(xs_v, 0, xs_b, s));
+        HIPCHK(hipMemcpy2DAsync(xs_v, sizeof(T) * np, old->xs, sizeof(T) * np1, sizeof(T) * n1, d, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpy2DAsync((T*)xs_v + n1, sizeof(T) * np, x2_v, sizeof(T) * n2p, sizeof(T) * n2, d, hipMemcpyDeviceToDevice, s));
+        // X = K(x2, x1) (n2p × np1; padding rows / columns zero), then X ← X L11⁻ᵀ = U12ᵀ                  :39
+        {
+            GridMap g = plain_map(0, 0, 0);
+            dim3 grid((unsigned)(np1 / 128), (unsigned)(n2p / 128));
+            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, X, ldx, (const T*)x2_v, n2p, (const T*)old->xs, np1, d,
+                               k.kind, (T)k.variance, (const T*)nullptr, n2, n1, 0, g, (const T*)nullptr, (const T*)nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        RC(trsm_rec<T>(c, s, X, ldx, n2p, A1, ld1, np1));
+        // S = C22 − U12ᵀ U12 (lower), chol(S) = U22ᵀ                                                       :40
+        {
+            GridMap g = plain_map(1, 0, 0);
+            dim3 grid((unsigned)(n2p / 128), (unsigned)(n2p / 128));
+            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, S, lds, (const T*)x2_v, n2p, (const T*)x2_v, n2p, d,
+                               k.kind, (T)k.variance, (const T*)nz_v, n2, n2, 1, g, (const T*)nullptr, (const T*)nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        RC(launch_gemm<T>(c, s, S, lds, X, ldx, X, ldx, n2p, n2p, np1, plain_map(1, 0, 0)));
+        RC(potrf_full<T>(c, S, lds, n2p, n2p, c->info_dev, n2, c->scal_dev));
+        // new factor [L11 0; U12ᵀ U22ᵀ], identity padding, δ as the right-hand side                          :41
+        HIPCHK(hipMemsetAsync(A + np * ld, 0, sizeof(T) * (size_t)(128 + 128) * ld, s));
+        HIPCHK(hipMemcpy2DAsync(A, sizeof(T) * ld, A1, sizeof(T) * ld1, sizeof(T) * n1, n1, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpy2DAsync(A + n1 * ld, sizeof(T) * ld, X, sizeof(T) * ldx, sizeof(T) * n1, n2, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpy2DAsync(A + n1 * ld + n1, sizeof(T) * ld, S, sizeof(T) * lds, sizeof(T) * n2, n2, hipMemcpyDeviceToDevice, s));
+        if (np > n) {
+            hipLaunchKernelGGL(pad_identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)(np - n)), dim3(256), 0, s, A,
+                               ld, n, np);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(alpha_v, delta_h.data(), v_b, hipMemcpyHostToDevice, s));
+        RC(trsv<T>(c, s, A, ld, np, (T*)alpha_v, np, 1, true));                                     // z = L⁻¹ δ
+        hipLaunchKernelGGL(rowsumsq_kernel<T>, dim3(1), dim3(256), 0, s, (const T*)alpha_v, np, np, c->scal_dev + 8);
+        HIPCHK(hipGetLastError());
+        RC(trsv<T>(c, s, A, ld, np, (T*)alpha_v, np, 1, false));                                    // α = L⁻ᵀ z        :53
+        HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(scal_h, c->scal_dev, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
+        if (alpha_out) HIPCHK(hipMemcpyAsync(alpha_out, alpha_v, sizeof(T) * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        (void)hipStreamSynchronize(c->sp);
+    }
+    ctx_release(c, X_v, X_b);
+    ctx_release(c, S_v, S_b);
+    ctx_release(c, x2_v, x2_b);
+    ctx_release(c, nz_v, nz_b);
+    if (rc == 0 && info_h != 0) rc = (int32_t)n1 + info_h;  // order of the failing leading minor of the bordered matrix
+    if (rc != 0) {
+        ctx_release(c, A_v, A_b);
+        ctx_release(c, xs_v, xs_b);
+        ctx_release(c, alpha_v, v_b);
+        return rc;
+    }
+    post->ctx = c;
+    post->dtype = old->dtype;
+    post->n = n; post->np = np; post->ld = ld; post->mtot = mtot; post->d = d;
+    post->kind = old->kind; post->variance = old->variance; post->nscale = old->nscale;
+    post->scale = old->scale;
+    post->A = A_v; post->A_bytes = A_b;
+    post->xs = xs_v; post->xs_bytes = xs_b;
+    post->alpha = alpha_v; post->alpha_bytes = v_b;
+    post->logdet_half = old->logdet_half + scal_h[0];
+    if (logpdf_out) *logpdf_out = -0.5 * ((double)n * LOG2PI + 2.0 * post->logdet_half + scal_h[8]);
+    return 0;
+}
+
+template <typename T> static int32_t factor_mul_impl(gp_post* post, const void* xi, int ncols, void* out) {
+    gp_ctx* c = post->ctx;
+    const long n = post->n, np = post->np;
+    void *in_v = 0, *out_v = 0;
+    const size_t b = sizeof(T) * (size_t)np * ncols;
+    RC(ctx_alloc(c, b, &in_v));
+    RC(ctx_alloc(c, b, &out_v));
+    hipStream_t s = c->sm;
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipMemsetAsync(in_v, 0, b, s));
+        HIPCHK(hipMemcpy2DAsync(in_v, sizeof(T) * np, xi, sizeof(T) * n, sizeof(T) * n, ncols, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(trmv_lower_kernel<T>, dim3((unsigned)n), dim3(256), 0, s, (const T*)post->A, post->ld, (const T*)in_v, np,
+                           ncols, (T*)out_v);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy2DAsync(out, sizeof(T) * n, out_v, sizeof(T) * np, sizeof(T) * n, ncols, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) (void)hipStreamSynchronize(s);
+    ctx_release(c, in_v, b);
+    ctx_release(c, out_v, b);
     return rc;
 }
 
@@ -1031,6 +1180,48 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
     HIPCHK(hipSetDevice(c->device));
     return post->dtype == 0 ? predict_impl<double>(post, xs, pm, what, mean_out, var_out, cov_out)
                             : predict_impl<float>(post, xs, pm, what, mean_out, var_out, cov_out);
+}
+
+int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post** out,
+                            void* alpha_out, void* logpdf_out) {
+    if (!old || !reg_has(old)) return set_arg_err(1, "not a live gp_post");
+    RC(check_points(x2, 2));
+    if (x2->d != old->d) return set_arg_err(2, "x2 has a different D than the training inputs");
+    if (!noise2 || (noise2->kind != 0 && noise2->kind != 1) || (noise2->kind == 1 && !noise2->diag))
+        return set_arg_err(3, "bad noise");
+    if (!delta_all) return set_arg_err(4, "delta_all is NULL");
+    if (!out) return set_arg_err(5, "out is NULL");
+    *out = nullptr;
+    gp_ctx* c = old->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    gp_post* p = new gp_post();
+    double lp = 0;
+    int32_t rc = old->dtype == 0 ? update_impl<double>(old, x2, noise2, delta_all, p, alpha_out, &lp)
+                                 : update_impl<float>(old, x2, noise2, delta_all, p, alpha_out, &lp);
+    if (rc != 0) {
+        delete p;
+        return rc;
+    }
+    if (logpdf_out) {
+        if (old->dtype == 0) *(double*)logpdf_out = lp;
+        else *(float*)logpdf_out = (float)lp;
+    }
+    c->refs++;
+    reg_add(p);
+    *out = p;
+    return 0;
+}
+
+int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, void* out) {
+    if (!post || !reg_has(post)) return set_arg_err(1, "not a live gp_post");
+    if (!xi) return set_arg_err(2, "xi is NULL");
+    if (ncols < 1) return set_arg_err(3, "ncols must be >= 1");
+    if (!out) return set_arg_err(4, "out is NULL");
+    gp_ctx* c = post->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return post->dtype == 0 ? factor_mul_impl<double>(post, xi, ncols, out) : factor_mul_impl<float>(post, xi, ncols, out);
 }
 
 int64_t gp_posterior_n(gp_post* post) {

@@ -1125,6 +1125,34 @@ __global__ __launch_bounds__(256) void rowdot_sub_kernel(const T* __restrict__ X
     if (threadIdx.x == 0) acc_out[blockIdx.x] -= red[0] + red[1] + red[2] + red[3];
 }
 
+// out[s][i] = Σ_{j<=i} L[i][j] ξ[s][j]   (C.U' * ξ for the row-major lower factor; one block per row i, ξ / out stored
+// as rows of length ldv)                                                       src/finite_gp_projection.jl:233-237
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const T* __restrict__ L, long ldl, const T* __restrict__ xi, long ldv,
+                                                          int nrhs, T* __restrict__ out) {
+    __shared__ double red[4];
+    const long i = blockIdx.x;
+    const T* l = L + i * ldl;
+    for (int s = 0; s < nrhs; ++s) {
+        const T* x = xi + (long)s * ldv;
+        double acc = 0;
+        for (long j = threadIdx.x; j <= i; j += 256) acc = fma((double)l[j], (double)x[j], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(long)s * ldv + i] = (T)(red[0] + red[1] + red[2] + red[3]);
+    }
+}
+// rows [n, np) of the np×np row-major matrix become identity rows (padding of a factor)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_identity_kernel(T* __restrict__ A, long lda, long n, long np) {
+    const long i = n + blockIdx.y;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < np && j < np) A[i * lda + j] = (i == j) ? T(1) : T(0);
+}
+
 // out[s] = Σ_i variance κ(‖xs_s − x_i‖) α_i   (K_*x α fused with the kernel evaluation; one block per s)
 template <typename T>
 __global__ __launch_bounds__(256) void kvec_kernel(const T* __restrict__ xs, long ldxs, const T* __restrict__ x,

@@ -19,7 +19,7 @@ using AbstractGPs: AbstractGP, FiniteGP, GP, ZeroMean, ConstMean, CustomMean, VF
 using KernelFunctions
 using KernelFunctions: SqExponentialKernel, Matern12Kernel, ExponentialKernel, Matern32Kernel, Matern52Kernel,
     TransformedKernel, ScaledKernel, ScaleTransform, ARDTransform, ColVecs, RowVecs
-using LinearAlgebra, FillArrays, Statistics, StatsBase, Distributions
+using LinearAlgebra, FillArrays, Statistics, StatsBase, Distributions, Random
 
 export HipGP, HipPosteriorGP, HipApproxPosteriorGP, HipContext
 
@@ -207,6 +207,43 @@ function AbstractGPs.posterior(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     C = DeviceCholesky(h[], length(yv), T)
     finalizer(c -> ccall((:gp_posterior_free, libgpmi355), Int32, (Ptr{Cvoid},), getfield(c, :handle)), C)
     return HipPosteriorGP(fx.f, (α=α, C=C, x=fx.x, δ=δ), Float64(lp[]))
+end
+
+# ---- sequential conditioning (src/exact_gpr_posterior.jl:46-56; update_chol src/util/common_covmat_ops.jl:38-42) ----
+function AbstractGPs.posterior(fx::FiniteGP{<:HipPosteriorGP}, y::AbstractVector{<:Real})
+    post = fx.f
+    px = points(fx.x)
+    px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior"))
+    xbuf, cx, T = px
+    nz = noise(fx.Σy, T)
+    nz === nothing && throw(ArgumentError("dense Σy is not accelerated"))
+    m2 = prior_mean(post.prior.gp, fx.x, T)
+    δ2 = m2 === nothing ? Vector{T}(y) : Vector{T}(y) - m2                 # :48-49
+    δ = vcat(post.data.δ, δ2)                                              # :52
+    α = Vector{T}(undef, length(δ))
+    lp = Ref{T}(zero(T))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve xbuf nz δ α begin
+        check(ccall((:gp_posterior_update, libgpmi355), Int32,
+            (Ptr{Cvoid}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Ref{T}),
+            getfield(post.data.C, :handle), cx, nz[2], δ, h, α, lp))
+    end
+    C = DeviceCholesky(h[], length(δ), T)
+    finalizer(c -> ccall((:gp_posterior_free, libgpmi355), Int32, (Ptr{Cvoid},), getfield(c, :handle)), C)
+    return HipPosteriorGP(post.prior, (α=α, C=C, x=vcat(post.data.x, fx.x), δ=δ), Float64(lp[]))   # :54-55
+end
+
+# ---- sampling (src/finite_gp_projection.jl:233-237): m .+ C.U' * randn(rng, n, N), product on the device ----------
+function Random.rand(rng::Random.AbstractRNG, fx::FiniteGP{<:HipGP}, N::Int)
+    a = marshal(fx)
+    a === nothing && return rand(rng, stock(fx), N)
+    T = a.T
+    p0 = posterior(fx, zeros(T, length(fx)))          # factor of cov(fx); α = C \ (0 − m) is discarded
+    ξ = randn(rng, T, length(fx), N)
+    out = similar(ξ)
+    GC.@preserve ξ out check(ccall((:gp_posterior_factor_mul, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+        getfield(p0.data.C, :handle), ξ, N, out))
+    return mean(fx) .+ out
 end
 
 # ---- predictive methods (src/exact_gpr_posterior.jl:60-90) ----------------------------------------

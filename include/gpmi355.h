@@ -125,6 +125,18 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pri
                              int32_t what, void* mean_out, void* var_out, void* cov_out);
 /* logpdf(post(x*, Σy*), y*) is not separate: predict + host.  */
 
+/* Sequential conditioning, posterior(fx::FiniteGP{<:PosteriorGP}, y) (src/exact_gpr_posterior.jl:46-56): the resident
+ * factor of `old` is extended by the bordered-Cholesky step update_chol (src/util/common_covmat_ops.jl:38-42):
+ *   U12 = U11'\C12  (here: rows K(x2,x1)·L11⁻ᵀ by the blocked MFMA TRSM),  U22 = chol(C22 − U12'U12).
+ * x2 / noise2: the new inputs and their noise;  delta_all: δ = vcat(δ_old, y2 − m(x2)) (length n_old + n2, host).
+ * `old` stays valid.  alpha_out (n_old + n2) and logpdf_out (logpdf of all observations under the prior) optional. */
+int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all,
+                            gp_post** out, void* alpha_out_or_null, void* logpdf_out_or_null);
+
+/* out[:, s] = C.U' * xi[:, s] (n×ncols column-major host arrays, leading dimension n): the sampling transform of
+ * rand / _rand! (src/finite_gp_projection.jl:233-237, 271-277); the caller draws xi = randn(rng, n, ncols). */
+int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, void* out);
+
 /* C.U (n×n column-major upper, strictly-lower part zero) to the host — parity / debugging only. */
 int32_t gp_posterior_get_factor(gp_post* post, void* U_out);
 int64_t gp_posterior_n(gp_post* post);

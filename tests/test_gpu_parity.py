@@ -192,3 +192,46 @@ def test_vfe_fp32_streaming(agp):
     assert float(got) == pytest.approx(ref, rel=1e-4)
     got64 = agp.elbo(agp.VFE(f(agp.RowVecs(z), 1e-4)), f(agp.RowVecs(X), 0.1), y)
     assert got64 == pytest.approx(ref, rel=1e-7)
+
+
+def test_sequential_conditioning_matches_batch(agp):
+    """posterior(p_fx1(X2, σ²), y2) ≡ posterior(f(X, σ²), y) — reference test/exact_gpr_posterior.jl:29-43 (atol 1e-5 there),
+    here also against the oracle's update_chol path and with n1, n2 that are not tile multiples."""
+    rng = np.random.default_rng(11)
+    for n1, n2, d in [(3, 2, 1), (300, 77, 3), (1000, 500, 2)]:
+        X = rng.standard_normal((n1 + n2, d))
+        y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n1 + n2)
+        xin = (lambda a: a[:, 0]) if d == 1 else agp.RowVecs
+        f = agp.GP(0.3, 1.3 * agp.Matern52Kernel() @ agp.ScaleTransform(0.7))
+        p1 = agp.posterior(f(xin(X[:n1]), 0.1), y[:n1])
+        p12 = agp.posterior(p1(xin(X[n1:]), 0.1), y[n1:])
+        pb = agp.posterior(f(xin(X), 0.1), y)
+        np.testing.assert_allclose(p12.data.alpha, pb.data.alpha, rtol=0, atol=1e-8 * np.abs(pb.data.alpha).max())
+        np.testing.assert_allclose(p12.data.delta, pb.data.delta, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(np.triu(p12.data.C.U), np.triu(pb.data.C.U), rtol=0, atol=1e-10)
+        assert float(p12.logpdf_value) == pytest.approx(float(pb.logpdf_value), rel=1e-10)
+        of = o.GP(o.Kernel(o.MATERN52, 1.3, 0.7), 0.3)
+        xo = X[:, 0] if d == 1 else X
+        op1 = o.posterior(o.FiniteGP(of, xo[:n1], 0.1), y[:n1])
+        op12 = o.posterior(o.FiniteGP(op1, xo[n1:], 0.1), y[n1:])
+        np.testing.assert_allclose(p12.data.alpha, op12.alpha, rtol=0, atol=1e-8 * np.abs(op12.alpha).max())
+        xs = xin(X[:7] + 0.05)
+        m_g, v_g = p12.mean_and_var(xs)
+        m_o, v_o = op12.mean_and_var(xo[:7] + 0.05)
+        np.testing.assert_allclose(m_g, m_o, atol=1e-8)
+        np.testing.assert_allclose(v_g, v_o, atol=1e-9)
+
+
+def test_rand_matches_oracle_with_given_normals(agp):
+    """rand(rng, fx, N) = m .+ C.U' * randn — src/finite_gp_projection.jl:233-237, same standard normals on both sides."""
+    rng = np.random.default_rng(3)
+    n, d = 333, 2
+    X = rng.standard_normal((n, d))
+    xi = rng.standard_normal((n, 3))
+    f = agp.GP(-0.2, agp.SqExponentialKernel() @ agp.ScaleTransform(1.7))
+    got = agp.rand(f(agp.RowVecs(X), 0.05), 3, xi=xi)
+    ref = o.rand_from(o.FiniteGP(o.GP(o.Kernel(o.SE, 1.0, 1.7), -0.2), X, 0.05), xi)
+    assert got.shape == (n, 3)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
+    one = agp.rand(f(agp.RowVecs(X), 0.05), xi=xi[:, 0])
+    np.testing.assert_allclose(one, ref[:, 0], rtol=0, atol=1e-11)
