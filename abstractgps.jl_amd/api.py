@@ -370,6 +370,41 @@ def logpdf(fx: FiniteGP, y):
     return out[0] if y.ndim == 1 else out
 
 
+def logpdf_and_grad(fx: FiniteGP, y) -> tuple:
+    """Value and gradient of logpdf(fx, y) for the rrule of the accelerated path (the reference differentiates the same
+    expression by AD — test/finite_gp_projection.jl:152-178).  Returns (logpdf, grads) with grads =
+    {"variance": ∂/∂σ_k², "scale": ∂/∂s (ScaleTransform) or ∂/∂v (ARDTransform) or None, "noise": ∂/∂σ² (scalar Σy) or the
+    vector ∂/∂Σy_ii, "y": −α, "mean": +α}."""
+    y = _check_y(fx, y)
+    if y.ndim != 1:
+        raise TypeError("logpdf_and_grad expects a vector of observations")
+    f = fx.f
+    if not isinstance(f, GP):
+        raise TypeError("logpdf_and_grad: unsupported GP type")
+    ctx = f.context()
+    dt = np.result_type(_input_dtype(fx.x), np.float32 if y.dtype == np.float32 else np.float64).type
+    m = _Marshal(dt)
+    px = m.points(fx.x)
+    kk = m.kernel(f.kernel, px.d)
+    nz = m.noise(fx.sigma2, px.n)
+    mean = _mean_vector(f.mean_fn, fx.x, dt)
+    mean = None if mean is None else m.arr(mean)
+    yv = m.arr(y)
+    lp = np.empty(1, dtype=dt)
+    dvar = C.c_double()
+    dscale = (C.c_double * max(kk.nscale, 1))()
+    dnoise = np.empty(1 if nz.kind == 0 else px.n, dtype=dt)
+    dy = np.empty(px.n, dtype=dt)
+    check(ctx.lib.gp_logpdf_grad(ctx.handle, C.byref(kk), C.byref(px), C.byref(nz), m.ptr(mean), yv.ctypes.data,
+                                 lp.ctypes.data, C.byref(dvar), dscale, dnoise.ctypes.data, dy.ctypes.data))
+    sc = None
+    if kk.nscale == 1:
+        sc = float(dscale[0])
+    elif kk.nscale > 1:
+        sc = np.array([dscale[i] for i in range(kk.nscale)])
+    return lp[0], {"variance": dvar.value, "scale": sc, "noise": dnoise[0] if nz.kind == 0 else dnoise, "y": dy, "mean": -dy}
+
+
 def loglikelihood(fx: FiniteGP, Y):  # src/finite_gp_projection.jl:304
     return np.sum(logpdf(fx, Y))
 

@@ -821,6 +821,88 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
     return rc;
 }
 
+// logpdf value + gradient (see include/gpmi355.h gp_logpdf_grad)
+template <typename T>
+static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean,
+                         const void* y, void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy) {
+    const long n = x->n;
+    const int d = x->d;
+    if (d > 16) return set_arg_err(3, "gradients support D <= 16");
+    gp_post post{};
+    post.ctx = c;
+    FitOut fo;
+    std::vector<T> alpha_h((size_t)n);
+    RC(fit_impl<T>(c, k, x, noise, mean, y, n, 1, fo, &post, alpha_h.data()));
+    const long np = post.np, ld = post.ld;
+    hipStream_t s = c->sm;
+    void *W_v = 0, *Ci_v = 0, *g_v = 0, *dn_v = 0, *sc_v = 0;
+    const size_t M_b = sizeof(T) * (size_t)(np + 128) * ld, g_b = sizeof(double) * 32, dn_b = sizeof(T) * (size_t)np;
+    const size_t sc_b = sizeof(double) * 16;
+    double g_h[32] = {0};
+    std::vector<T> dn_h((size_t)n);
+    std::vector<double> sc_h(16, 1.0);
+    for (int p = 0; p < k->nscale && p < 16; ++p) sc_h[p] = k->scale[p];
+    int32_t rc = [&]() -> int32_t {
+        RC(ctx_alloc(c, M_b, &W_v));
+        RC(ctx_alloc(c, M_b, &Ci_v));
+        RC(ctx_alloc(c, g_b, &g_v));
+        RC(ctx_alloc(c, dn_b, &dn_v));
+        RC(ctx_alloc(c, sc_b, &sc_v));
+        T* W = (T*)W_v;
+        T* Ci = (T*)Ci_v;
+        HIPCHK(hipMemsetAsync(g_v, 0, g_b, s));
+        HIPCHK(hipMemcpyAsync(sc_v, sc_h.data(), sc_b, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(W_v, 0, M_b, s));
+        HIPCHK(hipMemsetAsync(Ci_v, 0, M_b, s));
+        hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
+        HIPCHK(hipGetLastError());
+        RC(trsm_rec<T>(c, s, W, ld, np, (const T*)post.A, ld, np));                      // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
+        RC(launch_gemm<T>(c, s, Ci, ld, W, ld, W, ld, np, np, np, plain_map(1, 0, 0)));   // Ci = −W Wᵀ = −C⁻¹ (lower)
+        // fold the sign: the kernels below read +C⁻¹
+        {
+            const long cnt = np * ld;
+            hipLaunchKernelGGL((convert_kernel<T, T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const T*)Ci, Ci, cnt,
+                               -1.0);
+            HIPCHK(hipGetLastError());
+        }
+        dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
+        hipLaunchKernelGGL((kgrad_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
+                           (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)g_v);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(noise_grad_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)Ci, ld,
+                           (const T*)post.alpha, n, (T*)dn_v, (double*)g_v + 24);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(g_h, g_v, g_b, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(dn_h.data(), dn_v, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        (void)hipStreamSynchronize(c->sp);
+    }
+    ctx_release(c, W_v, M_b);
+    ctx_release(c, Ci_v, M_b);
+    ctx_release(c, g_v, g_b);
+    ctx_release(c, dn_v, dn_b);
+    ctx_release(c, sc_v, sc_b);
+    ctx_release(c, post.A, post.A_bytes);
+    ctx_release(c, post.xs, post.xs_bytes);
+    ctx_release(c, post.alpha, post.alpha_bytes);
+    if (rc != 0) return rc;
+    *(T*)logpdf_out = (T)fo.logpdf[0];
+    if (dvar) *dvar = g_h[0];
+    if (dscale)
+        for (int p = 0; p < k->nscale; ++p) dscale[p] = g_h[1 + p];
+    if (dnoise) {
+        if (noise->kind == 0) *(T*)dnoise = (T)g_h[24];
+        else memcpy(dnoise, dn_h.data(), sizeof(T) * (size_t)n);
+    }
+    if (dy)
+        for (long i = 0; i < n; ++i) ((T*)dy)[i] = -alpha_h[i];
+    return 0;
+}
+
 // Sequential conditioning: bordered Cholesky on the device (reference src/exact_gpr_posterior.jl:46-56,
 // src/util/common_covmat_ops.jl:38-42).
 template <typename T>
@@ -1180,6 +1262,17 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
     HIPCHK(hipSetDevice(c->device));
     return post->dtype == 0 ? predict_impl<double>(post, xs, pm, what, mean_out, var_out, cov_out)
                             : predict_impl<float>(post, xs, pm, what, mean_out, var_out, cov_out);
+}
+
+int32_t gp_logpdf_grad(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean, const void* y,
+                       void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy) {
+    RC(check_fit_args(c, k, x, noise));
+    if (!y) return set_arg_err(6, "y is NULL");
+    if (!logpdf_out) return set_arg_err(7, "logpdf_out is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return k->dtype == 0 ? grad_impl<double>(c, k, x, noise, mean, y, logpdf_out, dvar, dscale, dnoise, dy)
+                         : grad_impl<float>(c, k, x, noise, mean, y, logpdf_out, dvar, dscale, dnoise, dy);
 }
 
 int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post** out,

@@ -586,6 +586,124 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
 }
 
 // ------------------------------------------------------------------------------------------------
+// kgrad: reverse-mode weights of logpdf against the kernel hyper-parameters (the pullback a ChainRules rrule of
+//   logpdf(fx, y) needs; the reference differentiates the same expression by AD — test/finite_gp_projection.jl:152-178):
+//     ∂logpdf/∂θ = ½ Σ_ij (α_i α_j − C⁻¹_ij) ∂C_ij/∂θ
+//   One 128×128 tile of the lower triangle per workgroup (strict lower counted twice).  Outputs (fp64, atomics):
+//     g[0]        ∂/∂variance           (∂C_ij = κ_ij)
+//     g[1..ns]    ∂/∂scale_p            (ScaleTransform: ns = 1, ∂r² = 2 r²/s;  ARD: ∂r² = 2 (u_ip − u_jp)²/v_p)
+//   with dκ/dr²: SE −κ/2 · Matern12 −κ/(2r) · Matern32 −(3/2)e^{−√3 r} · Matern52 −(5/6)(1+√5 r)e^{−√5 r}.
+//   x: pre-scaled inputs u = s∘x, dimension-major.  Cinv: row-major lower.  NSMAX bounds the ARD dimension.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void kappa_and_dr2(int kind, T d2, T& kap, T& dk) {
+    if (kind == 0) {
+        kap = exp(T(-0.5) * d2);
+        dk = T(-0.5) * kap;
+        return;
+    }
+    const T d = sqrt(d2);
+    if (kind == 1) {
+        kap = exp(-d);
+        dk = d > T(0) ? -kap / (T(2) * d) : T(0);
+        return;
+    }
+    if (kind == 2) {
+        const T a = T(1.7320508075688772935) * d, e = exp(-a);
+        kap = (T(1) + a) * e;
+        dk = T(-1.5) * e;
+        return;
+    }
+    const T a = T(2.2360679774997896964) * d, e = exp(-a);
+    kap = (T(1) + a + T(5.0 / 3.0) * d2) * e;
+    dk = T(-5.0 / 6.0) * (T(1) + a) * e;
+}
+
+template <typename T, int NSMAX>
+__global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ x, long ldx, int d,
+                                                     int kind, T variance, int nscale, const double* __restrict__ scale,
+                                                     const T* __restrict__ alpha, long n, double* __restrict__ g) {
+    constexpr int DC = 16;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    if (n0 > m0) return;
+    __shared__ T xi[DC][128];
+    __shared__ T xj[DC][128];
+    __shared__ double red[4][1 + NSMAX];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < d * 128; e += 256) {  // d <= DC (checked by the host)
+        const int dd = e >> 7, i = e & 127;
+        xi[dd][i] = x[(long)dd * ldx + m0 + i];
+        xj[dd][i] = x[(long)dd * ldx + n0 + i];
+    }
+    __syncthreads();
+    double acc[1 + NSMAX];
+#pragma unroll
+    for (int p = 0; p <= NSMAX; ++p) acc[p] = 0.0;
+    for (int rr = 0; rr < 32; ++rr) {
+        const int row = w + 4 * rr;
+        const long gi = m0 + row;
+        if (gi >= n) continue;
+        const T ai = alpha[gi];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int col = 2 * lane + cc;
+            const long gj = n0 + col;
+            if (gj > gi || gj >= n) continue;
+            T d2 = 0;
+            for (int dd = 0; dd < d; ++dd) {
+                const T t = xi[dd][row] - xj[dd][col];
+                d2 = fma(t, t, d2);
+            }
+            T kap, dk;
+            kappa_and_dr2<T>(kind, d2, kap, dk);
+            const double wgt = ((double)ai * (double)alpha[gj] - (double)Cinv[gi * ld + gj]) * (gi == gj ? 0.5 : 1.0);
+            acc[0] += wgt * (double)kap;
+            const double wk = wgt * (double)variance * (double)dk * 2.0;
+            if (nscale == 1) {
+                acc[1] += wk * (double)d2;
+            } else if (nscale > 1) {
+#pragma unroll
+                for (int p = 0; p < NSMAX; ++p)
+                    if (p < nscale) {
+                        const T t = xi[p][row] - xj[p][col];
+                        acc[1 + p] += wk * (double)(t * t);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p <= NSMAX; ++p) {
+        double v = acc[p];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[w][p] = v;
+    }
+    __syncthreads();
+    if (tid <= nscale && tid <= NSMAX) {
+        double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid >= 1) v /= scale[tid - 1];  // the 1/s (1/v_p) factor of ∂r²
+        atomicAdd(g + tid, v);
+    }
+}
+// out[i] = ½ (α_i² − Cinv_ii)   (∂logpdf/∂Σy_ii);  sum[0] += Σ_i out[i]   (one block of 256 threads per 256 rows)
+template <typename T>
+__global__ __launch_bounds__(256) void noise_grad_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ alpha, long n,
+                                                          T* __restrict__ out, double* __restrict__ sum) {
+    __shared__ double red[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    double v = 0;
+    if (i < n) {
+        const double a = (double)alpha[i];
+        v = 0.5 * (a * a - (double)Cinv[i * ld + i]);
+        out[i] = (T)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // potf2_64: in-place lower Cholesky of one 64×64 tile by ONE wave; lane r keeps row r in registers.
 //   Right-looking: after column c is final, every lane updates its remaining columns with the
 //   column-c entries broadcast through LDS.  info (device int32): first failing global column
@@ -1213,9 +1331,10 @@ __global__ __launch_bounds__(256) void diag_shift_trace_kernel(double* __restric
     if (threadIdx.x == 0 && out) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 // A = I (n×n, leading dimension lda)
-__global__ __launch_bounds__(256) void identity_kernel(double* __restrict__ A, long lda, long n) {
+template <typename T>
+__global__ __launch_bounds__(256) void identity_kernel(T* __restrict__ A, long lda, long n) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (j < n) A[i * lda + j] = (i == j) ? 1.0 : 0.0;
+    if (j < n) A[i * lda + j] = (i == j) ? T(1) : T(0);
 }
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, double scale) {

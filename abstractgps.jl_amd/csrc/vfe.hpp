@@ -133,7 +133,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         {
             double* Iw = (double*)I_v;
             HIPCHK(hipMemsetAsync(I_v, 0, L_b, s));
-            hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
+            hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
             HIPCHK(hipGetLastError());
             RC(trsm_rec<double>(c, s, Iw, ld, mp, Lz, ld, mp));
             hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, s, Iw, ld, Ld, ld, mp);

@@ -125,6 +125,19 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pri
                              int32_t what, void* mean_out, void* var_out, void* cov_out);
 /* logpdf(post(x*, Σy*), y*) is not separate: predict + host.  */
 
+/* Value and gradient of logpdf(f(x, Σy), y) — the pullback a ChainRules rrule for the accelerated logpdf needs (the
+ * reference differentiates logpdf by AD: test/finite_gp_projection.jl:152-178, examples/*).  One factorisation, then
+ * C⁻¹ = L⁻ᵀL⁻¹ (blocked TRSM on the identity + MFMA SYRK) and one fused pass over the lower triangle:
+ *   ∂/∂θ = ½ Σ_ij (α_i α_j − C⁻¹_ij) ∂C_ij/∂θ.
+ * Outputs (all optional except logpdf_out; kernel dtype unless noted):
+ *   dvariance_out  double[1]        ∂/∂(kernel variance)
+ *   dscale_out     double[nscale]   ∂/∂scale (ScaleTransform s, or ARDTransform v_p; D <= 16)
+ *   dnoise_out     noise.kind 0: 1 entry ∂/∂σ² = ½(αᵀα − tr C⁻¹);  kind 1: n entries ½(α_i² − C⁻¹_ii)
+ *   dy_out         n entries ∂/∂y = −α   (∂/∂m = +α for a mean vector m) */
+int32_t gp_logpdf_grad(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null,
+                       const void* y, void* logpdf_out, double* dvariance_out, double* dscale_out, void* dnoise_out,
+                       void* dy_out);
+
 /* Sequential conditioning, posterior(fx::FiniteGP{<:PosteriorGP}, y) (src/exact_gpr_posterior.jl:46-56): the resident
  * factor of `old` is extended by the bordered-Cholesky step update_chol (src/util/common_covmat_ops.jl:38-42):
  *   U12 = U11'\C12  (here: rows K(x2,x1)·L11⁻ᵀ by the blocked MFMA TRSM),  U22 = chol(C22 − U12'U12).

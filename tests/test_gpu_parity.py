@@ -235,3 +235,30 @@ def test_rand_matches_oracle_with_given_normals(agp):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
     one = agp.rand(f(agp.RowVecs(X), 0.05), xi=xi[:, 0])
     np.testing.assert_allclose(one, ref[:, 0], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("kind,okind", [(0, o.SE), (1, o.MATERN12), (2, o.MATERN32), (3, o.MATERN52)])
+def test_logpdf_grad_vs_oracle(agp, kind, okind):
+    """gp_logpdf_grad against the oracle's dense-calculus gradient (itself checked against finite differences in
+    tests/test_oracle.py): kernel variance, ScaleTransform / ARDTransform parameters, scalar and diagonal noise, y."""
+    rng = np.random.default_rng(40 + kind)
+    n, d = 300, 3
+    X = rng.standard_normal((n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    for scale, sig in [(None, 0.05), (0.8, 0.05), (np.array([0.5, 1.1, 0.9]), rng.uniform(0.03, 0.1, n))]:
+        kern = 1.4 * agp.Kernel(kind)
+        if scale is not None:
+            kern = kern @ (agp.ScaleTransform(scale) if np.ndim(scale) == 0 else agp.ARDTransform(scale))
+        f = agp.GP(0.2, kern)
+        lp, g = agp.logpdf_and_grad(f(agp.RowVecs(X), sig), y)
+        ofx = o.FiniteGP(o.GP(o.Kernel(okind, 1.4, scale), 0.2), X, sig)
+        go = o.logpdf_grad(ofx, y)
+        assert float(lp) == pytest.approx(float(o.logpdf(ofx, y)), rel=1e-10)
+        sc = max(1.0, abs(go["variance"]))
+        assert g["variance"] == pytest.approx(go["variance"], rel=1e-8, abs=1e-8 * sc)
+        if scale is None:
+            assert g["scale"] is None
+        else:
+            np.testing.assert_allclose(g["scale"], go["scale"], rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go["scale"]).max()))
+        np.testing.assert_allclose(g["noise"], go["noise"], rtol=1e-7, atol=1e-7 * max(1.0, np.abs(go["noise"]).max()))
+        np.testing.assert_allclose(g["y"], go["y"], rtol=0, atol=1e-8 * np.abs(go["y"]).max())

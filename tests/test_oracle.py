@@ -149,3 +149,35 @@ def test_float32_type_stability():
     x, y = o.synth_inputs(30, 1, 6, dtype=np.float32)
     lp = o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, np.float32(0.1)), y, dtype=np.float32)
     assert lp.dtype == np.float32
+
+
+def test_logpdf_grad_matches_finite_differences():
+    """oracle.logpdf_grad (dense matrix calculus) against central differences of oracle.logpdf — the check the
+    reference runs with FiniteDifferences vs AD (test/finite_gp_projection.jl:152-178)."""
+    rng = np.random.default_rng(21)
+    n, d = 40, 3
+    X = rng.standard_normal((n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    for kind in (o.SE, o.MATERN32, o.MATERN52):
+        for scale in (0.8, np.array([0.5, 1.1, 0.9])):
+            base = dict(kind=kind, variance=1.4, scale=scale)
+            sig = 0.07
+            g = o.logpdf_grad(o.FiniteGP(o.GP(o.Kernel(**base), 0.2), X, sig), y)
+
+            def lp(variance=1.4, scale=scale, sig=sig, yy=y):
+                return float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(kind, variance, scale), 0.2), X, sig), yy))
+
+            h = 1e-6
+            assert g["variance"] == pytest.approx((lp(variance=1.4 + h) - lp(variance=1.4 - h)) / (2 * h), rel=1e-6, abs=1e-6)
+            assert g["noise"] == pytest.approx((lp(sig=sig + h) - lp(sig=sig - h)) / (2 * h), rel=1e-5, abs=1e-5)
+            if np.ndim(scale) == 0:
+                assert g["scale"] == pytest.approx((lp(scale=scale + h) - lp(scale=scale - h)) / (2 * h), rel=1e-6, abs=1e-6)
+            else:
+                for p in range(d):
+                    e = np.zeros(d)
+                    e[p] = h
+                    fd = (lp(scale=scale + e) - lp(scale=scale - e)) / (2 * h)
+                    assert g["scale"][p] == pytest.approx(fd, rel=1e-6, abs=1e-6)
+            e0 = np.zeros(n)
+            e0[5] = h
+            assert g["y"][5] == pytest.approx((lp(yy=y + e0) - lp(yy=y - e0)) / (2 * h), rel=1e-6, abs=1e-6)
