@@ -168,6 +168,27 @@ function Distributions.logpdf(fx::FiniteGP{<:HipGP}, Y::AbstractVecOrMat{<:Real}
     return Y isa AbstractVector ? out[1] : out
 end
 
+# ---- value + gradient (what a ChainRulesCore.rrule for the accelerated logpdf returns; the reference relies on AD through
+# logpdf: test/finite_gp_projection.jl:152-178, examples/1-mauna-loa/script.jl:228-240) ------------------------------
+function logpdf_and_grad(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
+    a = marshal(fx)
+    a === nothing && throw(ArgumentError("kernel / noise form is not accelerated"))
+    T = a.T
+    yv = Vector{T}(y)
+    lp = Ref{T}(zero(T)); dvar = Ref{Float64}(0.0)
+    dscale = zeros(Float64, max(length(a.scales), 1))
+    dnoise = Vector{T}(undef, a.cn.kind == 0 ? 1 : length(yv))
+    dy = Vector{T}(undef, length(yv))
+    mptr = a.m === nothing ? C_NULL : pointer(a.m)
+    GC.@preserve a yv dscale dnoise dy begin
+        check(ccall((:gp_logpdf_grad, libgpmi355), Int32,
+            (Ptr{Cvoid}, Ref{CKernel}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{T}, Ref{Float64}, Ptr{Float64},
+                Ptr{Cvoid}, Ptr{Cvoid}),
+            fx.f.ctx.handle, a.ck, a.cx, a.cn, mptr, yv, lp, dvar, dscale, dnoise, dy))
+    end
+    return lp[], (variance=dvar[], scale=dscale[1:length(a.scales)], noise=a.cn.kind == 0 ? dnoise[1] : dnoise, y=dy, mean=-dy)
+end
+
 # ---- posterior (src/exact_gpr_posterior.jl:29-35) -------------------------------------------------
 mutable struct DeviceCholesky          # stands where `C::Cholesky` sits in PosteriorGP.data (:34)
     handle::Ptr{Cvoid}

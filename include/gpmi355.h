@@ -126,7 +126,7 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pri
 /* logpdf(post(x*, Σy*), y*) is not separate: predict + host.  */
 
 /* Value and gradient of logpdf(f(x, Σy), y) — the pullback a ChainRules rrule for the accelerated logpdf needs (the
- * reference differentiates logpdf by AD: test/finite_gp_projection.jl:152-178, examples/*).  One factorisation, then
+ * reference differentiates logpdf by AD: test/finite_gp_projection.jl:152-178 and the examples).  One factorisation, then
  * C⁻¹ = L⁻ᵀL⁻¹ (blocked TRSM on the identity + MFMA SYRK) and one fused pass over the lower triangle:
  *   ∂/∂θ = ½ Σ_ij (α_i α_j − C⁻¹_ij) ∂C_ij/∂θ.
  * Outputs (all optional except logpdf_out; kernel dtype unless noted):
