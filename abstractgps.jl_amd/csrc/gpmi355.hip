@@ -82,6 +82,8 @@ struct gp_ctx {
     struct GemmRec {
         hipEvent_t a, b;
         double flops, bytes;
+        long M, N, K;
+        int stream;  // 0 main, 1 panel
     };
     std::vector<GemmRec> gemm_recs;
     hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -210,6 +212,8 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         const double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
         rec.flops = g.ktri ? (double)N * (double)M * (double)(M + 128) : 2.0 * (double)K * elems;
         rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
+        rec.M = M; rec.N = N; rec.K = K;
+        rec.stream = (s == c->sp);
         HIPCHK(hipEventRecord(rec.a, s));
     }
     if (c->gemm_variant == 0) {
@@ -700,6 +704,8 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
             c->tm.gemm_ms += ms;
             c->tm.gemm_flops += r.flops;
             c->tm.gemm_bytes += r.bytes;
+            if (getenv("GPMI_DUMP_GEMM"))
+                fprintf(stderr, "GEMM s%d M=%ld N=%ld K=%ld ms=%.4f tflops=%.2f\n", r.stream, r.M, r.N, r.K, ms, r.flops / ms / 1e9);
         }
         return 0;
     }();

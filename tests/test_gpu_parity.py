@@ -118,14 +118,24 @@ def test_variants_agree(agp):
     ctx = agp.default_context()
     vals = []
     try:
-        for nb, la, var, sched, tm in [(2048, 1, 0, 0, 0), (1024, 0, 0, 0, 0), (0, 0, 0, 0, 0), (1024, 1, 1, 0, 0),
-                                       (1024, 1, 0, 1, 0), (512, 0, 0, 1, 1), (1024, 1, 0, 0, 1)]:
+        for nb, la, var, sched, tm, extra in [(2048, 1, 0, 0, 0, {}), (1024, 0, 0, 0, 0, {}), (0, 0, 0, 0, 0, {}),
+                                              (1024, 1, 1, 0, 0, {}), (1024, 1, 0, 1, 0, {}), (512, 0, 0, 1, 1, {}),
+                                              (1024, 1, 0, 0, 1, {}), (1024, 1, 0, 0, 0, {"gemm_dma": 0}),
+                                              (1024, 1, 0, 0, 0, {"panel_fused": 0}),
+                                              (512, 1, 0, 0, 0, {"xcd_swizzle": 1, "xcd_min_tiles": 4}),
+                                              (512, 0, 0, 0, 0, {"gemm_dma": 0, "xcd_swizzle": 1, "xcd_min_tiles": 4})]:
             ctx.set_param("nb", nb), ctx.set_param("lookahead", la), ctx.set_param("gemm_variant", var)
             ctx.set_param("sched", sched), ctx.set_param("trsm_mfma", tm)
+            for kname, kval in extra.items():
+                ctx.set_param(kname, kval)
             vals.append(float(agp.logpdf(f(agp.RowVecs(x), 0.01), y)))
+            ctx.set_param("gemm_dma", 1), ctx.set_param("panel_fused", 1), ctx.set_param("xcd_swizzle", 0)
+            ctx.set_param("xcd_min_tiles", 256)
     finally:
         ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("gemm_variant", 0)
         ctx.set_param("sched", 0), ctx.set_param("trsm_mfma", 0)
+        ctx.set_param("gemm_dma", 1), ctx.set_param("panel_fused", 1), ctx.set_param("xcd_swizzle", 0)
+        ctx.set_param("xcd_min_tiles", 256)
     ref = float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y))
     for v in vals:
         assert v == pytest.approx(ref, rel=1e-10)
@@ -262,3 +272,25 @@ def test_logpdf_grad_vs_oracle(agp, kind, okind):
             np.testing.assert_allclose(g["scale"], go["scale"], rtol=1e-8, atol=1e-8 * max(1.0, np.abs(go["scale"]).max()))
         np.testing.assert_allclose(g["noise"], go["noise"], rtol=1e-7, atol=1e-7 * max(1.0, np.abs(go["noise"]).max()))
         np.testing.assert_allclose(g["y"], go["y"], rtol=0, atol=1e-8 * np.abs(go["y"]).max())
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 1025])
+def test_tile_boundary_sizes(agp, n):
+    """ragged sizes around every tile boundary (64-wide leaves, 128-wide tiles, identity padding), custom mean function,
+    matrix-valued Y, cross-covariance of the posterior."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 2))
+    Y = rng.standard_normal((n, 3))
+    mfun = lambda v: 0.3 * v[0] - 0.1  # CustomMean  src/mean_function.jl:52-55
+    f = agp.GP(mfun, 0.7 * agp.Matern32Kernel() @ agp.ScaleTransform(1.3))
+    of = o.GP(o.Kernel(o.MATERN32, 0.7, 1.3), mfun)
+    fx, ofx = f(agp.RowVecs(X), 0.2), o.FiniteGP(of, X, 0.2)
+    np.testing.assert_allclose(agp.logpdf(fx, Y), o.logpdf(ofx, Y), rtol=1e-10)
+    post, opost = agp.posterior(fx, Y[:, 0]), o.posterior(ofx, Y[:, 0])
+    assert _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+    xs, zs = rng.standard_normal((5, 2)), rng.standard_normal((4, 2))
+    np.testing.assert_allclose(post.cov(agp.RowVecs(xs), agp.RowVecs(zs)), opost.cov(xs, zs), atol=1e-9)
+    m, v = post.mean_and_var(agp.RowVecs(xs))
+    mo, vo = opost.mean_and_var(xs)
+    np.testing.assert_allclose(m, mo, atol=1e-8)
+    np.testing.assert_allclose(v, vo, atol=1e-9)
