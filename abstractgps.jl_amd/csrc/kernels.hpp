@@ -1304,6 +1304,13 @@ __global__ __launch_bounds__(256) void neg_sym_to_f64_kernel(const T* __restrict
     const long a = i > j ? i : j, b = i > j ? j : i;
     dst[i * ldd + j] = -(double)src[a * lds + b];
 }
+// dst[i][j] += (double) src[i][j] for j <= i  (fp64 accumulation of an fp32 partial SYRK result, lower triangle)
+template <typename T>
+__global__ __launch_bounds__(256) void add_lower_to_f64_kernel(const T* __restrict__ src, long lds, double* __restrict__ dst,
+                                                                long ldd, long n) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j <= i && j < n) dst[i * ldd + j] += (double)src[i * lds + j];
+}
 // dst = srcᵀ (n×n, 32×32 LDS tiles)
 __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst,
                                                             long ldd, long n) {

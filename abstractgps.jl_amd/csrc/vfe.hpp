@@ -82,7 +82,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     const size_t Y_b = sizeof(T) * (size_t)(mp + 128) * ldy, Li_b = sizeof(T) * (size_t)(mp + 128) * ld;
     const size_t vT_b = sizeof(double) * (size_t)mp, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
     void *xs_v = 0, *zsT_v = 0, *zsD_v = 0, *rs_v = 0, *b_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *LzT_v = 0, *cT_v = 0,
-         *vec_v = 0, *jit_v = 0, *Y_v = 0, *Li_v = 0, *I_v = 0;
+         *vec_v = 0, *jit_v = 0, *Y_v = 0, *Li_v = 0, *I_v = 0, *S_v = 0;
     constexpr bool is_f64 = sizeof(T) == 8;
     RC(ctx_alloc(c, xs_b, &xs_v));
     RC(ctx_alloc(c, zsT_b, &zsT_v));
@@ -96,6 +96,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(ctx_alloc(c, Y_b, &Y_v));
     RC(ctx_alloc(c, Li_b, &Li_v));
     RC(ctx_alloc(c, L_b, &I_v));
+    if (!is_f64) RC(ctx_alloc(c, Li_b, &S_v));
     RC(ctx_alloc(c, vT_b, &cT_v));
     RC(ctx_alloc(c, vD_b, &vec_v));
     RC(ctx_alloc(c, jit_b, &jit_v));
@@ -160,7 +161,22 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             hipLaunchKernelGGL(sumsq_accum_kernel<T>, dim3((unsigned)mp), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
                                c->scal_dev + 4);                                                   // ‖A‖²_F in fp64
             HIPCHK(hipGetLastError());
-            RC((launch_gemm<T, double>(c, s, (double*)D_v, ld, (const T*)Y_v, ldy, (const T*)Y_v, ldy, mp, mp, CH, plain_map(1, 0, 0))));
+            if constexpr (is_f64) {
+                RC((launch_gemm<T, double>(c, s, (double*)D_v, ld, (const T*)Y_v, ldy, (const T*)Y_v, ldy, mp, mp, CH,
+                                           plain_map(1, 0, 0))));
+            } else {
+                // fp32: the chunk's SYRK runs on the LDS-DMA kernel into an fp32 scratch (−Y Yᵀ over this chunk's 8 192 data
+                // points only), which is then added into the fp64 accumulator — fp64 sums across chunks, fp32 MFMA within
+                GridMap gs = plain_map(1, 0, 0);
+                gs.beta0 = 1;
+                constexpr long KS = 2048;  // fp32 chain length per partial product (accuracy: fp64 sums beyond this)
+                for (long k0 = 0; k0 < CH; k0 += KS) {
+                    RC(launch_gemm<T>(c, s, (T*)S_v, ld, (const T*)Y_v + k0, ldy, (const T*)Y_v + k0, ldy, mp, mp, KS, gs));
+                    hipLaunchKernelGGL(add_lower_to_f64_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0,
+                                       s, (const T*)S_v, ld, (double*)D_v, ld, mp);
+                    HIPCHK(hipGetLastError());
+                }
+            }
             hipLaunchKernelGGL(rowdot_sub_kernel<T>, dim3((unsigned)mp), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
                                (const T*)b_v + c0, (double*)cT_v);                                 // cT −= Y b_c = +B_c b_c
             HIPCHK(hipGetLastError());
@@ -219,6 +235,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     ctx_release(c, Y_v, Y_b);
     ctx_release(c, Li_v, Li_b);
     ctx_release(c, I_v, L_b);
+    ctx_release(c, S_v, Li_b);
     ctx_release(c, cT_v, vT_b);
     ctx_release(c, jit_v, jit_b);
     if (rc == 0 && info_h != 0) rc = info_h;
