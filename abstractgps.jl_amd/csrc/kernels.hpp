@@ -69,6 +69,7 @@ struct GridMap {
     int tm;          // number of tile rows (modes 2, 3)
     int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
     int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
+                     // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
 };
 // compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
 __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     acc_t acc[4][4];
     CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
     const CT* const Cr = active ? Cw : C + li;
-    dma(0, 0);
+    const int kt0 = (g.ktri == 2) ? m0 / BK : 0;
+    dma(0, kt0);
     if (g.beta0) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -428,11 +430,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     const int sw = (li >> 1) & 7;
     const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
     int nk = K / BK;
-    if (g.ktri) nk = min(nk, (m0 + 128) / BK);
+    if (g.ktri == 1) nk = min(nk, (m0 + 128) / BK);
     dma_wait_barrier();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         dma(cur ^ 1, (kt + 1 < nk) ? kt + 1 : kt);  // the last step re-fetches its own tile into the idle buffer
         chunk_t a[2][4], b[2][4];
 #pragma unroll

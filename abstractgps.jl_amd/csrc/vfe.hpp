@@ -136,7 +136,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             HIPCHK(hipMemsetAsync(I_v, 0, L_b, s));
             hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
             HIPCHK(hipGetLastError());
-            RC(trsm_rec<double>(c, s, Iw, ld, mp, Lz, ld, mp));
+            RC(trsm_upper_rec<double>(c, s, Iw, ld, Lz, ld, 0, mp));
             hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, s, Iw, ld, Ld, ld, mp);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemsetAsync(Li_v, 0, Li_b, s));
