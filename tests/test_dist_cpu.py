@@ -44,7 +44,7 @@ def _worker(rank, world, port, grid, n, d, nb, kind, q):
 
 
 @pytest.mark.parametrize("world,grid,n,d,nb", [(2, (1, 2), 700, 3, 128), (2, (2, 1), 515, 1, 256), (4, (2, 2), 900, 2, 128),
-                                               (1, (1, 1), 300, 3, 128)])
+                                               (1, (1, 1), 300, 3, 128), (8, (2, 4), 1300, 3, 128), (4, (1, 4), 1100, 2, 128)])
 def test_block_cyclic_fit_matches_oracle(world, grid, n, d, nb):
     from oracle import gp_oracle as o
 
