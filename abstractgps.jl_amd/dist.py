@@ -237,17 +237,20 @@ class BlockCyclicEngine:
             lbk_r, lbk_c = k // P, k // Q                     # local block indices on the owners
             if q == qk:
                 c0 = lbk_c * NB
-                if p == pk:
+                if P == 1:                                    # one owner: diagonal block and every row below in one call
                     r0 = lbk_r * NB
                     be.potrf(_sub(A, r0, c0), ldl, m_loc - r0, NB, info, k * NB, n, scal[0:1])
-                    if P > 1:
+                else:
+                    # several row owners: factor ONLY the diagonal block, ship L_kk down the process column at once, then
+                    # all owners (the diagonal owner included) solve their rows below concurrently
+                    if p == pk:
+                        r0 = lbk_r * NB
+                        be.potrf(_sub(A, r0, c0), ldl, NB, NB, info, k * NB, n, scal[0:1])
                         Lkk.copy_(A[r0:r0 + NB, c0:c0 + NB])
-                if P > 1:
                     self._bcast_col(Lkk, pk, qk)
-                    if p != pk:
-                        r0 = self._nlb_before(k, p, P) * NB   # my first local row with global block > k
-                        if m_loc - r0 > 0:
-                            be.trsm(_sub(A, r0, c0), ldl, m_loc - r0, Lkk, NB, NB)
+                    r0 = self._nlb_before(k, p, P) * NB       # my first local row with global block > k
+                    if m_loc - r0 > 0:
+                        be.trsm(_sub(A, r0, c0), ldl, m_loc - r0, Lkk, NB, NB)
             works = []
             for pp, (r0p, mp) in enumerate(rows_below(k)):    # one piece per process row, to everyone
                 if mp <= 0:
