@@ -70,6 +70,7 @@ struct gp_ctx {
     int gemm_variant = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
+    int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
     int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
     int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
@@ -360,15 +361,23 @@ template <typename T> static int32_t trtri_tiles(gp_ctx* c, hipStream_t s, const
     *Wout = (T*)c->w_ws;
     return 0;
 }
+// 64-wide TRSM leaf: MFMA kernel (trsm64_mfma, one workgroup per 128 rows) or the VALU kernel (one lane per row)
+template <typename T>
+static int32_t launch_trsm64(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl) {
+    if (M <= 0) return 0;
+    if (c->trsm_leaf_mfma)
+        hipLaunchKernelGGL(trsm64_mfma_kernel<T>, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, X, ldx, (int)M, L, ldl);
+    else
+        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, X, ldx, (int)M, L, ldl,
+                           (const T*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // VALU base case (trsm_64, one lane per row): faster when nothing else runs, starves beside fp64 MFMA kernels.
 template <typename T>
 static int32_t trsm_rec_v(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
-    if (n <= 64) {
-        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, X, ldx, (int)M, L, ldl,
-                           (const T*)nullptr);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
+    if (n <= 64) return launch_trsm64<T>(c, s, X, ldx, M, L, ldl);
     const long h = split_half(n);
     RC(trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, h));
     RC(launch_gemm<T>(c, s, X + h, ldx, X, ldx, L + h * ldl, ldl, M, n - h, h, plain_map(0, 0, 0)));
@@ -380,12 +389,7 @@ static int32_t trsm_rec_v(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, cons
 // solve.  Same recursion as trsm_rec_v.
 template <typename T>
 static int32_t trsm_upper_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, const T* L, long ldl, long j0, long n) {
-    if (n <= 64) {
-        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((j0 + 64) / 64)), dim3(64), 0, s, X + j0, ldx, (int)(j0 + 64),
-                           L + j0 * ldl + j0, ldl, (const T*)nullptr);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
+    if (n <= 64) return launch_trsm64<T>(c, s, X + j0, ldx, j0 + 64, L + j0 * ldl + j0, ldl);
     const long h = split_half(n);
     RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0, h));
     RC(launch_gemm<T>(c, s, X + j0 + h, ldx, X + j0, ldx, L + (j0 + h) * ldl + j0, ldl, j0 + h, n - h, h, plain_map(0, 0, 0)));
@@ -1157,6 +1161,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
+    else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);

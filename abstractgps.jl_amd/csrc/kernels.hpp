@@ -989,6 +989,104 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
 }
 
 // ------------------------------------------------------------------------------------------------
+// trsm64_mfma: X[M×64] ← X · L⁻ᵀ against a GIVEN 64×64 lower tile, on the matrix pipe (the leaf of every blocked TRSM:
+//   predictive variances, sequential updates, triangular inverses, the multi-GPU rows-below solve).  One workgroup per
+//   128 rows.  The four 16×16 diagonal blocks of L are inverted concurrently, one per wave (lane = column of the
+//   inverse, forward substitution against LDS broadcasts); then the same block TRSM / block update products P·Qᵀ as
+//   in panel64_kernel.  M multiple of 64.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void trsm64_mfma_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L, long ldl) {
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    using acc_t = typename TR::acc_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int LD = 65, LI = 17;
+    __shared__ T Ds[64 * LD];
+    __shared__ T Xs[128 * LD];
+    __shared__ T Inv[4][16 * LI];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    int xrows = M - (int)blockIdx.x * 128;
+    xrows = xrows > 128 ? 128 : xrows;
+    T* const Xg = X + (long)blockIdx.x * 128 * ldx;
+    for (int e = tid; e < 64 * (64 / VEC); e += 256) {
+        const int row = e / (64 / VEC), cc = e % (64 / VEC);
+        const chunk_t v = *reinterpret_cast<const chunk_t*>(L + (long)row * ldl + cc * VEC);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = v[q];
+    }
+    for (int e = tid; e < 128 * (64 / VEC); e += 256) {
+        const int row = e / (64 / VEC), cc = e % (64 / VEC);
+        chunk_t v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = T(0);
+        if (row < xrows) v = *reinterpret_cast<const chunk_t*>(Xg + (long)row * ldx + cc * VEC);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = v[q];
+    }
+    __syncthreads();
+    {  // wave w inverts diagonal block w: lane c (< 16) owns column c of inv(L16); x[r] = Inv[r][c]
+        const T* Lb = &Ds[(16 * w) * LD + 16 * w];
+        T x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            T sacc = (li == r) ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < r; ++k) sacc = fma(-Lb[r * LD + k], x[k], sacc);
+            x[r] = sacc / Lb[r * LD + r];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Inv[w][r * LI + li] = x[r];
+        }
+    }
+    __syncthreads();
+    const int nxt = xrows >> 4;
+    auto mma16 = [&](acc_t d, const T* P, int ldp, const T* Q, int ldq, bool neg) -> acc_t {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            T a = P[li * ldp + 4 * m + lg];
+            const T b = Q[li * ldq + 4 * m + lg];
+            if (neg) a = -a;
+            d = TR::mfma(a, b, d);
+        }
+        return d;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        for (int q = w; q < nxt; q += 4) {
+            T* P = &Xs[(16 * q) * LD + 16 * j];
+            acc_t d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = T(0);
+            d = mma16(d, P, LD, &Inv[j][0], LI, false);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[TR::crow(lane, r) * LD + li] = d[r];
+        }
+        __syncthreads();
+        if (j < 3) {
+            const int nk = 3 - j;
+            for (int q = w; q < nxt * nk; q += 4) {
+                const int rt = q / nk, bk = j + 1 + q % nk;
+                T* Cb = &Xs[(16 * rt) * LD + 16 * bk];
+                acc_t d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = Cb[TR::crow(lane, r) * LD + li];
+                d = mma16(d, &Xs[(16 * rt) * LD + 16 * j], LD, &Ds[(16 * bk) * LD + 16 * j], LD, true);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cb[TR::crow(lane, r) * LD + li] = d[r];
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < xrows * 64; e += 256) {
+        const int row = e >> 6, c = e & 63;
+        Xg[(long)row * ldx + c] = Xs[row * LD + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // trsm_64: X[M×64] ← X · L⁻ᵀ, L 64×64 lower (row-major).  One lane per row of X (row in registers),
 //   one wave (64 rows) per block so that M = 65 536 rows spread as 4 waves per CU.  Lᵀ sits in LDS so the
 //   column of L needed after x_c is final is one contiguous broadcast read.  lt_pre (nullable): the
