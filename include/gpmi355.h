@@ -91,8 +91,19 @@ typedef struct {
  * current torch stream in the multi-process driver); NULL = the ctx creates its own. */
 int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null);
 int32_t gp_ctx_destroy(gp_ctx* ctx);
-/* names: "nb" (outer panel width, multiple of 128), "lookahead" (0/1), "time_kernels" (0/1),
- * "gemm_variant" (0 = MFMA, 1 = VALU debug reference). */
+/* Tuning / diagnostic parameters (all optional; the GPMI_PARAMS="name=value,..." environment variable applies the same
+ * names at gp_ctx_create):
+ *   "nb"             outer panel width (multiple of 128; 0 = purely recursive)            default 2048
+ *   "lookahead"      next panel on a second, high-priority stream (0/1)                   default 1
+ *   "sched"          0 whole-panel look-ahead, 1 diagonal-first with all-MFMA rows-below  default 0
+ *   "time_kernels"   bracket every MFMA GEMM launch with HIP events (gp_get_timings)      default 0
+ *   "gemm_variant"   0 = MFMA kernels, 1 = VALU debug reference                           default 0
+ *   "gemm_dma"       NT GEMM operands by LDS-DMA (1) or register staging (0)              default 1
+ *   "panel_fused"    fused 64-column leaf kernel (1) or potf2_64 + trsm_64 (0)            default 1
+ *   "trsm_leaf_mfma" MFMA TRSM leaf (1) or VALU leaf (0)                                  default 1
+ *   "trsm_mfma"      all-MFMA blocked TRSM through I − inv(L_jj) tiles                    default 0
+ *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
+ *   "ldpad"          row padding in elements (multiple of 16)                             default 32 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 int32_t gp_get_timings(gp_ctx* ctx, gp_timings* out);
 const char* gp_last_error(void);
