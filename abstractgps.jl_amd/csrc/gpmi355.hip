@@ -144,7 +144,7 @@ static void ctx_release(gp_ctx* c, void* p, size_t bytes) {
         return;
     }
     c->pool.push_back({p, bytes});
-    while (c->pool.size() > 6) {  // bound the cache
+    while (c->pool.size() > 32) {  // bound the cache (a VFE fit alone cycles through ~16 buffers)
         (void)hipFree(c->pool.front().p);
         c->pool.erase(c->pool.begin());
     }
