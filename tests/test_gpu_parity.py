@@ -294,3 +294,31 @@ def test_tile_boundary_sizes(agp, n):
     mo, vo = opost.mean_and_var(xs)
     np.testing.assert_allclose(m, mo, atol=1e-8)
     np.testing.assert_allclose(v, vo, atol=1e-9)
+
+
+def test_float32_gradient_update_and_rand(agp):
+    """Float32 in -> Float32 out for the newer entry points too (reference type-stability tests,
+    test/finite_gp_projection.jl:180-191), values within fp32 accuracy of the fp64 oracle."""
+    rng = np.random.default_rng(8)
+    n, d = 500, 2
+    X = rng.standard_normal((n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    X32, y32 = X.astype(np.float32), y.astype(np.float32)
+    f = agp.GP(1.2 * agp.SqExponentialKernel() @ agp.ScaleTransform(0.9))
+    ofx = o.FiniteGP(o.GP(o.Kernel(o.SE, 1.2, 0.9)), X, 0.1)
+    lp, g = agp.logpdf_and_grad(f(agp.RowVecs(X32), np.float32(0.1)), y32)
+    go = o.logpdf_grad(ofx, y)
+    assert isinstance(lp, np.float32) and g["y"].dtype == np.float32
+    assert float(lp) == pytest.approx(float(o.logpdf(ofx, y)), rel=2e-4)
+    assert g["variance"] == pytest.approx(go["variance"], rel=5e-3, abs=5e-3 * abs(go["noise"]))
+    assert g["scale"] == pytest.approx(go["scale"], rel=5e-3, abs=5e-3 * abs(go["noise"]))
+    assert float(g["noise"]) == pytest.approx(go["noise"], rel=5e-3)
+    p1 = agp.posterior(f(agp.RowVecs(X32[:300]), np.float32(0.1)), y32[:300])
+    p12 = agp.posterior(p1(agp.RowVecs(X32[300:]), np.float32(0.1)), y32[300:])
+    assert p12.data.alpha.dtype == np.float32
+    oa = o.posterior(ofx, y).alpha
+    assert _relnorm(p12.data.alpha.astype(np.float64), oa) <= 5e-3
+    xi = rng.standard_normal((n, 2)).astype(np.float32)
+    smp = agp.rand(f(agp.RowVecs(X32), np.float32(0.1)), 2, xi=xi)
+    assert smp.dtype == np.float32
+    np.testing.assert_allclose(smp, o.rand_from(ofx, xi.astype(np.float64)), atol=5e-3)
