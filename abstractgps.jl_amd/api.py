@@ -552,8 +552,21 @@ def rand(fx: FiniteGP, N: Optional[int] = None, rng=None, xi=None):
         post0 = _posterior_exact(fx, np.zeros(n, dtype=_input_dtype(fx.x)))   # factor of cov(fx) = K + Σy
         fac, dt = post0.data.C, post0.data.C.dtype
         mvec = f.mean(fx.x)
-    elif isinstance(f, PosteriorGP):
-        raise NotImplementedError("rand of a posterior FiniteGP: use mean_and_cov + host Cholesky (small N*)")
+    elif isinstance(f, (PosteriorGP, ApproxPosteriorGP)) and hasattr(f, "mean_and_cov"):
+        # posterior samples at N* test points: predictive mean/cov from the device, N*×N* factor on the host
+        # (N* is plot-sized in the reference's usage: src/util/plotting.jl:120-132)
+        mvec, Cm = f.mean_and_cov(fx.x)
+        Cm = np.array(Cm, dtype=np.float64)
+        Cm[np.diag_indices_from(Cm)] += fx.noise_vector()
+        try:
+            Lh = np.linalg.cholesky(Cm)
+        except np.linalg.LinAlgError:
+            raise PosDefException(-1)
+        ncols = 1 if N is None else int(N)
+        if xi is None:
+            xi = (rng or np.random.default_rng()).standard_normal((n, ncols))
+        out = np.asarray(mvec, dtype=np.float64)[:, None] + Lh @ np.asarray(xi, dtype=np.float64).reshape(n, ncols)
+        return out[:, 0] if N is None else out
     else:
         raise TypeError("rand: unsupported GP type")
     ncols = 1 if N is None else int(N)

@@ -245,6 +245,16 @@ def test_rand_matches_oracle_with_given_normals(agp):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
     one = agp.rand(f(agp.RowVecs(X), 0.05), xi=xi[:, 0])
     np.testing.assert_allclose(one, ref[:, 0], rtol=0, atol=1e-11)
+    # posterior samples at a few test points (sampleplot-style usage)
+    y = np.sin(X.sum(1))
+    post = agp.posterior(f(agp.RowVecs(X), 0.05), y)
+    opost = o.posterior(o.FiniteGP(o.GP(o.Kernel(o.SE, 1.0, 1.7), -0.2), X, 0.05), y)
+    xs = rng.standard_normal((9, d))
+    xi2 = rng.standard_normal((9, 2))
+    mo, Co = opost.mean_and_cov(xs)
+    ref2 = mo[:, None] + np.linalg.cholesky(Co + 1e-6 * np.eye(9)) @ xi2
+    got2 = agp.rand(post(agp.RowVecs(xs), 1e-6), 2, xi=xi2)
+    np.testing.assert_allclose(got2, ref2, rtol=0, atol=1e-7)
 
 
 @pytest.mark.parametrize("kind,okind", [(0, o.SE), (1, o.MATERN12), (2, o.MATERN32), (3, o.MATERN52)])
