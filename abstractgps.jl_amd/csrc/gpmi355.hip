@@ -210,7 +210,8 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
     if (timed) {
         RC(ctx_event(c, &rec.a, true));
         RC(ctx_event(c, &rec.b, true));
-        const double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
+        double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
+        if (g.nbatch > 1) elems *= g.nbatch;
         rec.flops = g.ktri == 1 ? (double)N * (double)M * (double)(M + 128)
                                 : (g.ktri == 2 ? (double)M * (double)M * (double)M / 3.0 : 2.0 * (double)K * elems);
         rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
@@ -244,10 +245,11 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             g.compact = 1;
             grid = dim3((unsigned)total, 1);
         }
+        if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
         if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
-        else if ((c->gemm_dma || g.beta0 || g.ktri) && std::is_same<T, CT>::value)
+        else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value)
             hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g);
         else
@@ -283,6 +285,8 @@ static GridMap plain_map(int lower, long row0, long col0) {
     g.tm = 0;
     g.beta0 = 0;
     g.ktri = 0;
+    g.nbatch = 1;
+    g.cstride = 0;
     return g;
 }
 

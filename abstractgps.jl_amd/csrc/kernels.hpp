@@ -70,6 +70,8 @@ struct GridMap {
     int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
     int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
                      // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
+    int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
+    long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
 };
 // compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
 __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
@@ -350,6 +352,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     if (g.compact == 1) compact_tile(g, (int)blockIdx.x, bi, bj);
     else if (g.compact >= 2) {
         if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
+    } else if (g.ktri == 1) {
+        bi = (int)gridDim.y - 1 - bi;  // triangular k range: the long row tiles are dispatched first
+    }
+    if (g.nbatch > 1) {
+        C += (long)blockIdx.z * g.cstride;
+        A += (long)blockIdx.z * K;
+        B += (long)blockIdx.z * K;
     }
     const int m0 = bi * 128, n0 = bj * 128;
     long gr0 = 0, gc0 = 0;

@@ -96,7 +96,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(ctx_alloc(c, Y_b, &Y_v));
     RC(ctx_alloc(c, Li_b, &Li_v));
     RC(ctx_alloc(c, L_b, &I_v));
-    if (!is_f64) RC(ctx_alloc(c, Li_b, &S_v));
+    if (!is_f64) RC(ctx_alloc(c, 4 * Li_b, &S_v));
     RC(ctx_alloc(c, vT_b, &cT_v));
     RC(ctx_alloc(c, vD_b, &vec_v));
     RC(ctx_alloc(c, jit_b, &jit_v));
@@ -167,13 +167,18 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             } else {
                 // fp32: the chunk's SYRK runs on the LDS-DMA kernel into an fp32 scratch (−Y Yᵀ over this chunk's 8 192 data
                 // points only), which is then added into the fp64 accumulator — fp64 sums across chunks, fp32 MFMA within
+                // four K = 2 048 partial products in ONE launch (blockIdx.z): 4 × 528 lower tiles fill the 512 workgroup
+                // slots four times over instead of 1.03 times; the partials are summed into the fp64 accumulator below
+                constexpr long KS = 2048;
+                constexpr int NB4 = (int)(8192 / KS);
                 GridMap gs = plain_map(1, 0, 0);
                 gs.beta0 = 1;
-                constexpr long KS = 2048;  // fp32 chain length per partial product (accuracy: fp64 sums beyond this)
-                for (long k0 = 0; k0 < CH; k0 += KS) {
-                    RC(launch_gemm<T>(c, s, (T*)S_v, ld, (const T*)Y_v + k0, ldy, (const T*)Y_v + k0, ldy, mp, mp, KS, gs));
+                gs.nbatch = NB4;
+                gs.cstride = (long)(mp + 128) * ld;
+                RC(launch_gemm<T>(c, s, (T*)S_v, ld, (const T*)Y_v, ldy, (const T*)Y_v, ldy, mp, mp, KS, gs));
+                for (int b = 0; b < NB4; ++b) {
                     hipLaunchKernelGGL(add_lower_to_f64_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0,
-                                       s, (const T*)S_v, ld, (double*)D_v, ld, mp);
+                                       s, (const T*)S_v + (long)b * gs.cstride, ld, (double*)D_v, ld, mp);
                     HIPCHK(hipGetLastError());
                 }
             }
@@ -235,7 +240,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     ctx_release(c, Y_v, Y_b);
     ctx_release(c, Li_v, Li_b);
     ctx_release(c, I_v, L_b);
-    ctx_release(c, S_v, Li_b);
+    ctx_release(c, S_v, 4 * Li_b);
     ctx_release(c, cT_v, vT_b);
     ctx_release(c, jit_v, jit_b);
     if (rc == 0 && info_h != 0) rc = info_h;
