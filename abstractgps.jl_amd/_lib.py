@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gp_posterior_n": (i64, [vp]),
     "gp_posterior_free": (i32, [vp]),
     "gp_vfe_fit": (i32, [vp, PK, PP, PP, PN, dbl, vp, vp, i32, C.POINTER(vp), vp]),
+    "gp_vfe_update": (i32, [vp, PP, PN, vp, vp, C.POINTER(vp), vp]),
     "gp_vfe_predict": (i32, [vp, PP, vp, i32, vp, vp]),
     "gp_vfe_get": (i32, [vp, vp, vp]),
     "gp_vfe_free": (i32, [vp]),

@@ -737,6 +737,41 @@ def inducing_points(f: ApproxPosteriorGP):  # :219
     return f.approx.fz.x
 
 
+def update_posterior(f_post_approx: ApproxPosteriorGP, fx: FiniteGP, y=None):
+    """update_posterior(f_post_approx, fx, y)  — new observations, same pseudo-points (src/sparse_approximations.jl:87-121):
+    the device continues its streamed reductions with the new points and re-finalises the M×M side.
+    update_posterior(f_post_approx, fz)      — append pseudo-points (:131-176): the bordered update of the reference equals
+    a fit with z = vcat(z_old, z_new); the mirror refits from the observations it has seen."""
+    if f_post_approx.prior is not fx.f:
+        raise AssertionError("f_post_approx.prior === fx.f")
+    st = f_post_approx._state
+    dt = f_post_approx._dtype
+    if y is None:  # new pseudo-points
+        hist = getattr(f_post_approx, "_history", None)
+        if hist is None:
+            raise NotImplementedError("appending pseudo-points needs the observations (posterior built by this module)")
+        z_all, _ = _stack_inputs(f_post_approx.approx.fz.x, fx.x)
+        approx = type(f_post_approx.approx)(f_post_approx.prior(z_all, f_post_approx.approx.fz.sigma2))
+        post = None
+        for i, (hx, hs2, hy) in enumerate(hist):
+            hfx = f_post_approx.prior(hx, hs2)
+            post = posterior(approx, hfx, hy) if i == 0 else update_posterior(post, hfx, hy)
+        return post
+    y = _check_y(fx, y)
+    mm = _Marshal(dt)
+    px = mm.points(fx.x)
+    nz = mm.noise(fx.sigma2, px.n)
+    mean = _mean_vector(f_post_approx.prior.mean_fn, fx.x, dt)
+    mean = None if mean is None else mm.arr(mean)
+    yv = mm.arr(y)
+    obj = np.empty(1, dtype=dt)
+    h = C.c_void_p()
+    check(st.ctx.lib.gp_vfe_update(st.handle, C.byref(px), C.byref(nz), mm.ptr(mean), yv.ctypes.data, C.byref(h), obj.ctypes.data))
+    new = ApproxPosteriorGP(f_post_approx.approx, f_post_approx.prior, _VfeState(st.ctx, h), dt, f_post_approx._m, obj[0])
+    new._history = list(getattr(f_post_approx, "_history", [])) + [(fx.x, fx.sigma2, np.asarray(y))]
+    return new
+
+
 def posterior(*args):
     """posterior(fx, y)                      — src/exact_gpr_posterior.jl:29-35
     posterior(VFE(fz)|DTC(fz), fx, y)     — src/sparse_approximations.jl:58-75
@@ -749,7 +784,9 @@ def posterior(*args):
             return _posterior_exact(fx, y)
         if isinstance(a, (VFE, DTC)):
             h, obj, ctx, dt, m = _vfe_call(a, fx, y, True)
-            return ApproxPosteriorGP(a, fx.f, _VfeState(ctx, h), dt, m, obj)
+            post = ApproxPosteriorGP(a, fx.f, _VfeState(ctx, h), dt, m, obj)
+            post._history = [(fx.x, fx.sigma2, np.asarray(y))]
+            return post
     raise TypeError("posterior(fx, y) or posterior(approx, fx, y)")
 
 

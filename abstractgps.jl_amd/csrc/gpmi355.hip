@@ -1426,6 +1426,41 @@ int32_t gp_vfe_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_p
     return 0;
 }
 
+int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, const void* mean2, const void* y2, gp_vfe** out,
+                      void* objective_out) {
+    if (!old || !reg_has(old)) return set_arg_err(1, "not a live gp_vfe");
+    RC(check_points(x2, 2));
+    if (x2->d != old->d) return set_arg_err(2, "x2 has a different D than the training inputs");
+    if (!noise2 || (noise2->kind != 0 && noise2->kind != 1) || (noise2->kind == 1 && !noise2->diag))
+        return set_arg_err(3, "bad noise");
+    if (!y2) return set_arg_err(5, "y2 is NULL");
+    if (!out) return set_arg_err(6, "out is NULL");
+    *out = nullptr;
+    gp_ctx* c = old->ctx;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    gp_kernel k{};
+    k.kind = old->kind; k.dtype = old->dtype; k.variance = old->variance; k.nscale = old->nscale;
+    k.scale = old->scale.empty() ? nullptr : old->scale.data();
+    gp_vfe* p = new gp_vfe();
+    p->ctx = c;
+    double obj = 0;
+    int32_t rc = old->dtype == 0 ? vfe_fit_impl<double>(c, &k, x2, nullptr, noise2, 0.0, mean2, y2, old->approx, p, &obj, old)
+                                 : vfe_fit_impl<float>(c, &k, x2, nullptr, noise2, 0.0, mean2, y2, old->approx, p, &obj, old);
+    if (rc != 0) {
+        delete p;
+        return rc;
+    }
+    if (objective_out) {
+        if (old->dtype == 0) *(double*)objective_out = obj;
+        else *(float*)objective_out = (float)obj;
+    }
+    c->refs++;
+    reg_add(p);
+    *out = p;
+    return 0;
+}
+
 int32_t gp_vfe_predict(gp_vfe* p, const gp_points* xs, const void* pm, int32_t what, void* mean_out, void* var_out) {
     if (!p || !reg_has(p)) return set_arg_err(1, "not a live gp_vfe");
     RC(check_points(xs, 2));
@@ -1470,6 +1505,10 @@ int32_t gp_vfe_free(gp_vfe* p) {
         ctx_release(c, p->Ld, p->L_bytes);
         ctx_release(c, p->zs, p->zs_bytes);
         ctx_release(c, p->alpha, p->vec_bytes);
+        ctx_release(c, p->Dacc, p->D_bytes);
+        ctx_release(c, p->cacc, p->c_bytes);
+        ctx_release(c, p->Li, p->Li_bytes);
+        ctx_release(c, p->zsT, p->zsT_bytes);
     }
     delete p;
     ctx_unref(c);

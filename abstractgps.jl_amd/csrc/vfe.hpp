@@ -33,13 +33,22 @@ struct gp_vfe {
     size_t zs_bytes;
     void *alpha, *meps;  // double [mp]
     size_t vec_bytes;
+    // streaming state kept for update_posterior (new observations, src/sparse_approximations.jl:87-121): the accumulators
+    // of the N-long reductions before the M×M finalisation, and what the chunk loop needs (inv(L_z), scaled z in T)
+    int approx;
+    long n_obs;
+    void *Dacc, *cacc, *Li, *zsT;
+    size_t D_bytes, c_bytes, Li_bytes, zsT_bytes;
+    double logdet_sy, dd, tr_kff, trZ;
 };
 
 template <typename T>
 static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_points* z, const gp_noise* noise,
                             double jitter, const void* mean_or_null, const void* yv, int approx, gp_vfe* out,
-                            double* objective) {
-    const long n = x->n, m = z->n, mp = round_up(m, 128);
+                            double* objective, const gp_vfe* prev = nullptr) {
+    // prev != NULL: continue the streamed reductions of an existing fit with the new observations (x, y) — z, k, jitter
+    // are then taken from prev (z == NULL)
+    const long n = x->n, m = prev ? prev->m : z->n, mp = round_up(m, 128);
     const int d = x->d;
     const long CH = 8192;                       // columns (data points) per streamed chunk
     const long npad = round_up(n, CH);
@@ -57,10 +66,11 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     // ---- host marshalling
     std::vector<T> xs_h, zsT_h;
     scale_points<T>(k, x, npad, xs_h);
-    scale_points<T>(k, z, mp, zsT_h);
+    if (!prev) scale_points<T>(k, z, mp, zsT_h);
+    else zsT_h.assign((size_t)d * mp, T(0));
     std::vector<double> zsD_h(zsT_h.begin(), zsT_h.end());
     std::vector<T> rs_h((size_t)npad, T(0)), b_h((size_t)npad, T(0));  // s_i = σ_i⁻¹ ; b_i = s_i δ_i  (b_y, :66)
-    double logdet_sy = 0, dd = 0, tr_kff = 0;
+    double logdet_sy = prev ? prev->logdet_sy : 0, dd = prev ? prev->dd : 0, tr_kff = prev ? prev->tr_kff : 0;
     for (long i = 0; i < n; ++i) {
         const double s2 = noise->kind == 0 ? noise->s : (double)((const T*)noise->diag)[i];
         if (!(s2 > 0)) return 1 + (int32_t)i;  // chol(Σy) fails at i (reference :61 / :296)
@@ -106,6 +116,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     double scal_h[16] = {0};
     int info_h = 0;
     hipStream_t s = c->sm;
+    const double trZ_prev = prev ? prev->trZ : 0.0;
+    if (prev && prev->D_bytes != D_b) return set_arg_err(1, "stale gp_vfe state");
+    const long n_all = (prev ? prev->n_obs : 0) + n;
 
     int32_t rc = [&]() -> int32_t {
         HIPCHK(hipEventRecord(c->ev_phase[0], s));
@@ -120,6 +133,15 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         HIPCHK(hipMemsetAsync(D_v, 0, D_b, s));
         HIPCHK(hipMemsetAsync(cT_v, 0, vT_b, s));
         HIPCHK(hipMemsetAsync(vec_v, 0, vD_b, s));
+        if (prev) {  // resume: factor of K_zz, its inverse, the scaled inducing inputs and the running sums come from prev
+            HIPCHK(hipMemcpyAsync(Lz_v, prev->Lz, L_b, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(Li_v, prev->Li, Li_b, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(zsT_v, prev->zsT, zsT_b, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(zsD_v, prev->zs, zsD_b, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(D_v, prev->Dacc, D_b, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(cT_v, prev->cacc, vT_b, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(c->scal_dev + 4, &trZ_prev, sizeof(double), hipMemcpyHostToDevice, s));
+        } else {
         // ---- L_z = chol(K_zz + jitter I), fp64                                                    :62
         {
             GridMap g = plain_map(1, 0, 0);
@@ -144,6 +166,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                                (T*)Li_v, (long)mp * ld, 1.0);
             HIPCHK(hipGetLastError());
         }
+        }  // !prev
         HIPCHK(hipEventRecord(c->ev_phase[1], s));
         // ---- streamed pass over the N data points                                                :64-71
         for (long c0 = 0; c0 < npad; c0 += CH) {
@@ -232,16 +255,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         (void)hipStreamSynchronize(c->sp);
     }
     ctx_release(c, xs_v, xs_b);
-    ctx_release(c, zsT_v, zsT_b);
     ctx_release(c, rs_v, rs_b);
     ctx_release(c, b_v, rs_b);
-    ctx_release(c, D_v, D_b);
     ctx_release(c, X_v, X_b);
     ctx_release(c, Y_v, Y_b);
-    ctx_release(c, Li_v, Li_b);
     ctx_release(c, I_v, L_b);
     ctx_release(c, S_v, 4 * Li_b);
-    ctx_release(c, cT_v, vT_b);
     ctx_release(c, jit_v, jit_b);
     if (rc == 0 && info_h != 0) rc = info_h;
     if (rc != 0 || !out) {
@@ -249,12 +268,16 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         ctx_release(c, Ld_v, L_b);
         ctx_release(c, zsD_v, zsD_b);
         ctx_release(c, vec_v, vD_b);
+        ctx_release(c, D_v, D_b);
+        ctx_release(c, cT_v, vT_b);
+        ctx_release(c, Li_v, Li_b);
+        ctx_release(c, zsT_v, zsT_b);
         if (rc != 0) return rc;
     }
     // objective: dtc = -½ (N log2π + logdet Σy + logdet Λ_ε + ‖δ_s‖² − ‖Λ_ε.U⁻ᵀ A δ_s‖²)          :302-303
     //            elbo = dtc − ½ (tr(K_ff Σy⁻¹) − ‖A‖²_F),  ‖A‖²_F = tr(D − I)                      :251
     const double logdet_lam = 2.0 * scal_h[1], trZ = scal_h[4], quad = scal_h[3];  // trZ = ‖B‖²_F = ‖A‖²_F
-    double obj = -0.5 * ((double)n * LOG2PI + logdet_sy + logdet_lam + dd - quad);
+    double obj = -0.5 * ((double)n_all * LOG2PI + logdet_sy + logdet_lam + dd - quad);
     if (approx == 0) obj -= 0.5 * (tr_kff - trZ);
     if (objective) *objective = obj;
     if (out) {
@@ -268,6 +291,13 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         out->alpha = vec + 2 * mp; out->meps = vec + mp; out->vec_bytes = vD_b;
         // keep the base pointer of the vector block for release
         out->alpha = (void*)vec;  // block base; α at +2mp, m_ε at +mp
+        out->approx = approx;
+        out->n_obs = n_all;
+        out->Dacc = D_v; out->D_bytes = D_b;
+        out->cacc = cT_v; out->c_bytes = vT_b;
+        out->Li = Li_v; out->Li_bytes = Li_b;
+        out->zsT = zsT_v; out->zsT_bytes = zsT_b;
+        out->logdet_sy = logdet_sy; out->dd = dd; out->tr_kff = tr_kff; out->trZ = trZ;
     }
     return 0;
 }

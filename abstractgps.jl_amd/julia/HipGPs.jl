@@ -363,4 +363,24 @@ Statistics.var(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 2
 StatsBase.mean_and_var(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 3)      # :212-217
 AbstractGPs.inducing_points(f::HipApproxPosteriorGP) = f.approx.fz.x                            # :219
 
+# update_posterior with new observations, same pseudo-points (src/sparse_approximations.jl:87-121)
+function AbstractGPs.update_posterior(f::HipApproxPosteriorGP, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
+    @assert f.prior === fx.f
+    xbuf, cx, T = points(fx.x)
+    nz = noise(fx.Σy, T)
+    nz === nothing && throw(ArgumentError("dense Σy is not accelerated"))
+    m2 = prior_mean(f.prior.gp, fx.x, T)
+    yv = Vector{T}(y)
+    obj = Ref{T}(zero(T))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve xbuf nz m2 yv begin
+        check(ccall((:gp_vfe_update, libgpmi355), Int32,
+            (Ptr{Cvoid}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{T}),
+            f.handle[], cx, nz[2], m2 === nothing ? C_NULL : pointer(m2), yv, h, obj))
+    end
+    p = HipApproxPosteriorGP(f.approx, f.prior, h, T)
+    finalizer(hh -> ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), hh[]), p.handle)
+    return p
+end
+
 end # module

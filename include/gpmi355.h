@@ -174,6 +174,11 @@ int32_t gp_posterior_free(gp_post* post); /* NULL or already-freed handle: retur
 int32_t gp_vfe_fit(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_points* z,
                    const gp_noise* noise, double jitter, const void* mean_or_null, const void* y,
                    int32_t approx, gp_vfe** out, void* objective_out_or_null);
+/* update_posterior(f_post_approx, fx, y) with the same pseudo-points (src/sparse_approximations.jl:87-121): the streamed
+ * reductions of `old` (B Bᵀ, B b_y, ‖B‖²_F, the Σy terms) are continued with the new observations and the M×M side is
+ * re-finalised — equal to refitting on all observations.  objective_out: ELBO / DTC evidence of all observations. */
+int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, const void* mean2_or_null, const void* y2,
+                      gp_vfe** out, void* objective_out_or_null);
 /* mean_and_var / mean (src/sparse_approximations.jl:183-217).  what: bit0 mean, bit1 var. */
 int32_t gp_vfe_predict(gp_vfe* post, const gp_points* xs, const void* prior_mean_xs_or_null, int32_t what,
                        void* mean_out, void* var_out);

@@ -332,3 +332,40 @@ def test_float32_gradient_update_and_rand(agp):
     smp = agp.rand(f(agp.RowVecs(X32), np.float32(0.1)), 2, xi=xi)
     assert smp.dtype == np.float32
     np.testing.assert_allclose(smp, o.rand_from(ofx, xi.astype(np.float64)), atol=5e-3)
+
+
+@pytest.mark.parametrize("dtc", [False, True])
+def test_vfe_update_posterior_matches_batch(agp, dtc):
+    """update_posterior(f_post_approx, fx2, y2) ≡ posterior(vfe, f([x; x2]), [y; y2]) and pseudo-point appends ≡ a fit with
+    vcat(z_old, z_new) — reference test/sparse_approximations.jl:32-84 — also against the oracle's batch fit."""
+    rng = np.random.default_rng(17)
+    n1, n2, m, d = 700, 333, 40, 2
+    X = rng.uniform(-2, 2, (n1 + n2, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n1 + n2)
+    z = rng.uniform(-2, 2, (m, d))
+    z2 = rng.uniform(-2, 2, (7, d))
+    f = agp.GP(0.1, 0.9 * agp.Matern52Kernel() @ agp.ScaleTransform(1.1))
+    A = agp.DTC if dtc else agp.VFE
+    appr = A(f(agp.RowVecs(z), 1e-9))
+    p1 = agp.posterior(appr, f(agp.RowVecs(X[:n1]), 0.07), y[:n1])
+    p12 = agp.update_posterior(p1, f(agp.RowVecs(X[n1:]), 0.07), y[n1:])
+    pb = agp.posterior(appr, f(agp.RowVecs(X), 0.07), y)
+    assert float(p12.objective) == pytest.approx(float(pb.objective), rel=1e-9)
+    np.testing.assert_allclose(p12.data["alpha"], pb.data["alpha"], rtol=0, atol=1e-7 * np.abs(pb.data["alpha"]).max())
+    xs = rng.uniform(-2, 2, (11, d))
+    m1, v1 = p12.mean_and_var(agp.RowVecs(xs))
+    m2, v2 = pb.mean_and_var(agp.RowVecs(xs))
+    np.testing.assert_allclose(m1, m2, atol=1e-8)
+    np.testing.assert_allclose(v1, v2, atol=1e-9)
+    of = o.GP(o.Kernel(o.MATERN52, 0.9, 1.1), 0.1)
+    op = o.vfe_posterior(of, z, 1e-9, o.FiniteGP(of, X, 0.07), y)
+    mo, vo = op.mean_and_var(xs)
+    np.testing.assert_allclose(m1, mo, atol=1e-7)
+    np.testing.assert_allclose(v1, vo, atol=1e-8)
+    # pseudo-point append
+    pz = agp.update_posterior(p12, f(agp.RowVecs(z2), 1e-9))
+    opz = o.vfe_posterior(of, np.concatenate([z, z2]), 1e-9, o.FiniteGP(of, X, 0.07), y)
+    mz, vz = pz.mean_and_var(agp.RowVecs(xs))
+    moz, voz = opz.mean_and_var(xs)
+    np.testing.assert_allclose(mz, moz, atol=1e-7)
+    np.testing.assert_allclose(vz, voz, atol=1e-8)
