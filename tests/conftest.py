@@ -34,6 +34,12 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def agp():
+    # the .so is a build artefact (git-ignored): cross-compile it for gfx950 if this checkout has not been built yet
+    lib = ROOT / "abstractgps.jl_amd" / "csrc" / "libgpmi355.so"
+    if not lib.exists():
+        import __graft_entry__
+
+        __graft_entry__.build()
     import abstractgps_jl_amd as m
 
     return m
