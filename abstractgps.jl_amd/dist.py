@@ -55,6 +55,7 @@ class HipTileBackend:
         self.ctx = Context(device, stream=self.stream.cuda_stream)
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
+        self._timing = False
 
     @staticmethod
     def _p(t: Optional[torch.Tensor]):
@@ -88,8 +89,12 @@ class HipTileBackend:
 
     def gemm_nt(self, c, ldc, a, lda, b, ldb, m, n, k, grid, row0, col0):
         g = self._lib.gp_grid(*grid)
+        if self._timing:  # only the trailing-update launches are timed (their algorithmic flops are counted by the driver)
+            self.ctx.set_param("time_kernels", 1)
         self._lib.check(self.lib.gpd_gemm_nt(self.h, self._p(c), ldc, self._p(a), lda, self._p(b), ldb, m, n, k,
                                              C.byref(g), row0, col0))
+        if self._timing:
+            self.ctx.set_param("time_kernels", 0)
 
     def trsv(self, l, ldl, np_, r, ldr, nrhs, forward):
         self._lib.check(self.lib.gpd_trsv(self.h, self._p(l), ldl, np_, self._p(r), ldr, nrhs, 1 if forward else 0))
@@ -105,7 +110,7 @@ class HipTileBackend:
         torch.cuda.synchronize(self.device)
 
     def time_kernels(self, on: bool):
-        self.ctx.set_param("time_kernels", 1 if on else 0)
+        self._timing = bool(on)
 
     def gemm_time(self):
         """(Σ ms, launches) of the MFMA update launches since the last call (needs time_kernels)."""
