@@ -522,9 +522,9 @@ template <typename T> __device__ __forceinline__ T kappa(int kind, T d2) {
     return (T(1) + a + T(5.0 / 3.0) * d2) * exp(-a);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
-                                                    const T* __restrict__ xc, long ldxc, int d, int kind, T variance,
+template <typename T, int KIND>
+__device__ __forceinline__ void kmat_body(T (*xi)[128], T (*xj)[128], T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
+                                                    const T* __restrict__ xc, long ldxc, int d, T variance,
                                                     const T* __restrict__ noise, long nr_valid, long nc_valid, int sym,
                                                     GridMap g, const T* __restrict__ colscale,
                                                     const T* __restrict__ rowscale) {
@@ -535,8 +535,6 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
     const long gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
     if (g.lower && gc0 > gr0 + 127) return;
 
-    __shared__ T xi[DC][128];
-    __shared__ __attribute__((aligned(16))) T xj[DC][128];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     T acc0[32], acc1[32];
@@ -564,6 +562,17 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
         }
     }
     const long gj0 = gc0 + 2 * lane, gj1 = gj0 + 1;
+    // interior tiles (no padding, not on the diagonal, no row/column scaling): nothing but κ and the 1 KiB row stores
+    if (gr0 + 128 <= nr_valid && gc0 + 128 <= nc_valid && !(sym && gr0 == gc0) && colscale == nullptr && rowscale == nullptr) {
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr) {
+            pair_t o;
+            o.x = variance * kappa<T>(KIND, acc0[rr]);
+            o.y = variance * kappa<T>(KIND, acc1[rr]);
+            *reinterpret_cast<pair_t*>(out + (long)(m0 + w + 4 * rr) * ld + n0 + 2 * lane) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int rr = 0; rr < 32; ++rr) {
         const int row = w + 4 * rr;
@@ -573,8 +582,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
             v0 = (sym && gi == gj0) ? T(1) : T(0);
             v1 = (sym && gi == gj1) ? T(1) : T(0);
         } else {
-            v0 = (gj0 < nc_valid) ? variance * kappa<T>(kind, acc0[rr]) : T(0);
-            v1 = (gj1 < nc_valid) ? variance * kappa<T>(kind, acc1[rr]) : T(0);
+            v0 = (gj0 < nc_valid) ? variance * kappa<T>(KIND, acc0[rr]) : T(0);
+            v1 = (gj1 < nc_valid) ? variance * kappa<T>(KIND, acc1[rr]) : T(0);
             if (sym && noise != nullptr) {
                 if (gi == gj0) v0 += noise[gi];
                 if (gi == gj1) v1 += noise[gi];
@@ -593,6 +602,23 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
         o.x = v0;
         o.y = v1;
         *reinterpret_cast<pair_t*>(out + (long)(m0 + row) * ld + n0 + 2 * lane) = o;
+    }
+}
+
+// runtime kernel kind -> compile-time specialisation (the κ branch is hoisted out of the 64-element inner loops)
+template <typename T>
+__global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
+                                                    const T* __restrict__ xc, long ldxc, int d, int kind, T variance,
+                                                    const T* __restrict__ noise, long nr_valid, long nc_valid, int sym,
+                                                    GridMap g, const T* __restrict__ colscale,
+                                                    const T* __restrict__ rowscale) {
+    __shared__ T xi[16][128];
+    __shared__ __attribute__((aligned(16))) T xj[16][128];
+    switch (kind) {
+        case 0: kmat_body<T, 0>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        case 1: kmat_body<T, 1>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        case 2: kmat_body<T, 2>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        default: kmat_body<T, 3>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
     }
 }
 
