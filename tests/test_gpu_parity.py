@@ -369,3 +369,18 @@ def test_vfe_update_posterior_matches_batch(agp, dtc):
     moz, voz = opz.mean_and_var(xs)
     np.testing.assert_allclose(mz, moz, atol=1e-7)
     np.testing.assert_allclose(vz, voz, atol=1e-8)
+
+
+def test_multi_panel_parity_8192(agp):
+    """N = 8 192 (four 2 048-column panels, look-ahead, recursion depth 5, RHS block row) against the oracle's LAPACK path."""
+    x, y = o.synth_inputs(8192, 3, 12)
+    f = agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(1.2))
+    post = agp.posterior(f(agp.RowVecs(x), 0.01), y)
+    lp, opost = o.logpdf_and_posterior(o.FiniteGP(o.GP(o.Kernel(o.SE, 1.0, 1.2)), x, 0.01), y)
+    assert float(post.logpdf_value) == pytest.approx(lp, rel=1e-10)
+    assert _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+    xs = x[:64] + 0.03
+    m, v = post.mean_and_var(agp.RowVecs(xs))
+    mo, vo = opost.mean_and_var(xs)
+    np.testing.assert_allclose(m, mo, atol=1e-8)
+    np.testing.assert_allclose(v, vo, atol=1e-9)
