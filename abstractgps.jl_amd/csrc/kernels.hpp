@@ -867,7 +867,7 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
 //     block TRSM   B_ij ← B_ij · Inv_jᵀ          (tile rows below the block and the workgroup's X rows)
 //     block update B_ik ← B_ik − B_ij · B_kjᵀ     (k > j)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int XR = 128>  // XR: rows of X per workgroup (128; 64 keeps the LDS footprint at 75 KB)
 __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
                                                        int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket) {
     using TR = Tr<T>;
@@ -876,14 +876,14 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     constexpr int VEC = TR::VEC;
     constexpr int LD = 65, LI = 17;
     __shared__ T Ds[64 * LD];
-    __shared__ T Xs[128 * LD];
+    __shared__ T Xs[XR * LD];
     __shared__ T Inv[4][16 * LI];
     __shared__ int writer_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    int xrows = mrows - (int)blockIdx.x * 128;
-    xrows = xrows < 0 ? 0 : (xrows > 128 ? 128 : xrows);
-    T* const Xg = A + (long)(64 + (long)blockIdx.x * 128) * lda;
+    int xrows = mrows - (int)blockIdx.x * XR;
+    xrows = xrows < 0 ? 0 : (xrows > XR ? XR : xrows);
+    T* const Xg = A + (long)(64 + (long)blockIdx.x * XR) * lda;
 
     for (int e = tid; e < 64 * (64 / VEC); e += 256) {
         const int row = e / (64 / VEC), cc = e % (64 / VEC);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
 #pragma unroll
         for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = v[q];
     }
-    for (int e = tid; e < 128 * (64 / VEC); e += 256) {
+    for (int e = tid; e < XR * (64 / VEC); e += 256) {
         const int row = e / (64 / VEC), cc = e % (64 / VEC);
         chunk_t v;
 #pragma unroll
