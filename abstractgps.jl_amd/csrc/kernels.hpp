@@ -18,6 +18,9 @@
 #ifndef GPMI_GEMM_SCHED
 #define GPMI_GEMM_SCHED 1  // explicit MFMA / LDS interleave of the gemm k loop (sched_group_barrier)
 #endif
+#ifndef GPMI_POTF2_LDS
+#define GPMI_POTF2_LDS 1  // panel64: multipliers of the 16×16 block factorisation by LDS broadcast (0: v_readlane)
+#endif
 #ifndef GPMI_ABL
 #define GPMI_ABL 0  // ablation switches of tools/gemm_ablate.hip (timing experiments only; 0 in the product build)
 #endif
@@ -878,29 +881,53 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     __shared__ T Ds[64 * LD];
     __shared__ T Xs[XR * LD];
     __shared__ T Inv[4][16 * LI];
+    __shared__ T Lc[16 * LI];  // columns of the 16×16 block being factored (GPMI_POTF2_LDS)
     __shared__ int writer_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef GPMI_PANEL_STAMPS
+    long stamps[16];
+    int nst = 0;
+#define PSTAMP() do { if (nst < 16) stamps[nst++] = (long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PSTAMP() do { } while (0)
+#endif
+    PSTAMP();
     const int li = lane & 15, lg = lane >> 4;
     int xrows = mrows - (int)blockIdx.x * XR;
     xrows = xrows < 0 ? 0 : (xrows > XR ? XR : xrows);
     T* const Xg = A + (long)(64 + (long)blockIdx.x * XR) * lda;
 
-    for (int e = tid; e < 64 * (64 / VEC); e += 256) {
-        const int row = e / (64 / VEC), cc = e % (64 / VEC);
-        const chunk_t v = *reinterpret_cast<const chunk_t*>(A + (long)row * lda + cc * VEC);
+    {  // all global loads of the tile and of the X slab are issued before the first LDS store (one memory round trip)
+        constexpr int CPR = 64 / VEC;              // 16-B chunks per 64-column row
+        constexpr int ND = 64 * CPR / 256, NX = XR * CPR / 256;
+        chunk_t dv[ND], xv[NX];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = v[q];
-    }
-    for (int e = tid; e < XR * (64 / VEC); e += 256) {
-        const int row = e / (64 / VEC), cc = e % (64 / VEC);
-        chunk_t v;
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+            dv[i] = *reinterpret_cast<const chunk_t*>(A + (long)row * lda + cc * VEC);
+        }
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) v[q] = T(0);
-        if (row < xrows) v = *reinterpret_cast<const chunk_t*>(Xg + (long)row * lda + cc * VEC);
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = v[q];
+            for (int q = 0; q < VEC; ++q) xv[i][q] = T(0);
+            if (row < xrows) xv[i] = *reinterpret_cast<const chunk_t*>(Xg + (long)row * lda + cc * VEC);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = dv[i][q];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = xv[i][q];
+        }
     }
     __syncthreads();  // every load of the input tile by this workgroup has completed (values are in LDS)
+    PSTAMP();
     if (tid == 0) writer_s = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
 
     int bad = 0;
@@ -920,6 +947,48 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (w == 0) {  // 16×16 diagonal block: L16 and inv(L16)
+#if GPMI_POTF2_LDS
+            // lane = row (factor) and lane = column (inverse); the finished column c is published in LDS (Lc[c][·]) and
+            // every multiplier L[t][c] / L[c][k] is an LDS broadcast read — ~10 instructions per column instead of
+            // ~30 v_readlane pairs; only the pivot travels by readlane
+            T a[16], x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = Ds[(16 * j + li) * LD + 16 * j + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const T piv = lane_bcast<T>(a[c], c);
+                if (!(piv > T(0)) && bad == 0) bad = 16 * j + c + 1;
+                const T ri = fast_rsqrt<T>(piv);
+                const T dd = piv * ri;
+                const T v = (li == c) ? dd : a[c] * ri;
+                a[c] = v;
+                if (li == c) mydiag[j] = dd;
+                Lc[c * LI + li] = v;  // column c of L16 (rows >= c valid)
+                // the next pivot only needs a[c+1]: its multiplier travels by readlane (short critical path), the rest
+                // of the row update and the inverse read the published column from LDS
+                if (c + 1 < 16) a[c + 1] = fma(-v, lane_bcast<T>(v, c + 1 < 16 ? c + 1 : 15), a[c + 1]);
+                T s0 = (li == c) ? T(1) : T(0), s1 = T(0);
+#ifndef GPMI_EXP_NOINV
+#pragma unroll
+                for (int k = 0; k < c; ++k) {  // L[c][k], k < c; two partial sums halve the dependent FMA chain
+                    if (k & 1) s1 = fma(-Lc[k * LI + c], x[k], s1);
+                    else s0 = fma(-Lc[k * LI + c], x[k], s0);
+                }
+#endif
+                x[c] = (s0 + s1) * ri;
+#ifndef GPMI_EXP_NOUPD
+#pragma unroll
+                for (int t = c + 2; t < 16; ++t) a[t] = fma(-v, Lc[c * LI + t], a[t]);  // L[t][c]
+#endif
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c <= li) Ds[(16 * j + li) * LD + 16 * j + c] = a[c];
+                    Inv[j][c * LI + li] = x[c];
+                }
+            }
+#else
             T a[16], x[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = Ds[(16 * j + li) * LD + 16 * j + c];
@@ -946,8 +1015,10 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
                     Inv[j][c * LI + li] = x[c];
                 }
             }
+#endif
         }
         __syncthreads();
+        PSTAMP();
         // block TRSM: tasks 0..2-j: tile blocks (j+1+q, j); then the X row tiles
         {
             const int ntile = 3 - j;
@@ -962,6 +1033,7 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
             }
         }
         __syncthreads();
+        PSTAMP();
         // block updates: tile pairs (i, k), j < k <= i <= 3, then (X row tile, k), k = j+1..3
         if (j < 3) {
             const int nk = 3 - j;
@@ -997,14 +1069,17 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
         }
     }
 
+    PSTAMP();
     // write back
+#pragma unroll 8
     for (int e = tid; e < xrows * 64; e += 256) {
         const int row = e >> 6, c = e & 63;
         Xg[(long)row * lda + c] = Xs[row * LD + c];
     }
     if (writer_s) {  // (the barriers of the block loop made writer_s visible)
-        for (int e = tid; e < 64 * 64; e += 256) {
-            const int row = e >> 6, c = e & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i, row = e >> 6, c = e & 63;
             if (c <= row) A[(long)row * lda + c] = Ds[row * LD + c];
         }
         if (w == 0) {
@@ -1021,6 +1096,14 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
             }
         }
     }
+#ifdef GPMI_PANEL_STAMPS
+    PSTAMP();
+    if (blockIdx.x == 0 && tid == 0 && logdet_acc) {
+        long* dst = reinterpret_cast<long*>(logdet_acc) + 8;
+        for (int i = 0; i < 16; ++i) dst[i] = i < nst ? stamps[i] - stamps[0] : 0;
+    }
+#endif
+#undef PSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1045,20 +1128,34 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(T* __restrict__ X, lon
     int xrows = M - (int)blockIdx.x * 128;
     xrows = xrows > 128 ? 128 : xrows;
     T* const Xg = X + (long)blockIdx.x * 128 * ldx;
-    for (int e = tid; e < 64 * (64 / VEC); e += 256) {
-        const int row = e / (64 / VEC), cc = e % (64 / VEC);
-        const chunk_t v = *reinterpret_cast<const chunk_t*>(L + (long)row * ldl + cc * VEC);
+    {  // all global loads first, then the LDS stores (one memory round trip)
+        constexpr int CPR = 64 / VEC;
+        constexpr int ND = 64 * CPR / 256, NX = 128 * CPR / 256;
+        chunk_t dv[ND], xv[NX];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = v[q];
-    }
-    for (int e = tid; e < 128 * (64 / VEC); e += 256) {
-        const int row = e / (64 / VEC), cc = e % (64 / VEC);
-        chunk_t v;
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+            dv[i] = *reinterpret_cast<const chunk_t*>(L + (long)row * ldl + cc * VEC);
+        }
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) v[q] = T(0);
-        if (row < xrows) v = *reinterpret_cast<const chunk_t*>(Xg + (long)row * ldx + cc * VEC);
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = v[q];
+            for (int q = 0; q < VEC; ++q) xv[i][q] = T(0);
+            if (row < xrows) xv[i] = *reinterpret_cast<const chunk_t*>(Xg + (long)row * ldx + cc * VEC);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = dv[i][q];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = xv[i][q];
+        }
     }
     __syncthreads();
     {  // wave w inverts diagonal block w: lane c (< 16) owns column c of inv(L16); x[r] = Inv[r][c]
@@ -1115,6 +1212,7 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(T* __restrict__ X, lon
             __syncthreads();
         }
     }
+#pragma unroll 8
     for (int e = tid; e < xrows * 64; e += 256) {
         const int row = e >> 6, c = e & 63;
         Xg[(long)row * ldx + c] = Xs[row * LD + c];
