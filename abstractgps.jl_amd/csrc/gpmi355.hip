@@ -72,6 +72,9 @@ struct gp_ctx {
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
     int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
     int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
+    long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
+                           // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
+    bool gemm_pad_set = false;
     int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;
@@ -249,9 +252,17 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
-        else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value)
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M, (int)N,
-                               (int)K, g);
+        else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
+            if (c->gemm_pad_lds > 0 && !c->gemm_pad_set) {
+                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+                c->gemm_pad_set = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), (size_t)c->gemm_pad_lds, s, C, ldc, A, lda, B, ldb,
+                               (int)M, (int)N, (int)K, g);
+        }
         else
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, false, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
@@ -1164,6 +1175,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "sched")) c->sched = (int)v;
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
+    else if (!strcmp(name, "gemm_pad_lds")) c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;

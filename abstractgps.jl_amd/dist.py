@@ -56,6 +56,10 @@ class HipTileBackend:
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
         self._timing = False
+        # ("gemm_pad_lds" = 20480 would pin the GEMM to one workgroup per CU and leave room for the RCCL kernels of the
+        # look-ahead; on one GPU that costs 4-7 % of the whole factorisation, so it stays off until measured on a node.)
+        if os.environ.get("GPMI_DIST_GEMM_PAD"):
+            self.ctx.set_param("gemm_pad_lds", int(os.environ["GPMI_DIST_GEMM_PAD"]))
 
     @staticmethod
     def _p(t: Optional[torch.Tensor]):

@@ -103,6 +103,8 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "trsm_leaf_mfma" MFMA TRSM leaf (1) or VALU leaf (0)                                  default 1
  *   "trsm_mfma"      all-MFMA blocked TRSM through I − inv(L_jj) tiles                    default 0
  *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
+ *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (same speed on one large
+ *                    launch, 4-7 % slower over a whole factorisation; leaves room for concurrent kernels)   default 0
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 int32_t gp_get_timings(gp_ctx* ctx, gp_timings* out);
