@@ -72,6 +72,9 @@ struct gp_ctx {
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
     int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
     int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
+    int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
+                           // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
+    int num_cus = 256;
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
     bool gemm_pad_set = false;
@@ -252,7 +255,19 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
-        else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
+        else if (c->gemm_streamk && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
+                 g.P == 1 && g.Q == 1 && g.compact <= 1) {
+            // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
+            const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
+            const long ntiles = g.compact == 1 ? (long)grid.x : tm * tn;
+            const long Gmax = 2L * c->num_cus;
+            const long G = std::max(1L, std::min(Gmax, ntiles));
+            const long R = ntiles - (ntiles / G) * G;
+            long G2 = std::min(G, std::max(1L, R * nk / 16));  // at least 16 k-steps per tail share
+            if (R == 0) G2 = 0;
+            hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                               (int)K, g, ntiles, (int)G2);
+        } else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
             if (c->gemm_pad_lds > 0 && !c->gemm_pad_set) {
                 HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
@@ -1125,6 +1140,10 @@ int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null) {
         }
         c->own_sm = true;
     }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     hipError_t e = hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, hi);
@@ -1175,6 +1194,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "sched")) c->sched = (int)v;
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
+    else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
     else if (!strcmp(name, "gemm_pad_lds")) c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;

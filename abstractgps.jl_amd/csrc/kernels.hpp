@@ -486,6 +486,174 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_sk: gemm_nt_dma with a persistent grid and a stream-K tail (single-GPU maps only: plain rectangle or the
+//   compact lower trapezoid).  G workgroups (2 per CU).  Whole "rounds" of G tiles are processed tile-parallel exactly
+//   as before (workgroup w takes tiles w, w+G, ...: neighbouring workgroups share operand panels in L2); the last,
+//   partial round — R < G tiles, which used to leave G−R workgroup slots idle for a whole tile time — is cut along k:
+//   its R·nk k-steps are dealt out evenly to G2 workgroups, each accumulating its share of one (or two) tiles from zero
+//   and adding it to C with hardware fp64/fp32 atomics.  Tiles of complete rounds never see atomics.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_sk_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M, int N,
+                                                             int K, GridMap g, long ntiles, int G2) {
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    using acc_t = typename TR::acc_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int BK = 8 * VEC;
+    __shared__ __attribute__((aligned(1024))) chunk_t As[2][128 * 8];
+    __shared__ __attribute__((aligned(1024))) chunk_t Bs[2][128 * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int drow = lane >> 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const int sw = (li >> 1) & 7;
+    const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
+    const unsigned ldsA = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&As[0][0];
+    const unsigned ldsB = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&Bs[0][0];
+    auto dma1 = [&](const T* src, unsigned dst) {
+        unsigned keep;
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(d)
+                     : "memory");
+    };
+    auto dma_wait_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int nk = K / BK;
+    const long G = gridDim.x;
+    const long full = (ntiles / G) * G;          // tiles of complete rounds
+    const long R = ntiles - full;                // tail tiles, cut along k
+    const long tail_units = R * nk;
+    long tu0 = 0, tu1 = 0;                       // my share of the tail's k-steps
+    if ((long)blockIdx.x < G2) {
+        tu0 = (long)blockIdx.x * tail_units / G2;
+        tu1 = ((long)blockIdx.x + 1) * tail_units / G2;
+    }
+    long next_full = blockIdx.x;                 // next whole tile of mine
+    while (true) {
+        long tile;
+        int k0, k1;
+        if (next_full < full) {
+            tile = next_full;
+            k0 = 0;
+            k1 = nk;
+            next_full += G;
+        } else if (tu0 < tu1) {
+            const long t = tu0 / nk;
+            tile = full + t;
+            k0 = (int)(tu0 - t * nk);
+            const long left = tu1 - tu0;
+            k1 = (left < (long)(nk - k0)) ? k0 + (int)left : nk;
+            tu0 += k1 - k0;
+        } else {
+            break;
+        }
+        const bool complete = (k0 == 0 && k1 == nk);
+        int bi, bj;
+        if (g.compact == 1) compact_tile(g, (int)tile, bi, bj);
+        else {
+            bi = (int)(tile / g.tn);
+            bj = (int)(tile - (long)bi * g.tn);
+        }
+        const int m0 = bi * 128, n0 = bj * 128;
+        const long gr0 = g.row0 + m0, gc0 = g.col0 + n0;
+        if (g.lower && gc0 > gr0 + 127) continue;  // tile above the diagonal (workgroup-uniform)
+        bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
+        if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
+        const T* Ag[4];
+        const T* Bg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * (4 * i + w) + drow;
+            const int cch = (lane & 7) ^ ((r >> 1) & 7);
+            Ag[i] = A + (long)(m0 + r) * lda + cch * VEC;
+            Bg[i] = B + (long)(n0 + r) * ldb + cch * VEC;
+        }
+        auto dma = [&](int buf, long kt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+                dma1(Bg[i] + kt * BK, ldsB + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+            }
+        };
+        acc_t acc[4][4];
+        T* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
+        const T* const Cr = active ? Cw : C + li;
+        dma(0, k0);
+        if (complete) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][nt][r] = T(0);
+        }
+        dma_wait_barrier();
+        for (int kt = k0; kt < k1; ++kt) {
+            const int cur = (kt - k0) & 1;
+            dma(cur ^ 1, (kt + 1 < k1) ? kt + 1 : kt);
+            chunk_t a[2][4], b[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = (4 * h + lg) ^ sw;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[h][t] = As[cur][fa + t * 128 + sl];
+                    b[h][t] = Bs[cur][fb + t * 128 + sl];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[h][mt][v], b[h][nt][v], acc[mt][nt]);
+#if GPMI_GEMM_SCHED
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC - 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC + 8, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            dma_wait_barrier();
+        }
+        if (active) {
+            if (complete) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = -acc[mt][nt][r];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            unsafeAtomicAdd(&Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16], -acc[mt][nt][r]);
+            }
+        }
+    }
+}
+
 // Debug reference (gemm_variant = 1): same contract, plain VALU, one thread per C element.
 template <typename T, bool KM, typename CT = T>
 __global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,

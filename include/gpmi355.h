@@ -103,6 +103,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "trsm_leaf_mfma" MFMA TRSM leaf (1) or VALU leaf (0)                                  default 1
  *   "trsm_mfma"      all-MFMA blocked TRSM through I − inv(L_jj) tiles                    default 0
  *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
+ *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail (gemm_nt_sk_kernel)           default 0
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (same speed on one large
  *                    launch, 4-7 % slower over a whole factorisation; leaves room for concurrent kernels)   default 0
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32 */
