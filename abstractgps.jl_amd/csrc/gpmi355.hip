@@ -75,6 +75,8 @@ struct gp_ctx {
     int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
                            // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
     int num_cus = 256;
+    int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there
+                           // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
     bool gemm_pad_set = false;
@@ -103,6 +105,12 @@ struct gp_ctx {
     long scal_cap = 0;
     int refs = 1;
     bool dead = false;
+};
+
+struct SkScope {
+    gp_ctx* c;
+    explicit SkScope(gp_ctx* c_) : c(c_) { ++c->sk_scope; }
+    ~SkScope() { --c->sk_scope; }
 };
 
 static std::mutex g_reg_mu;
@@ -255,15 +263,16 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
-        else if (c->gemm_streamk && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
+        else if ((c->gemm_streamk || c->sk_scope > 0) && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
                  g.P == 1 && g.Q == 1 && g.compact <= 1) {
             // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
             const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
             const long ntiles = g.compact == 1 ? (long)grid.x : tm * tn;
             const long Gmax = 2L * c->num_cus;
-            const long G = std::max(1L, std::min(Gmax, ntiles));
+            const long G = Gmax;  // fewer tiles than workgroups: every tile is cut along k
             const long R = ntiles - (ntiles / G) * G;
-            long G2 = std::min(G, std::max(1L, R * nk / 16));  // at least 16 k-steps per tail share
+            // tail shares: never fewer workgroups than tail tiles; beyond that at least 16 k-steps per share
+            long G2 = std::min(G, std::max(R, R * nk / 16));
             if (R == 0) G2 = 0;
             hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g, ntiles, (int)G2);
@@ -789,6 +798,7 @@ template <typename T>
 static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, int what, void* mean_out,
                             void* var_out, void* cov_out) {
     gp_ctx* c = post->ctx;
+    SkScope sk(c);
     const long n = post->n, np = post->np, ld = post->ld;
     const long ns = xs->n, nsp = round_up(ns, 128);
     const int d = post->d;
@@ -892,6 +902,7 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     FitOut fo;
     std::vector<T> alpha_h((size_t)n);
     RC(fit_impl<T>(c, k, x, noise, mean, y, n, 1, fo, &post, alpha_h.data()));
+    SkScope sk(c);
     const long np = post.np, ld = post.ld;
     hipStream_t s = c->sm;
     void *W_v = 0, *Ci_v = 0, *g_v = 0, *dn_v = 0, *sc_v = 0;
@@ -979,6 +990,7 @@ static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* no
     gp_kernel k{};
     k.kind = old->kind; k.dtype = old->dtype; k.variance = old->variance; k.nscale = old->nscale;
     k.scale = old->scale.empty() ? nullptr : old->scale.data();
+    SkScope sk(c);
     hipStream_t s = c->sm;
     c->ev_used = 0;
     c->gemm_recs.clear();
