@@ -75,6 +75,7 @@ struct gp_ctx {
     int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
                            // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
     int num_cus = 256;
+    int sk_u1 = 0;         // stream-K for the U1 update of the look-ahead schedule (measured: no effect)
     int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there
                            // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
@@ -535,9 +536,15 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
         }
         if (k1 >= np) break;  // RHS rows were already solved inside potrf_rec
         const long nb1 = std::min(nb, np - k1);
-        // U1: next panel's columns, all rows below
-        RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, mtot - k1,
-                          nb1, nbk, plain_map(1, k1, k1)));
+        // U1: next panel's columns, all rows below.  Nothing can run beside it (the panel waits for it, U2 is queued behind
+        // it), so its tail is not filled by another stream: stream-K variant (sk_u1)
+        {
+            if (c->sk_u1) ++c->sk_scope;
+            const int32_t rc_u1 = launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda,
+                                                 mtot - k1, nb1, nbk, plain_map(1, k1, k1));
+            if (c->sk_u1) --c->sk_scope;
+            RC(rc_u1);
+        }
         if (la) {
             RC(ctx_event(c, &ev_u1, false));
             HIPCHK(hipEventRecord(ev_u1, c->sm));
@@ -1207,6 +1214,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
+    else if (!strcmp(name, "sk_u1")) c->sk_u1 = v != 0;
     else if (!strcmp(name, "gemm_pad_lds")) c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
