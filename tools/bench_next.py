@@ -9,8 +9,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
 import abstractgps_jl_amd as agp  # noqa: E402
-from oracle import gp_oracle as o  # noqa: E402
+from _synth import synth_inputs  # noqa: E402
 
 
 def t(fn, reps=2):
@@ -24,7 +25,7 @@ def t(fn, reps=2):
 
 
 def main(n=16384, ns=4096):
-    x, y = o.synth_inputs(n, 3, 2)
+    x, y = synth_inputs(n, 3, 2)
     f = agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(0.9))
     fx = f(agp.RowVecs(x), 0.01)
     dt_fit, post = t(lambda: agp.posterior(fx, y), 2)
@@ -32,7 +33,7 @@ def main(n=16384, ns=4096):
     dt_mv, (m, v) = t(lambda: post.mean_and_var(agp.RowVecs(xs)))
     dt_cov, cm = t(lambda: post.cov(agp.RowVecs(xs[:1024])), 1)
     n2 = n // 8
-    x2, y2 = o.synth_inputs(n2, 3, 77)
+    x2, y2 = synth_inputs(n2, 3, 77)
     dt_seq, p2 = t(lambda: agp.posterior(post(agp.RowVecs(x2), 0.01), y2), 1)
     dt_rand, smp = t(lambda: agp.rand(fx, 4, rng=np.random.default_rng(0)), 1)
     dt_grad, (lp, g) = t(lambda: agp.logpdf_and_grad(fx, y), 1)

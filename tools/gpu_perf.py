@@ -9,12 +9,13 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
 import abstractgps_jl_amd as agp  # noqa: E402
-from oracle import gp_oracle as o  # noqa: E402
+from _synth import synth_inputs  # noqa: E402
 
 
 def fit_time(ctx, n, d, nb, la, reps=2, timed=True):
-    x, y = o.synth_inputs(n, d, 4)
+    x, y = synth_inputs(n, d, 4)
     ctx.set_param("nb", nb)
     ctx.set_param("lookahead", la)
     ctx.set_param("time_kernels", 1 if timed else 0)

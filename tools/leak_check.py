@@ -1,8 +1,8 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import abstractgps_jl_amd as agp
-from oracle import gp_oracle as o
-x, y = o.synth_inputs(3000, 3, 1)
+from _synth import synth_inputs
+x, y = synth_inputs(3000, 3, 1)
 f = agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(0.9))
 def once():
     fx = f(agp.RowVecs(x), 0.05)
