@@ -1,0 +1,74 @@
+"""GPU: BASELINE.json's configurations at FULL size, checked through size-independent properties (the oracle cannot be
+run at these sizes inside a test):
+  * normal equations through an independent device path: the posterior mean at training inputs is K α, so
+    mean(post, x_i) = δ_i − σ² α_i   (kvec kernel: Gram rows fused with κ, no factor involved);
+  * the same rows recomputed on the host with NumPy for a handful of points;
+  * predictive variances in [0, k(x,x)], posterior collapses at the training inputs (reference
+    test/exact_gpr_posterior.jl:21-22 with noise);
+  * fp32 VFE (C5) against the SAME engine run in fp64, and ELBO <= ... monotone sanity via DTC >= VFE objective.
+"""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact(agp, n, d, seed, kernel, okernel, sigma2=0.01):
+    x, y = o.synth_inputs(n, d, seed)
+    f = agp.GP(kernel)
+    post = agp.posterior(f(agp.RowVecs(x), sigma2), y)
+    try:
+        alpha = post.data.alpha
+        assert np.all(np.isfinite(alpha)) and np.isfinite(post.logpdf_value)
+        idx = np.linspace(0, n - 1, 256).astype(int)
+        m_tr, v_tr = post.mean_and_var(agp.RowVecs(x[idx]))
+        np.testing.assert_allclose(m_tr, y[idx] - sigma2 * alpha[idx], rtol=0, atol=1e-9)   # K α = δ − σ² α
+        Krows = o.kernelmatrix(okernel, x[idx[:16]], x)                                       # host recomputation
+        np.testing.assert_allclose(Krows @ alpha + sigma2 * alpha[idx[:16]], y[idx[:16]], rtol=0, atol=1e-9)
+        # latent posterior variance at a training input is below the noise level and non-negative
+        assert v_tr.min() > -1e-9 and v_tr.max() <= sigma2 + 1e-9
+        xs = x[:64] + 3.0                                                                      # away from the data
+        _, v_far = post.mean_and_var(agp.RowVecs(xs))
+        assert v_far.min() >= -1e-9 and v_far.max() <= okernel.variance + 1e-9
+    finally:
+        post.data.C.free()
+
+
+def test_c2_full_size(agp):
+    _exact(agp, 16384, 3, 2, agp.SqExponentialKernel(), o.Kernel(o.SE))
+
+
+def test_c3_full_size_scale_and_ard(agp):
+    _exact(agp, 32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5), o.Kernel(o.MATERN32, 1.0, 0.5))
+    v = np.linspace(0.25, 1, 8)
+    _exact(agp, 32768, 8, 3, agp.Matern32Kernel() @ agp.ARDTransform(v), o.Kernel(o.MATERN32, 1.0, v))
+
+
+def test_c4_full_size(agp):
+    _exact(agp, 65536, 3, 4, agp.SqExponentialKernel(), o.Kernel(o.SE))
+
+
+def test_c5_full_size_fp32_vs_fp64(agp):
+    rng = np.random.default_rng(5)
+    n, m, d = 262144, 4096, 3
+    X = rng.uniform(0, 1, (n, d)) * 4
+    y = np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n)
+    z = X[rng.permutation(n)[:m]].copy()
+    xs = rng.uniform(0, 1, (512, d)) * 4
+    f = agp.GP(agp.SqExponentialKernel())
+    X32, y32, z32, xs32 = X.astype(np.float32), y.astype(np.float32), z.astype(np.float32), xs.astype(np.float32)
+    p32 = agp.posterior(agp.VFE(f(agp.RowVecs(z32), 1e-4)), f(agp.RowVecs(X32), np.float32(0.1)), y32)
+    p64 = agp.posterior(agp.VFE(f(agp.RowVecs(z32.astype(np.float64)), 1e-4)), f(agp.RowVecs(X32.astype(np.float64)), 0.1),
+                        y32.astype(np.float64))
+    assert isinstance(p32.objective, np.float32)
+    assert float(p32.objective) == pytest.approx(float(p64.objective), rel=1e-4)       # ELBO rel <= 1e-4
+    m32, v32 = p32.mean_and_var(agp.RowVecs(xs32))
+    m64, v64 = p64.mean_and_var(agp.RowVecs(xs32.astype(np.float64)))
+    np.testing.assert_allclose(m32, m64, atol=1e-3)                                      # mean abs <= 1e-3
+    np.testing.assert_allclose(v32, v64, atol=1e-3)
+    assert v64.min() > 0
+    dtc = agp.approx_log_evidence(agp.DTC(f(agp.RowVecs(z32.astype(np.float64)), 1e-4)), f(agp.RowVecs(X32.astype(np.float64)), 0.1),
+                                  y32.astype(np.float64))
+    assert float(dtc) >= float(p64.objective)                                            # ELBO = DTC − ½·trace term, trace >= 0
