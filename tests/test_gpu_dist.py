@@ -57,7 +57,8 @@ def _worker(rank, world, port, grid, n, d, nb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,grid,n,nb", [(2, (1, 2), 1500, 256), (2, (2, 1), 1100, 128), (4, (2, 2), 2100, 256)])
+@pytest.mark.parametrize("world,grid,n,nb", [(2, (1, 2), 1500, 256), (2, (2, 1), 1100, 128), (4, (2, 2), 2100, 256),
+                                            (8, (2, 4), 2600, 128)])
 def test_virtual_ranks_on_one_gpu(world, grid, n, nb):
     import torch.multiprocessing as mp
 
