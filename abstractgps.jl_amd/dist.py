@@ -228,9 +228,11 @@ class BlockCyclicEngine:
 
         max_rows = nlb_r * NB + RHS_ROWS
         # two sets of panel buffers: panel k+1 is factored and travels while the bulk of update k still runs
-        Pbufs = [[be.empty(max_rows, NB) for _ in range(P)] for _ in range(2)]
-        Bbuf = be.empty(n_loc + 128, NB)                      # B operand gathered in my local column order
-        Lkk = be.empty(NB, NB)
+        # operand buffers carry 32 padding columns: a power-of-two row stride (NB·8 B) would alias HBM channels
+        LDP = NB + 32
+        Pbufs = [[be.zeros(max_rows, LDP) for _ in range(P)] for _ in range(2)]
+        Bbuf = be.zeros(n_loc + 128, LDP)                     # B operand gathered in my local column order
+        Lkk = be.zeros(NB + 128, LDP)                         # (+128 slack rows: operand over-read contract of the GEMM)
 
         def rows_below(k):
             """per process row pp: (first local row below block k, number of local rows from there incl. RHS rows)"""
@@ -255,18 +257,18 @@ class BlockCyclicEngine:
                     if p == pk:
                         r0 = lbk_r * NB
                         be.potrf(_sub(A, r0, c0), ldl, NB, NB, info, k * NB, n, scal[0:1])
-                        Lkk.copy_(A[r0:r0 + NB, c0:c0 + NB])
+                        Lkk[:NB, :NB].copy_(A[r0:r0 + NB, c0:c0 + NB])
                     self._bcast_col(Lkk, pk, qk)
                     r0 = self._nlb_before(k, p, P) * NB       # my first local row with global block > k
                     if m_loc - r0 > 0:
-                        be.trsm(_sub(A, r0, c0), ldl, m_loc - r0, Lkk, NB, NB)
+                        be.trsm(_sub(A, r0, c0), ldl, m_loc - r0, Lkk, LDP, NB)
             works = []
             for pp, (r0p, mp) in enumerate(rows_below(k)):    # one piece per process row, to everyone
                 if mp <= 0:
                     continue
                 piece = Pbuf[pp][:mp]
                 if p == pp and q == qk:
-                    piece.copy_(A[r0p:r0p + mp, lbk_c * NB:(lbk_c + 1) * NB])
+                    piece[:, :NB].copy_(A[r0p:r0p + mp, lbk_c * NB:(lbk_c + 1) * NB])
                 if self.coll:
                     works.append(dist.broadcast(piece, src=self._rank_of(pp, qk), async_op=True))
             return works
@@ -283,7 +285,7 @@ class BlockCyclicEngine:
                 pp = gj % P
                 off = (gj // P) * NB - rows[pp][0]
                 Bbuf[(lj - lj_lo) * NB:(lj - lj_lo + 1) * NB].copy_(Pbuf[pp][off:off + NB])
-            be.gemm_nt(_sub(A, r0, lj_lo * NB), ldl, Pbuf[p], NB, Bbuf, NB, mrows, ncols, NB, grid, r0, lj_lo * NB)
+            be.gemm_nt(_sub(A, r0, lj_lo * NB), ldl, Pbuf[p], LDP, Bbuf, LDP, mrows, ncols, NB, grid, r0, lj_lo * NB)
             # algorithmic flops of this launch: local elements on/below the global diagonal × 2·NB
             cnt = 0
             for lj in range(lj_lo, lj_hi):
