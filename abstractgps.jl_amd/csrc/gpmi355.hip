@@ -75,6 +75,8 @@ struct gp_ctx {
     int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
                            // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
     int num_cus = 256;
+    long sk_max_tiles = 4096;  // stream-K only for launches of at most this many tiles (8 rounds): the persistent kernel is
+                           // ~5 % slower than hardware dispatch on large launches, where the tail does not matter anyway
     int sk_u1 = 0;         // stream-K for the U1 update of the look-ahead schedule (measured: no effect)
     int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there
                            // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
@@ -265,7 +267,8 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
         else if ((c->gemm_streamk || c->sk_scope > 0) && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
-                 g.P == 1 && g.Q == 1 && g.compact <= 1) {
+                 g.P == 1 && g.Q == 1 && g.compact <= 1 &&
+                 (g.compact == 1 ? (long)grid.x : tm * tn) <= c->sk_max_tiles) {
             // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
             const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
             const long ntiles = g.compact == 1 ? (long)grid.x : tm * tn;
@@ -1215,6 +1218,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
     else if (!strcmp(name, "sk_u1")) c->sk_u1 = v != 0;
+    else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
     else if (!strcmp(name, "gemm_pad_lds")) c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
