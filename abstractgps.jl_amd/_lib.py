@@ -60,7 +60,14 @@ PROTOTYPES = {
     "gp_posterior_free": (i32, [vp]),
     "gp_vfe_fit": (i32, [vp, PK, PP, PP, PN, dbl, vp, vp, i32, C.POINTER(vp), vp]),
     "gp_vfe_update": (i32, [vp, PP, PN, vp, vp, C.POINTER(vp), vp]),
-    "gp_vfe_predict": (i32, [vp, PP, vp, i32, vp, vp]),
+    "gp_vfe_predict": (i32, [vp, PP, vp, i32, vp, vp, vp]),
+    "gp_vfe_append": (i32, [vp, PP, C.POINTER(vp), vp]),
+    "gp_vfe_logpdf": (i32, [vp, PP, vp, PN, vp, i64, i32, vp]),
+    "gp_vfe_rand": (i32, [vp, PP, vp, PN, vp, i32, vp]),
+    "gp_vfe_m": (i64, [vp]),
+    "gp_posterior_logpdf": (i32, [vp, PP, vp, PN, vp, i64, i32, vp]),
+    "gp_posterior_rand": (i32, [vp, PP, vp, PN, vp, i32, vp]),
+    "gp_ctx_trim": (i32, [vp]),
     "gp_vfe_get": (i32, [vp, vp, vp]),
     "gp_vfe_free": (i32, [vp]),
     "gpd_assemble": (i32, [vp, PK, vp, i64, i64, i32, vp, PG, vp, i64, i64, i64]),
@@ -101,7 +108,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.gp_abi_version() != 1:
+    if lib.gp_abi_version() != 2:
         raise ImportError("libgpmi355.so ABI version mismatch")
     _lib = lib
     return lib

@@ -3,7 +3,8 @@
 Line-for-line Python counterpart of the Julia shim (julia/HipGPs.jl): same names, argument meaning
 and error behaviour as the reference (file:line cited per function, relative to the upstream repo),
 every numeric step a call through the C ABI (include/gpmi355.h) into the HIP library.  Nothing here
-computes Gram matrices, factorisations or solves on the host.
+computes Gram matrices, factorisations or solves on the host (held-out logpdf and posterior sampling included:
+gp_posterior_logpdf / gp_posterior_rand / gp_vfe_logpdf / gp_vfe_rand).
 
     f   = GP(SqExponentialKernel())                    # src/base_gp.jl:57-64
     fx  = f(x, 0.01)                                   # src/finite_gp_projection.jl:32
@@ -217,6 +218,10 @@ class Context:
         check(self.lib.gp_get_timings(self.handle, C.byref(t)))
         return {f: getattr(t, f) for f, _ in gp_timings._fields_}
 
+    def trim(self) -> None:
+        """Hand the ctx's cached free device blocks back to the HIP allocator (e.g. after freeing a 34 GB posterior)."""
+        check(self.lib.gp_ctx_trim(self.handle))
+
     def close(self):
         self._fin()
 
@@ -317,6 +322,15 @@ class FiniteGP:
         s = np.asarray(self.sigma2)
         return np.full(len(self), float(s)) if s.ndim == 0 else s
 
+    def _prior_factor(self):
+        """Device-resident factor of cov(fx) = K + Σy for a GP prior, computed once per FiniteGP object and reused by
+        rand (the reference refactors on every call, src/finite_gp_projection.jl:235)."""
+        fac = getattr(self, "_fac", None)
+        if fac is None:
+            fac = _posterior_exact(self, np.zeros(len(self), dtype=_input_dtype(self.x)), zero_mean=True).data.C
+            object.__setattr__(self, "_fac", fac)
+        return fac
+
 
 def kernelmatrix(k: Kernel, x, z=None, ctx: Optional[Context] = None) -> np.ndarray:
     """KernelFunctions.kernelmatrix(k, x[, z]) on the device (src/base_gp.jl:70,74)."""
@@ -351,7 +365,7 @@ def logpdf(fx: FiniteGP, y):
     eltype; matrix (N×S) -> length-S vector."""
     y = _check_y(fx, y)
     f = fx.f
-    if isinstance(f, PosteriorGP):
+    if isinstance(f, (PosteriorGP, ApproxPosteriorGP)):
         return _logpdf_posterior(fx, y)
     if not isinstance(f, GP):
         raise TypeError("logpdf: unsupported GP type")
@@ -490,7 +504,7 @@ def _stack_inputs(x, z):
     return np.concatenate([x, z]), True
 
 
-def _posterior_exact(fx: FiniteGP, y) -> PosteriorGP:
+def _posterior_exact(fx: FiniteGP, y, zero_mean: bool = False) -> PosteriorGP:
     """posterior(fx::FiniteGP, y) — src/exact_gpr_posterior.jl:29-35.  One device call: Gram, Cholesky,
     α and logpdf(fx, y) (kept as .logpdf_value) from a single factorisation."""
     y = _check_y(fx, y)
@@ -507,7 +521,7 @@ def _posterior_exact(fx: FiniteGP, y) -> PosteriorGP:
     px = m.points(fx.x)
     kk = m.kernel(f.kernel, px.d)
     nz = m.noise(fx.sigma2, px.n)
-    mean = _mean_vector(f.mean_fn, fx.x, dt)
+    mean = None if zero_mean else _mean_vector(f.mean_fn, fx.x, dt)
     yv = m.arr(y)
     delta = yv - mean if mean is not None else yv.copy()  # δ = y - m  (:32)
     mean = None if mean is None else m.arr(mean)
@@ -542,58 +556,74 @@ def _posterior_sequential(fx: FiniteGP, y) -> PosteriorGP:
     return PosteriorGP(prior, _PostData(alpha, _Factor(fac.ctx, h, n, dt), x_all, delta), lp[0])
 
 
+def _joint_call(fx: FiniteGP, name: str, payload: np.ndarray):
+    """Shared marshalling of gp_{posterior,vfe}_{logpdf,rand}: payload is ns × ncols (y* columns or standard normals)."""
+    f = fx.f
+    if isinstance(f, PosteriorGP):
+        ctx, h, dt, prior, fn = f.data.C.ctx, f.data.C.handle, f.data.C.dtype, f.prior, "gp_posterior_" + name
+    elif isinstance(f, ApproxPosteriorGP):
+        ctx, h, dt, prior, fn = f._state.ctx, f._state.handle, f._dtype, f.prior, "gp_vfe_" + name
+    else:
+        raise TypeError(f"{name}: unsupported GP type")
+    m = _Marshal(dt)
+    px = m.points(fx.x)
+    nz = m.noise(fx.sigma2, px.n)
+    pm = _mean_vector(prior.mean_fn, fx.x, dt)
+    pm = None if pm is None else m.arr(pm)
+    P = m.arr(payload, order="F")
+    ncols = P.shape[1]
+    if name == "logpdf":
+        out = np.empty(ncols, dtype=dt)
+        check(getattr(ctx.lib, fn)(h, C.byref(px), m.ptr(pm), C.byref(nz), P.ctypes.data, P.shape[0], ncols, out.ctypes.data))
+    else:
+        out = np.empty((px.n, ncols), dtype=dt, order="F")
+        check(getattr(ctx.lib, fn)(h, C.byref(px), m.ptr(pm), C.byref(nz), P.ctypes.data, ncols, out.ctypes.data))
+    return out
+
+
 def rand(fx: FiniteGP, N: Optional[int] = None, rng=None, xi=None):
-    """rand([rng,] fx[, N]) — src/finite_gp_projection.jl:233-240: m .+ C.U' * randn(rng, n, N).  The factor and the
-    triangular product run on the device; the standard normals are drawn on the host (`rng`: numpy Generator) or passed
-    in as `xi` (n × N) for reproducible parity checks."""
+    """rand([rng,] fx[, N]) — src/finite_gp_projection.jl:233-240: m .+ C.U' * randn(rng, n, N).  Factor and triangular
+    product run on the device for priors AND posteriors (exact / VFE: the N*×N* predictive covariance is built and
+    factored in HBM against the resident factor — nothing is refitted); the standard normals are drawn on the host
+    (`rng`: numpy Generator) or passed in as `xi` (n × N) for reproducible parity checks."""
     f = fx.f
     n = len(fx)
+    ncols = 1 if N is None else int(N)
     if isinstance(f, GP):
-        post0 = _posterior_exact(fx, np.zeros(n, dtype=_input_dtype(fx.x)))   # factor of cov(fx) = K + Σy
-        fac, dt = post0.data.C, post0.data.C.dtype
-        mvec = f.mean(fx.x)
-    elif isinstance(f, (PosteriorGP, ApproxPosteriorGP)) and hasattr(f, "mean_and_cov"):
-        # posterior samples at N* test points: predictive mean/cov from the device, N*×N* factor on the host
-        # (N* is plot-sized in the reference's usage: src/util/plotting.jl:120-132)
-        mvec, Cm = f.mean_and_cov(fx.x)
-        Cm = np.array(Cm, dtype=np.float64)
-        Cm[np.diag_indices_from(Cm)] += fx.noise_vector()
-        try:
-            Lh = np.linalg.cholesky(Cm)
-        except np.linalg.LinAlgError:
-            raise PosDefException(-1)
-        ncols = 1 if N is None else int(N)
-        if xi is None:
-            xi = (rng or np.random.default_rng()).standard_normal((n, ncols))
-        out = np.asarray(mvec, dtype=np.float64)[:, None] + Lh @ np.asarray(xi, dtype=np.float64).reshape(n, ncols)
-        return out[:, 0] if N is None else out
+        fac = fx._prior_factor()
+        dt = fac.dtype
+    elif isinstance(f, (PosteriorGP, ApproxPosteriorGP)):
+        dt = f.data.C.dtype if isinstance(f, PosteriorGP) else f._dtype
     else:
         raise TypeError("rand: unsupported GP type")
-    ncols = 1 if N is None else int(N)
     if xi is None:
-        rng = rng or np.random.default_rng()
-        xi = rng.standard_normal((n, ncols))
+        xi = (rng or np.random.default_rng()).standard_normal((n, ncols))
     xi = np.asfortranarray(np.asarray(xi, dtype=dt).reshape(n, ncols))
-    out = np.empty((n, ncols), dtype=dt, order="F")
-    check(fac.ctx.lib.gp_posterior_factor_mul(fac.handle, xi.ctypes.data, ncols, out.ctypes.data))
-    out += np.asarray(mvec, dtype=dt)[:, None]
+    if isinstance(f, GP):
+        out = np.empty((n, ncols), dtype=dt, order="F")
+        check(fac.ctx.lib.gp_posterior_factor_mul(fac.handle, xi.ctypes.data, ncols, out.ctypes.data))
+        out += np.asarray(f.mean(fx.x), dtype=dt)[:, None]
+    else:
+        out = _joint_call(fx, "rand", xi)
     return out[:, 0] if N is None else out
 
 
+def rand_(fx: FiniteGP, out: np.ndarray, rng=None, xi=None) -> np.ndarray:
+    """rand!(rng, fx, y) — src/finite_gp_projection.jl:271-277 (via _rand!): fills the vector (n) or matrix (n × N) `out`
+    in place and returns it."""
+    out_arr = np.asarray(out)
+    if out_arr.shape[0] != len(fx):
+        raise ValueError(f"DimensionMismatch: length(fx) = {len(fx)} but the output has {out_arr.shape[0]} rows")
+    res = rand(fx, None if out_arr.ndim == 1 else out_arr.shape[1], rng=rng, xi=xi)
+    out[...] = res
+    return out
+
+
 def _logpdf_posterior(fx: FiniteGP, y):
-    """logpdf(post(x*, Σy*), y*): predictive mean/cov from the device, small N* Cholesky on the host
-    (N* is a handful of held-out points in the reference's usage; README.md:46-54)."""
-    if y.ndim != 1:
-        raise NotImplementedError
-    m, Cm = fx.f.mean_and_cov(fx.x)
-    Cm = np.array(Cm, dtype=np.float64)
-    Cm[np.diag_indices_from(Cm)] += fx.noise_vector()
-    try:
-        L = np.linalg.cholesky(Cm)
-    except np.linalg.LinAlgError:
-        raise PosDefException(-1)
-    z = np.linalg.solve(L, np.asarray(y, dtype=np.float64) - m)
-    return -0.5 * (len(y) * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(L))) + z @ z)
+    """logpdf(post(x*, Σy*), y*) — the generic FiniteGP path of the reference (src/finite_gp_projection.jl:306-311 over the
+    posterior's mean_and_cov, src/exact_gpr_posterior.jl:78-83 / src/sparse_approximations.jl:205-210) as ONE device call."""
+    out = _joint_call(fx, "logpdf", y if y.ndim == 2 else y[:, None])
+    return out[0] if y.ndim == 1 else out
 
 
 # Distribution-style accessors on FiniteGP (src/finite_gp_projection.jl:53,96,114,133,154,203)
@@ -718,8 +748,9 @@ class ApproxPosteriorGP(AbstractGP):
         pm = None if pm is None else mm.arr(pm)
         mean = np.empty(px.n, dtype=self._dtype) if what & 1 else None
         var = np.empty(px.n, dtype=self._dtype) if what & 2 else None
-        check(st.ctx.lib.gp_vfe_predict(st.handle, C.byref(px), mm.ptr(pm), what, mm.ptr(mean), mm.ptr(var)))
-        return mean, var
+        cov = np.empty((px.n, px.n), dtype=self._dtype, order="F") if what & 4 else None
+        check(st.ctx.lib.gp_vfe_predict(st.handle, C.byref(px), mm.ptr(pm), what, mm.ptr(mean), mm.ptr(var), mm.ptr(cov)))
+        return mean, var, cov
 
     def mean(self, x=None):  # :183-185
         if x is None:
@@ -729,8 +760,19 @@ class ApproxPosteriorGP(AbstractGP):
     def var(self, x):  # :192-195
         return self._predict(x, 2)[1]
 
+    def cov(self, x, z=None):  # :187-190, :197-203
+        if z is None:
+            return self._predict(x, 4)[2]
+        xa, _ = _stack_inputs(x, z)  # cov(f, x, z) = off-diagonal block of the joint covariance over [x; z]
+        nx = _npoints(x)
+        return np.asfortranarray(self._predict(xa, 4)[2][:nx, nx:])
+
     def mean_and_var(self, x):  # :212-217
-        return self._predict(x, 3)
+        return self._predict(x, 3)[:2]
+
+    def mean_and_cov(self, x):  # :205-210
+        m, _, c = self._predict(x, 5)
+        return m, c
 
 
 def inducing_points(f: ApproxPosteriorGP):  # :219
@@ -740,36 +782,30 @@ def inducing_points(f: ApproxPosteriorGP):  # :219
 def update_posterior(f_post_approx: ApproxPosteriorGP, fx: FiniteGP, y=None):
     """update_posterior(f_post_approx, fx, y)  — new observations, same pseudo-points (src/sparse_approximations.jl:87-121):
     the device continues its streamed reductions with the new points and re-finalises the M×M side.
-    update_posterior(f_post_approx, fz)      — append pseudo-points (:131-176): the bordered update of the reference equals
-    a fit with z = vcat(z_old, z_new); the mirror refits from the observations it has seen."""
+    update_posterior(f_post_approx, fz)      — append pseudo-points (:131-176): bordered Cholesky of K_zz on the resident
+    factor (update_chol), then the observations retained on the device are streamed once more for the NEW block rows of
+    B Bᵀ / B b_y only (gp_vfe_append)."""
     if f_post_approx.prior is not fx.f:
         raise AssertionError("f_post_approx.prior === fx.f")
     st = f_post_approx._state
     dt = f_post_approx._dtype
-    if y is None:  # new pseudo-points
-        hist = getattr(f_post_approx, "_history", None)
-        if hist is None:
-            raise NotImplementedError("appending pseudo-points needs the observations (posterior built by this module)")
-        z_all, _ = _stack_inputs(f_post_approx.approx.fz.x, fx.x)
-        approx = type(f_post_approx.approx)(f_post_approx.prior(z_all, f_post_approx.approx.fz.sigma2))
-        post = None
-        for i, (hx, hs2, hy) in enumerate(hist):
-            hfx = f_post_approx.prior(hx, hs2)
-            post = posterior(approx, hfx, hy) if i == 0 else update_posterior(post, hfx, hy)
-        return post
-    y = _check_y(fx, y)
     mm = _Marshal(dt)
+    obj = np.empty(1, dtype=dt)
+    h = C.c_void_p()
+    if y is None:  # new pseudo-points: fx is fz
+        pz = mm.points(fx.x)
+        check(st.ctx.lib.gp_vfe_append(st.handle, C.byref(pz), C.byref(h), obj.ctypes.data))
+        z_all, _ = _stack_inputs(f_post_approx.approx.fz.x, fx.x)                                     # z_new = vcat(z_old, z)  (:160)
+        approx = type(f_post_approx.approx)(f_post_approx.prior(z_all, f_post_approx.approx.fz.sigma2))  # _update_approx (:178-179)
+        return ApproxPosteriorGP(approx, f_post_approx.prior, _VfeState(st.ctx, h), dt, f_post_approx._m + pz.n, obj[0])
+    y = _check_y(fx, y)
     px = mm.points(fx.x)
     nz = mm.noise(fx.sigma2, px.n)
     mean = _mean_vector(f_post_approx.prior.mean_fn, fx.x, dt)
     mean = None if mean is None else mm.arr(mean)
     yv = mm.arr(y)
-    obj = np.empty(1, dtype=dt)
-    h = C.c_void_p()
     check(st.ctx.lib.gp_vfe_update(st.handle, C.byref(px), C.byref(nz), mm.ptr(mean), yv.ctypes.data, C.byref(h), obj.ctypes.data))
-    new = ApproxPosteriorGP(f_post_approx.approx, f_post_approx.prior, _VfeState(st.ctx, h), dt, f_post_approx._m, obj[0])
-    new._history = list(getattr(f_post_approx, "_history", [])) + [(fx.x, fx.sigma2, np.asarray(y))]
-    return new
+    return ApproxPosteriorGP(f_post_approx.approx, f_post_approx.prior, _VfeState(st.ctx, h), dt, f_post_approx._m, obj[0])
 
 
 def posterior(*args):
@@ -784,9 +820,7 @@ def posterior(*args):
             return _posterior_exact(fx, y)
         if isinstance(a, (VFE, DTC)):
             h, obj, ctx, dt, m = _vfe_call(a, fx, y, True)
-            post = ApproxPosteriorGP(a, fx.f, _VfeState(ctx, h), dt, m, obj)
-            post._history = [(fx.x, fx.sigma2, np.asarray(y))]
-            return post
+            return ApproxPosteriorGP(a, fx.f, _VfeState(ctx, h), dt, m, obj)
     raise TypeError("posterior(fx, y) or posterior(approx, fx, y)")
 
 

@@ -10,14 +10,17 @@
 #include "../../include/gpmi355.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <set>
+#include <memory>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 using namespace gpmi;
@@ -88,7 +91,11 @@ struct gp_ctx {
     long xcd_min_tiles = 256;
     long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
     gp_timings tm{};
-    std::vector<FreeBlock> pool;
+    std::vector<FreeBlock> pool;               // cached free device blocks (true sizes)
+    std::unordered_map<void*, size_t> blk;     // true size of every block handed out by ctx_alloc
+    size_t pool_bytes = 0;
+    size_t pool_cap = (size_t)96 << 30;        // bytes kept in the cache at most ("pool_cap_mb"; gp_ctx_trim drops it all)
+    long vfe_chunk = 8192;                     // data points per streamed VFE chunk (multiple of 2048)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct GemmRec {
@@ -106,7 +113,7 @@ struct gp_ctx {
     void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
     double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
     long scal_cap = 0;
-    int refs = 1;
+    std::atomic<int> refs{1};
     bool dead = false;
 };
 
@@ -130,7 +137,37 @@ static bool reg_has(void* p) {
     std::lock_guard<std::mutex> l(g_reg_mu);
     return g_live.count(p) > 0;
 }
+static void ctx_unref(gp_ctx* c);
+// Validates a handle (gp_ctx / gp_post / gp_vfe) and locks its ctx without racing a concurrent *_free / gp_ctx_destroy from
+// another thread: the ctx is pinned under the registry mutex, locked, and the handle is checked again under the ctx lock
+// (every *_free removes its handle from the registry BEFORE it takes the ctx lock to release the buffers).
+struct Guard {
+    gp_ctx* c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    bool ok = false;
+    static gp_ctx* ctx_of(gp_ctx* h) { return h; }
+    template <class H> static gp_ctx* ctx_of(H* h) { return h->ctx; }
+    template <class H> explicit Guard(H* h) {
+        {
+            std::lock_guard<std::mutex> l(g_reg_mu);
+            if (!h || !g_live.count((void*)h)) return;
+            c = ctx_of(h);
+            c->refs++;
+        }
+        lk = std::unique_lock<std::mutex>(c->mu);
+        ok = reg_has((void*)h) && !c->dead;
+    }
+    ~Guard() {
+        if (lk.owns_lock()) lk.unlock();
+        if (c) ctx_unref(c);
+    }
+};
 
+static void pool_drop(gp_ctx* c, size_t i) {
+    c->pool_bytes -= c->pool[i].bytes;
+    (void)hipFree(c->pool[i].p);
+    c->pool.erase(c->pool.begin() + i);
+}
 static int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out) {
     size_t best = (size_t)-1;
     int bi = -1;
@@ -141,40 +178,66 @@ static int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out) {
         }
     if (bi >= 0) {
         *out = c->pool[bi].p;
+        c->blk[*out] = c->pool[bi].bytes;  // the block keeps its true size
+        c->pool_bytes -= c->pool[bi].bytes;
         c->pool.erase(c->pool.begin() + bi);
         return 0;
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) {  // drop the cache and retry once
-        for (auto& b : c->pool) (void)hipFree(b.p);
-        c->pool.clear();
+        (void)hipGetLastError();
+        while (!c->pool.empty()) pool_drop(c, c->pool.size() - 1);
         e = hipMalloc(out, bytes);
     }
     if (e != hipSuccess) return set_hip_err(e, "hipMalloc", __LINE__);
+    c->blk[*out] = bytes;
     return 0;
 }
-static size_t block_bytes(size_t want) { return want; }
-static void ctx_release(gp_ctx* c, void* p, size_t bytes) {
+static void ctx_release(gp_ctx* c, void* p, size_t /*requested*/) {
     if (!p) return;
-    if (c->dead) {
+    size_t bytes = 0;
+    auto it = c->blk.find(p);
+    if (it != c->blk.end()) {
+        bytes = it->second;
+        c->blk.erase(it);
+    }
+    if (c->dead || bytes == 0 || bytes > c->pool_cap) {
         (void)hipFree(p);
         return;
     }
     c->pool.push_back({p, bytes});
-    while (c->pool.size() > 32) {  // bound the cache (a VFE fit alone cycles through ~16 buffers)
-        (void)hipFree(c->pool.front().p);
-        c->pool.erase(c->pool.begin());
-    }
+    c->pool_bytes += bytes;
+    // bound the cache by bytes and by count (a VFE fit alone cycles through ~16 buffers); oldest blocks go first
+    while (c->pool.size() > 1 && (c->pool_bytes > c->pool_cap || c->pool.size() > 48)) pool_drop(c, 0);
 }
-static void ctx_unref(gp_ctx* c) {
-    bool destroy = false;
-    {
-        std::lock_guard<std::mutex> l(c->mu);
-        destroy = (--c->refs == 0);
+// RAII owner of the device blocks of one call: everything still owned when it goes out of scope returns to the ctx cache
+// (every early-return / error path included); keep() hands a block over to a handle.
+struct DevBufs {
+    gp_ctx* c;
+    std::vector<void*> v;
+    explicit DevBufs(gp_ctx* c_) : c(c_) {}
+    DevBufs(const DevBufs&) = delete;
+    int32_t get(size_t bytes, void** out) {
+        *out = nullptr;
+        int32_t rc = ctx_alloc(c, bytes ? bytes : 16, out);
+        if (rc == 0) v.push_back(*out);
+        return rc;
     }
-    if (!destroy) return;
+    void* keep(void* p) {
+        for (auto& q : v)
+            if (q == p) q = nullptr;
+        return p;
+    }
+    ~DevBufs() {
+        for (void* q : v)
+            if (q) ctx_release(c, q, 0);
+    }
+};
+static void ctx_unref(gp_ctx* c) {
+    if (--c->refs != 0) return;
     (void)hipSetDevice(c->device);
     for (auto& b : c->pool) (void)hipFree(b.p);
+    for (auto& kv : c->blk) (void)hipFree(kv.first);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->ev_phase)
         if (e) (void)hipEventDestroy(e);
@@ -229,7 +292,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         RC(ctx_event(c, &rec.b, true));
         double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
         if (g.nbatch > 1) elems *= g.nbatch;
-        rec.flops = g.ktri == 1 ? (double)N * (double)M * (double)(M + 128)
+        rec.flops = g.ktri == 1 ? (double)N * (double)M * (double)(2 * g.ktri_off + M + 128)
                                 : (g.ktri == 2 ? (double)M * (double)M * (double)M / 3.0 : 2.0 * (double)K * elems);
         rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
         rec.M = M; rec.N = N; rec.K = K;
@@ -326,6 +389,7 @@ static GridMap plain_map(int lower, long row0, long col0) {
     g.ktri = 0;
     g.nbatch = 1;
     g.cstride = 0;
+    g.ktri_off = 0;
     return g;
 }
 
@@ -704,24 +768,17 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
     for (int s = 0; s < ncols; ++s)
         for (long i = 0; i < n; ++i) rhs_h[(size_t)s * np + i] = Y[(size_t)s * ldy + i] - (mean ? mean[i] : T(0));
 
-    // ---- device buffers
+    // ---- device buffers (RAII: every exit path returns what is not handed to the posterior handle)
     void *A_v = nullptr, *xs_v = nullptr, *noise_v = nullptr, *alpha_v = nullptr;
     const size_t A_bytes = sizeof(T) * (size_t)(mtot + 128) * ld;
     const size_t xs_bytes = sizeof(T) * (size_t)d * np, nz_bytes = sizeof(T) * (size_t)np;
-    RC(ctx_alloc(c, A_bytes, &A_v));
-    RC(ctx_alloc(c, xs_bytes, &xs_v));
-    RC(ctx_alloc(c, nz_bytes, &noise_v));
-    RC(ctx_alloc(c, nz_bytes, &alpha_v));
+    DevBufs bufs(c);
+    RC(bufs.get(A_bytes, &A_v));
+    RC(bufs.get(xs_bytes, &xs_v));
+    RC(bufs.get(nz_bytes, &noise_v));
+    RC(bufs.get(nz_bytes, &alpha_v));
     T* A = (T*)A_v;
     double logdet_half_out = 0;
-    auto cleanup = [&](bool keep) {
-        ctx_release(c, noise_v, nz_bytes);
-        if (!keep) {
-            ctx_release(c, A_v, A_bytes);
-            ctx_release(c, xs_v, xs_bytes);
-            ctx_release(c, alpha_v, nz_bytes);
-        }
-    };
     int32_t rc = [&]() -> int32_t {
         HIPCHK(hipEventRecord(c->ev_phase[0], c->sm));
         HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), xs_bytes, hipMemcpyHostToDevice, c->sm));
@@ -784,14 +841,12 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
     if (rc != 0) {
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
-        cleanup(false);
         return rc;
     }
-    if (out.info != 0 || !post) {
-        cleanup(false);
-        return out.info;
-    }
-    cleanup(true);
+    if (out.info != 0 || !post) return out.info;
+    bufs.keep(A_v);
+    bufs.keep(xs_v);
+    bufs.keep(alpha_v);
     post->dtype = k->dtype;
     post->n = n; post->np = np; post->ld = ld; post->mtot = mtot; post->d = d;
     post->kind = k->kind; post->variance = k->variance; post->nscale = k->nscale;
@@ -819,7 +874,8 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
     scale_points<T>(&k, xs, nsp, xs_h);
     void* xs_v = nullptr;
     const size_t xs_bytes = sizeof(T) * (size_t)d * nsp;
-    RC(ctx_alloc(c, xs_bytes, &xs_v));
+    DevBufs bufs(c);
+    RC(bufs.get(xs_bytes, &xs_v));
     void *m_v = nullptr, *X_v = nullptr, *C_v = nullptr;
     size_t m_bytes = sizeof(T) * (size_t)nsp, X_bytes = 0, C_bytes = 0;
     const T* prior_mean = (const T*)pm;
@@ -829,7 +885,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
     int32_t rc = [&]() -> int32_t {
         HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), xs_bytes, hipMemcpyHostToDevice, c->sm));
         if (what & 1) {
-            RC(ctx_alloc(c, m_bytes, &m_v));
+            RC(bufs.get(m_bytes, &m_v));
             hipLaunchKernelGGL(kvec_kernel<T>, dim3((unsigned)ns), dim3(256), 0, c->sm, (const T*)xs_v, nsp,
                                (const T*)post->xs, np, d, post->kind, (T)post->variance, n, (const T*)post->alpha,
                                (T*)m_v);
@@ -847,7 +903,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
             const long chunk = want_cov ? nsp : std::min<long>(nsp, 4096);
             const long ldx = np + c->ldpad;
             X_bytes = sizeof(T) * (size_t)(chunk + 128) * ldx;
-            RC(ctx_alloc(c, X_bytes, &X_v));
+            RC(bufs.get(X_bytes, &X_v));
             RC(ctx_scal(c, 8 + chunk));
             T* X = (T*)X_v;
             std::vector<double> ss(chunk);
@@ -875,7 +931,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
             if (want_cov) {
                 const long ldc = nsp + c->ldpad;
                 C_bytes = sizeof(T) * (size_t)(nsp + 128) * ldc;
-                RC(ctx_alloc(c, C_bytes, &C_v));
+                RC(bufs.get(C_bytes, &C_v));
                 T* Cm = (T*)C_v;
                 GridMap g = plain_map(0, 0, 0);
                 dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
@@ -893,10 +949,6 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
         return 0;
     }();
     if (rc != 0) (void)hipStreamSynchronize(c->sm);
-    ctx_release(c, xs_v, xs_bytes);
-    ctx_release(c, m_v, m_bytes);
-    ctx_release(c, X_v, X_bytes);
-    ctx_release(c, C_v, C_bytes);
     return rc;
 }
 
@@ -918,16 +970,20 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     void *W_v = 0, *Ci_v = 0, *g_v = 0, *dn_v = 0, *sc_v = 0;
     const size_t M_b = sizeof(T) * (size_t)(np + 128) * ld, g_b = sizeof(double) * 32, dn_b = sizeof(T) * (size_t)np;
     const size_t sc_b = sizeof(double) * 16;
+    DevBufs bufs(c);
+    bufs.v.push_back(post.A);  // the temporary posterior's blocks go back to the cache with everything else
+    bufs.v.push_back(post.xs);
+    bufs.v.push_back(post.alpha);
     double g_h[32] = {0};
     std::vector<T> dn_h((size_t)n);
     std::vector<double> sc_h(16, 1.0);
     for (int p = 0; p < k->nscale && p < 16; ++p) sc_h[p] = k->scale[p];
     int32_t rc = [&]() -> int32_t {
-        RC(ctx_alloc(c, M_b, &W_v));
-        RC(ctx_alloc(c, M_b, &Ci_v));
-        RC(ctx_alloc(c, g_b, &g_v));
-        RC(ctx_alloc(c, dn_b, &dn_v));
-        RC(ctx_alloc(c, sc_b, &sc_v));
+        RC(bufs.get(M_b, &W_v));
+        RC(bufs.get(M_b, &Ci_v));
+        RC(bufs.get(g_b, &g_v));
+        RC(bufs.get(dn_b, &dn_v));
+        RC(bufs.get(sc_b, &sc_v));
         T* W = (T*)W_v;
         T* Ci = (T*)Ci_v;
         HIPCHK(hipMemsetAsync(g_v, 0, g_b, s));
@@ -965,14 +1021,6 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
     }
-    ctx_release(c, W_v, M_b);
-    ctx_release(c, Ci_v, M_b);
-    ctx_release(c, g_v, g_b);
-    ctx_release(c, dn_v, dn_b);
-    ctx_release(c, sc_v, sc_b);
-    ctx_release(c, post.A, post.A_bytes);
-    ctx_release(c, post.xs, post.xs_bytes);
-    ctx_release(c, post.alpha, post.alpha_bytes);
     if (rc != 0) return rc;
     *(T*)logpdf_out = (T)fo.logpdf[0];
     if (dvar) *dvar = g_h[0];
@@ -1019,13 +1067,14 @@ static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* no
     const size_t A_b = sizeof(T) * (size_t)(mtot + 128) * ld, xs_b = sizeof(T) * (size_t)d * np, v_b = sizeof(T) * (size_t)np;
     const size_t X_b = sizeof(T) * (size_t)(n2p + 128) * ldx, S_b = sizeof(T) * (size_t)(n2p + 128) * lds;
     const size_t x2_b = sizeof(T) * (size_t)d * n2p, nz_b = sizeof(T) * (size_t)n2p;
-    RC(ctx_alloc(c, A_b, &A_v));
-    RC(ctx_alloc(c, xs_b, &xs_v));
-    RC(ctx_alloc(c, v_b, &alpha_v));
-    RC(ctx_alloc(c, X_b, &X_v));
-    RC(ctx_alloc(c, S_b, &S_v));
-    RC(ctx_alloc(c, x2_b, &x2_v));
-    RC(ctx_alloc(c, nz_b, &nz_v));
+    DevBufs bufs(c);
+    RC(bufs.get(A_b, &A_v));
+    RC(bufs.get(xs_b, &xs_v));
+    RC(bufs.get(v_b, &alpha_v));
+    RC(bufs.get(X_b, &X_v));
+    RC(bufs.get(S_b, &S_v));
+    RC(bufs.get(x2_b, &x2_v));
+    RC(bufs.get(nz_b, &nz_v));
     T* A = (T*)A_v;
     T* X = (T*)X_v;
     T* S = (T*)S_v;
@@ -1085,17 +1134,11 @@ static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* no
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
     }
-    ctx_release(c, X_v, X_b);
-    ctx_release(c, S_v, S_b);
-    ctx_release(c, x2_v, x2_b);
-    ctx_release(c, nz_v, nz_b);
     if (rc == 0 && info_h != 0) rc = (int32_t)n1 + info_h;  // order of the failing leading minor of the bordered matrix
-    if (rc != 0) {
-        ctx_release(c, A_v, A_b);
-        ctx_release(c, xs_v, xs_b);
-        ctx_release(c, alpha_v, v_b);
-        return rc;
-    }
+    if (rc != 0) return rc;
+    bufs.keep(A_v);
+    bufs.keep(xs_v);
+    bufs.keep(alpha_v);
     post->ctx = c;
     post->dtype = old->dtype;
     post->n = n; post->np = np; post->ld = ld; post->mtot = mtot; post->d = d;
@@ -1114,8 +1157,9 @@ template <typename T> static int32_t factor_mul_impl(gp_post* post, const void* 
     const long n = post->n, np = post->np;
     void *in_v = 0, *out_v = 0;
     const size_t b = sizeof(T) * (size_t)np * ncols;
-    RC(ctx_alloc(c, b, &in_v));
-    RC(ctx_alloc(c, b, &out_v));
+    DevBufs bufs(c);
+    RC(bufs.get(b, &in_v));
+    RC(bufs.get(b, &out_v));
     hipStream_t s = c->sm;
     int32_t rc = [&]() -> int32_t {
         HIPCHK(hipMemsetAsync(in_v, 0, b, s));
@@ -1128,9 +1172,163 @@ template <typename T> static int32_t factor_mul_impl(gp_post* post, const void* 
         return 0;
     }();
     if (rc != 0) (void)hipStreamSynchronize(s);
-    ctx_release(c, in_v, b);
-    ctx_release(c, out_v, b);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Joint predictive distribution on the device: logpdf(post(x*, Σy*), y*) and rand(post(x*, Σy*)) without leaving HBM.
+// Reference: a FiniteGP over a PosteriorGP goes through the generic path — mean_and_cov(fx) (src/finite_gp_projection.jl:133-136
+// on top of src/exact_gpr_posterior.jl:78-83), cholesky (:308 / :235), logdet + _sqmahal (:310, :325-326) or m + C.U'ξ (:236).
+// TC = compute type of the N*×N* side (the posterior's dtype; always fp64 for VFE), TIO = host array type.
+// ------------------------------------------------------------------------------------------------
+template <typename TC> struct Joint {
+    void* C = nullptr;  // (nsp + R + 128) × ld, row-major lower triangle of cov(f_post, x*) + Σy*, identity padding; R RHS rows
+    long ns = 0, nsp = 0, ld = 0, R = 0;
+    std::vector<double> mean;  // m(x*) + K_*· α  (host)
+};
+
+template <typename TC, typename TIO>
+static void noise_to(const gp_noise* noise, long ns, long nsp, std::vector<TC>& out) {
+    out.assign((size_t)nsp, TC(0));
+    if (!noise) return;
+    for (long i = 0; i < ns; ++i) out[i] = noise->kind == 0 ? (TC)noise->s : (TC)((const TIO*)noise->diag)[i];
+}
+
+template <typename T>
+static int32_t post_joint(gp_post* post, const gp_points* xs, const void* pm, const gp_noise* noise, long R, DevBufs& bufs,
+                          Joint<T>& J) {
+    gp_ctx* c = post->ctx;
+    SkScope sk(c);
+    const long n = post->n, np = post->np, ld = post->ld;
+    const long ns = xs->n, nsp = round_up(ns, 128);
+    const int d = post->d;
+    gp_kernel k{};
+    k.kind = post->kind; k.dtype = post->dtype; k.variance = post->variance; k.nscale = post->nscale;
+    k.scale = post->scale.empty() ? nullptr : post->scale.data();
+    std::vector<T> xs_h, nz_h;
+    scale_points<T>(&k, xs, nsp, xs_h);
+    noise_to<T, T>(noise, ns, nsp, nz_h);
+    const long ldx = np + c->ldpad, ldc = nsp + c->ldpad;
+    void *xs_v = 0, *m_v = 0, *X_v = 0, *nz_v = 0;
+    RC(bufs.get(sizeof(T) * (size_t)d * nsp, &xs_v));
+    RC(bufs.get(sizeof(T) * (size_t)nsp, &m_v));
+    RC(bufs.get(sizeof(T) * (size_t)nsp, &nz_v));
+    RC(bufs.get(sizeof(T) * (size_t)(nsp + 128) * ldx, &X_v));
+    RC(bufs.get(sizeof(T) * (size_t)(nsp + R + 128) * ldc, &J.C));
+    J.ns = ns; J.nsp = nsp; J.ld = ldc; J.R = R;
+    T* X = (T*)X_v;
+    T* Cm = (T*)J.C;
+    hipStream_t s = c->sm;
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    std::vector<T> m_h((size_t)ns);
+    HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), sizeof(T) * (size_t)d * nsp, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(nz_v, nz_h.data(), sizeof(T) * (size_t)nsp, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kvec_kernel<T>, dim3((unsigned)ns), dim3(256), 0, s, (const T*)xs_v, nsp, (const T*)post->xs, np, d,
+                       post->kind, (T)post->variance, n, (const T*)post->alpha, (T*)m_v);                       // K_*x α
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(m_h.data(), m_v, sizeof(T) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    {
+        GridMap g = plain_map(0, 0, 0);
+        dim3 grid((unsigned)(np / 128), (unsigned)(nsp / 128));
+        hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, X, ldx, (const T*)xs_v, nsp, (const T*)post->xs, np, d,
+                           post->kind, (T)post->variance, (const T*)nullptr, ns, n, 0, g, (const T*)nullptr, (const T*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    RC(trsm_rec<T>(c, s, X, ldx, nsp, (const T*)post->A, ld, np));                                             // V ᵀ = K_*x L⁻ᵀ
+    {
+        GridMap g = plain_map(1, 0, 0);
+        dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
+        hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, Cm, ldc, (const T*)xs_v, nsp, (const T*)xs_v, nsp, d,
+                           post->kind, (T)post->variance, (const T*)nz_v, ns, ns, 1, g, (const T*)nullptr, (const T*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemsetAsync(Cm + nsp * ldc, 0, sizeof(T) * (size_t)(R + 128) * ldc, s));
+    RC(launch_gemm<T>(c, s, Cm, ldc, X, ldx, X, ldx, nsp, nsp, np, plain_map(1, 0, 0)));                       // K** + Σy* − VᵀV
+    HIPCHK(hipStreamSynchronize(s));
+    const T* prior_mean = (const T*)pm;
+    J.mean.resize((size_t)ns);
+    for (long i = 0; i < ns; ++i) J.mean[i] = (double)(prior_mean ? prior_mean[i] : T(0)) + (double)m_h[i];
+    return 0;
+}
+
+// logpdf of Y (ns × ncols column-major host, leading dimension ldy) under N(J.mean, J.C): factor J.C in place with δ rows riding along
+template <typename TC, typename TIO>
+static int32_t joint_logpdf(gp_ctx* c, Joint<TC>& J, const void* Yv, long ldy, int ncols, void* outv) {
+    const long ns = J.ns, nsp = J.nsp, ld = J.ld;
+    TC* Cm = (TC*)J.C;
+    hipStream_t s = c->sm;
+    const TIO* Y = (const TIO*)Yv;
+    if (!c->info_dev) HIPCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    RC(ctx_scal(c, 8 + J.R));
+    std::vector<TC> rhs((size_t)ncols * nsp, TC(0));
+    for (int q = 0; q < ncols; ++q)
+        for (long i = 0; i < ns; ++i) rhs[(size_t)q * nsp + i] = (TC)((double)Y[(size_t)q * ldy + i] - J.mean[i]);
+    int info_h = 0;
+    std::vector<double> scal_h(8 + ncols);
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), s));
+        HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * (8 + J.R), s));
+        HIPCHK(hipMemcpy2DAsync(Cm + nsp * ld, sizeof(TC) * ld, rhs.data(), sizeof(TC) * nsp, sizeof(TC) * nsp, ncols,
+                                hipMemcpyHostToDevice, s));
+        RC(potrf_full<TC>(c, Cm, ld, nsp, nsp + J.R, c->info_dev, ns, c->scal_dev));
+        hipLaunchKernelGGL(rowsumsq_kernel<TC>, dim3((unsigned)ncols), dim3(256), 0, s, Cm + nsp * ld, ld, nsp, c->scal_dev + 8);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(scal_h.data(), c->scal_dev, sizeof(double) * (8 + ncols), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        (void)hipStreamSynchronize(c->sp);
+        return rc;
+    }
+    if (info_h != 0) return info_h;
+    for (int q = 0; q < ncols; ++q)
+        ((TIO*)outv)[q] = (TIO)(-0.5 * ((double)ns * LOG2PI + 2.0 * scal_h[0] + scal_h[8 + q]));
+    return 0;
+}
+
+// out[:, q] = J.mean + chol(J.C)ᵀ-factor product with xi[:, q]  (ns × ncols column-major host arrays, leading dimension ns)
+template <typename TC, typename TIO>
+static int32_t joint_rand(gp_ctx* c, Joint<TC>& J, DevBufs& bufs, const void* xiv, int ncols, void* outv) {
+    const long ns = J.ns, nsp = J.nsp, ld = J.ld;
+    TC* Cm = (TC*)J.C;
+    hipStream_t s = c->sm;
+    const TIO* xi = (const TIO*)xiv;
+    if (!c->info_dev) HIPCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    RC(ctx_scal(c, 16));
+    std::vector<TC> in_h((size_t)ncols * nsp, TC(0)), out_h((size_t)ncols * nsp);
+    for (int q = 0; q < ncols; ++q)
+        for (long i = 0; i < ns; ++i) in_h[(size_t)q * nsp + i] = (TC)xi[(size_t)q * ns + i];
+    void *in_v = 0, *out_v = 0;
+    const size_t b = sizeof(TC) * (size_t)nsp * ncols;
+    RC(bufs.get(b, &in_v));
+    RC(bufs.get(b, &out_v));
+    int info_h = 0;
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), s));
+        HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * 16, s));
+        HIPCHK(hipMemcpyAsync(in_v, in_h.data(), b, hipMemcpyHostToDevice, s));
+        RC(potrf_full<TC>(c, Cm, ld, nsp, nsp, c->info_dev, ns, c->scal_dev));
+        hipLaunchKernelGGL(trmv_lower_kernel<TC>, dim3((unsigned)ns), dim3(256), 0, s, (const TC*)Cm, ld, (const TC*)in_v, nsp, ncols,
+                           (TC*)out_v);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out_h.data(), out_v, b, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        (void)hipStreamSynchronize(c->sp);
+        return rc;
+    }
+    if (info_h != 0) return info_h;
+    for (int q = 0; q < ncols; ++q)
+        for (long i = 0; i < ns; ++i) ((TIO*)outv)[(size_t)q * ns + i] = (TIO)(J.mean[i] + (double)out_h[(size_t)q * nsp + i]);
+    return 0;
 }
 
 #include "vfe.hpp"
@@ -1225,7 +1423,19 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
+    else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
+    else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else return set_arg_err(2, "unknown parameter");
+    return 0;
+}
+
+int32_t gp_ctx_trim(gp_ctx* c) {
+    Guard gd(c);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_ctx");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->sm);
+    (void)hipStreamSynchronize(c->sp);
+    while (!c->pool.empty()) pool_drop(c, c->pool.size() - 1);
     return 0;
 }
 
@@ -1259,9 +1469,10 @@ int32_t gp_kernelmatrix(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
         if (y) scale_points<T>(k, y, mp, xr_h);
         void *xc_v = nullptr, *xr_v = nullptr, *K_v = nullptr;
         const size_t xcb = sizeof(T) * xc_h.size(), xrb = sizeof(T) * xr_h.size(), Kb = sizeof(T) * (size_t)mp * ld;
-        RC(ctx_alloc(c, xcb, &xc_v));
-        if (y) RC(ctx_alloc(c, xrb, &xr_v));
-        RC(ctx_alloc(c, Kb, &K_v));
+        DevBufs bufs(c);
+        RC(bufs.get(xcb, &xc_v));
+        if (y) RC(bufs.get(xrb, &xr_v));
+        RC(bufs.get(Kb, &K_v));
         int32_t rc = [&]() -> int32_t {
             HIPCHK(hipMemcpyAsync(xc_v, xc_h.data(), xcb, hipMemcpyHostToDevice, c->sm));
             if (y) HIPCHK(hipMemcpyAsync(xr_v, xr_h.data(), xrb, hipMemcpyHostToDevice, c->sm));
@@ -1277,9 +1488,6 @@ int32_t gp_kernelmatrix(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
             return 0;
         }();
         if (rc != 0) (void)hipStreamSynchronize(c->sm);
-        ctx_release(c, xc_v, xcb);
-        ctx_release(c, xr_v, xrb);
-        ctx_release(c, K_v, Kb);
         return rc;
     };
     return k->dtype == 0 ? run(double()) : run(float());
@@ -1344,15 +1552,15 @@ int32_t gp_posterior_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
 
 int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm, int32_t what, void* mean_out,
                              void* var_out, void* cov_out) {
-    if (!post || !reg_has(post)) return set_arg_err(1, "not a live gp_post");
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
     RC(check_points(xs, 2));
     if (xs->d != post->d) return set_arg_err(2, "xs has a different D than the training inputs");
     if (what <= 0 || what > 7) return set_arg_err(4, "what must be a combination of 1|2|4");
     if ((what & 1) && !mean_out) return set_arg_err(5, "mean_out is NULL");
     if ((what & 2) && !var_out) return set_arg_err(6, "var_out is NULL");
     if ((what & 4) && !cov_out) return set_arg_err(7, "cov_out is NULL");
-    gp_ctx* c = post->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
     return post->dtype == 0 ? predict_impl<double>(post, xs, pm, what, mean_out, var_out, cov_out)
                             : predict_impl<float>(post, xs, pm, what, mean_out, var_out, cov_out);
@@ -1371,7 +1579,8 @@ int32_t gp_logpdf_grad(gp_ctx* c, const gp_kernel* k, const gp_points* x, const 
 
 int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post** out,
                             void* alpha_out, void* logpdf_out) {
-    if (!old || !reg_has(old)) return set_arg_err(1, "not a live gp_post");
+    Guard gd(old);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
     RC(check_points(x2, 2));
     if (x2->d != old->d) return set_arg_err(2, "x2 has a different D than the training inputs");
     if (!noise2 || (noise2->kind != 0 && noise2->kind != 1) || (noise2->kind == 1 && !noise2->diag))
@@ -1379,8 +1588,7 @@ int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* n
     if (!delta_all) return set_arg_err(4, "delta_all is NULL");
     if (!out) return set_arg_err(5, "out is NULL");
     *out = nullptr;
-    gp_ctx* c = old->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
     gp_post* p = new gp_post();
     double lp = 0;
@@ -1401,26 +1609,27 @@ int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* n
 }
 
 int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, void* out) {
-    if (!post || !reg_has(post)) return set_arg_err(1, "not a live gp_post");
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
     if (!xi) return set_arg_err(2, "xi is NULL");
     if (ncols < 1) return set_arg_err(3, "ncols must be >= 1");
     if (!out) return set_arg_err(4, "out is NULL");
-    gp_ctx* c = post->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
     return post->dtype == 0 ? factor_mul_impl<double>(post, xi, ncols, out) : factor_mul_impl<float>(post, xi, ncols, out);
 }
 
 int64_t gp_posterior_n(gp_post* post) {
-    if (!post || !reg_has(post)) return -1;
+    Guard gd(post);
+    if (!gd.ok) return -1;
     return post->n;
 }
 
 int32_t gp_posterior_get_factor(gp_post* post, void* U_out) {
-    if (!post || !reg_has(post)) return set_arg_err(1, "not a live gp_post");
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
     if (!U_out) return set_arg_err(2, "U_out is NULL");
-    gp_ctx* c = post->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
     const size_t es = post->dtype == 0 ? 8 : 4;
     const long n = post->n;
@@ -1436,15 +1645,15 @@ int32_t gp_posterior_get_factor(gp_post* post, void* U_out) {
 
 int32_t gp_posterior_free(gp_post* post) {
     if (!post || !reg_take(post)) return set_arg_err(1, "not a live gp_post");
-    gp_ctx* c = post->ctx;
+    gp_ctx* c = post->ctx;  // the handle holds a reference on its ctx: c is alive
     {
-        std::lock_guard<std::mutex> l(c->mu);
+        std::lock_guard<std::mutex> l(c->mu);  // waits for any call still using the handle (Guard re-checks the registry under this lock)
         (void)hipSetDevice(c->device);
         ctx_release(c, post->A, post->A_bytes);
         ctx_release(c, post->xs, post->xs_bytes);
         ctx_release(c, post->alpha, post->alpha_bytes);
+        delete post;
     }
-    delete post;
     ctx_unref(c);
     return 0;
 }
@@ -1484,7 +1693,8 @@ int32_t gp_vfe_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_p
 
 int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, const void* mean2, const void* y2, gp_vfe** out,
                       void* objective_out) {
-    if (!old || !reg_has(old)) return set_arg_err(1, "not a live gp_vfe");
+    Guard gd(old);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
     RC(check_points(x2, 2));
     if (x2->d != old->d) return set_arg_err(2, "x2 has a different D than the training inputs");
     if (!noise2 || (noise2->kind != 0 && noise2->kind != 1) || (noise2->kind == 1 && !noise2->diag))
@@ -1492,8 +1702,7 @@ int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, 
     if (!y2) return set_arg_err(5, "y2 is NULL");
     if (!out) return set_arg_err(6, "out is NULL");
     *out = nullptr;
-    gp_ctx* c = old->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
     gp_kernel k{};
     k.kind = old->kind; k.dtype = old->dtype; k.variance = old->variance; k.nscale = old->nscale;
@@ -1501,8 +1710,9 @@ int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, 
     gp_vfe* p = new gp_vfe();
     p->ctx = c;
     double obj = 0;
-    int32_t rc = old->dtype == 0 ? vfe_fit_impl<double>(c, &k, x2, nullptr, noise2, 0.0, mean2, y2, old->approx, p, &obj, old)
-                                 : vfe_fit_impl<float>(c, &k, x2, nullptr, noise2, 0.0, mean2, y2, old->approx, p, &obj, old);
+    int32_t rc = old->dtype == 0
+                     ? vfe_fit_impl<double>(c, &k, x2, nullptr, noise2, 0.0, mean2, y2, old->approx, p, &obj, old, VFE_UPDATE)
+                     : vfe_fit_impl<float>(c, &k, x2, nullptr, noise2, 0.0, mean2, y2, old->approx, p, &obj, old, VFE_UPDATE);
     if (rc != 0) {
         delete p;
         return rc;
@@ -1517,27 +1727,107 @@ int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, 
     return 0;
 }
 
-int32_t gp_vfe_predict(gp_vfe* p, const gp_points* xs, const void* pm, int32_t what, void* mean_out, void* var_out) {
-    if (!p || !reg_has(p)) return set_arg_err(1, "not a live gp_vfe");
+int32_t gp_vfe_append(gp_vfe* old, const gp_points* z2, gp_vfe** out, void* objective_out) {
+    Guard gd(old);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    RC(check_points(z2, 2));
+    if (z2->d != old->d) return set_arg_err(2, "z2 has a different D than the pseudo-points");
+    if (!out) return set_arg_err(3, "out is NULL");
+    *out = nullptr;
+    if (old->segs.empty()) return set_arg_err(1, "gp_vfe holds no observations");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    gp_kernel k{};
+    k.kind = old->kind; k.dtype = old->dtype; k.variance = old->variance; k.nscale = old->nscale;
+    k.scale = old->scale.empty() ? nullptr : old->scale.data();
+    gp_vfe* p = new gp_vfe();
+    p->ctx = c;
+    double obj = 0;
+    int32_t rc = old->dtype == 0
+                     ? vfe_fit_impl<double>(c, &k, nullptr, z2, nullptr, 0.0, nullptr, nullptr, old->approx, p, &obj, old, VFE_APPEND)
+                     : vfe_fit_impl<float>(c, &k, nullptr, z2, nullptr, 0.0, nullptr, nullptr, old->approx, p, &obj, old, VFE_APPEND);
+    if (rc != 0) {
+        delete p;
+        return rc;
+    }
+    if (objective_out) {
+        if (old->dtype == 0) *(double*)objective_out = obj;
+        else *(float*)objective_out = (float)obj;
+    }
+    c->refs++;
+    reg_add(p);
+    *out = p;
+    return 0;
+}
+
+int32_t gp_vfe_predict(gp_vfe* p, const gp_points* xs, const void* pm, int32_t what, void* mean_out, void* var_out, void* cov_out) {
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
     RC(check_points(xs, 2));
     if (xs->d != p->d) return set_arg_err(2, "xs has a different D than the training inputs");
-    if (what <= 0 || what > 3) return set_arg_err(4, "what must be a combination of 1|2");
+    if (what <= 0 || what > 7) return set_arg_err(4, "what must be a combination of 1|2|4");
     if ((what & 1) && !mean_out) return set_arg_err(5, "mean_out is NULL");
     if ((what & 2) && !var_out) return set_arg_err(6, "var_out is NULL");
-    gp_ctx* c = p->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    if ((what & 4) && !cov_out) return set_arg_err(7, "cov_out is NULL");
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
-    return p->dtype == 0 ? vfe_predict_impl<double>(p, xs, pm, what, mean_out, var_out)
-                         : vfe_predict_impl<float>(p, xs, pm, what, mean_out, var_out);
+    return p->dtype == 0 ? vfe_predict_impl<double>(p, xs, pm, what, mean_out, var_out, cov_out)
+                         : vfe_predict_impl<float>(p, xs, pm, what, mean_out, var_out, cov_out);
+}
+
+static int32_t check_joint_args(const gp_points* xs, int d, const gp_noise* noise) {
+    RC(check_points(xs, 2));
+    if (xs->d != d) return set_arg_err(2, "xs has a different D than the training inputs");
+    if (!noise || (noise->kind != 0 && noise->kind != 1) || (noise->kind == 1 && !noise->diag)) return set_arg_err(4, "bad noise");
+    return 0;
+}
+
+int32_t gp_vfe_logpdf(gp_vfe* p, const gp_points* xs, const void* pm, const gp_noise* noise, const void* Y, int64_t ldy,
+                      int32_t ncols, void* out) {
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    RC(check_joint_args(xs, p->d, noise));
+    if (!Y) return set_arg_err(5, "Y is NULL");
+    if (ldy < xs->n) return set_arg_err(6, "ldy < n");
+    if (ncols < 1) return set_arg_err(7, "ncols must be >= 1");
+    if (!out) return set_arg_err(8, "out is NULL");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    DevBufs bufs(c);
+    Joint<double> J;
+    const long R = round_up(ncols, 128);
+    int32_t rc = p->dtype == 0 ? vfe_joint<double>(p, xs, pm, noise, R, bufs, J) : vfe_joint<float>(p, xs, pm, noise, R, bufs, J);
+    if (rc == 0)
+        rc = p->dtype == 0 ? joint_logpdf<double, double>(c, J, Y, ldy, ncols, out) : joint_logpdf<double, float>(c, J, Y, ldy, ncols, out);
+    if (rc < 0) (void)hipStreamSynchronize(c->sm);
+    return rc;
+}
+
+int32_t gp_vfe_rand(gp_vfe* p, const gp_points* xs, const void* pm, const gp_noise* noise, const void* xi, int32_t ncols, void* out) {
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    RC(check_joint_args(xs, p->d, noise));
+    if (!xi) return set_arg_err(5, "xi is NULL");
+    if (ncols < 1) return set_arg_err(6, "ncols must be >= 1");
+    if (!out) return set_arg_err(7, "out is NULL");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    DevBufs bufs(c);
+    Joint<double> J;
+    int32_t rc = p->dtype == 0 ? vfe_joint<double>(p, xs, pm, noise, 0, bufs, J) : vfe_joint<float>(p, xs, pm, noise, 0, bufs, J);
+    if (rc == 0)
+        rc = p->dtype == 0 ? joint_rand<double, double>(c, J, bufs, xi, ncols, out) : joint_rand<double, float>(c, J, bufs, xi, ncols, out);
+    if (rc < 0) (void)hipStreamSynchronize(c->sm);
+    return rc;
 }
 
 int32_t gp_vfe_get(gp_vfe* p, void* alpha_out, void* meps_out) {
-    if (!p || !reg_has(p)) return set_arg_err(1, "not a live gp_vfe");
-    gp_ctx* c = p->ctx;
-    std::lock_guard<std::mutex> l(c->mu);
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
     std::vector<double> h((size_t)p->mp * 3);
-    HIPCHK(hipMemcpy(h.data(), p->alpha, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h.data(), p->vec, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
     for (long i = 0; i < p->m; ++i) {
         if (alpha_out) {
             if (p->dtype == 0) ((double*)alpha_out)[i] = h[2 * p->mp + i];
@@ -1551,24 +1841,76 @@ int32_t gp_vfe_get(gp_vfe* p, void* alpha_out, void* meps_out) {
     return 0;
 }
 
+int64_t gp_vfe_m(gp_vfe* p) {
+    Guard gd(p);
+    if (!gd.ok) return -1;
+    return p->m;
+}
+
 int32_t gp_vfe_free(gp_vfe* p) {
     if (!p || !reg_take(p)) return set_arg_err(1, "not a live gp_vfe");
     gp_ctx* c = p->ctx;
     {
         std::lock_guard<std::mutex> l(c->mu);
         (void)hipSetDevice(c->device);
-        ctx_release(c, p->Lz, p->L_bytes);
-        ctx_release(c, p->Ld, p->L_bytes);
-        ctx_release(c, p->zs, p->zs_bytes);
-        ctx_release(c, p->alpha, p->vec_bytes);
-        ctx_release(c, p->Dacc, p->D_bytes);
-        ctx_release(c, p->cacc, p->c_bytes);
-        ctx_release(c, p->Li, p->Li_bytes);
-        ctx_release(c, p->zsT, p->zsT_bytes);
+        vfe_release(p);
+        delete p;
     }
-    delete p;
     ctx_unref(c);
     return 0;
+}
+
+// ---- joint predictive logpdf / rand of an exact posterior --------------------------------------------------
+int32_t gp_posterior_logpdf(gp_post* post, const gp_points* xs, const void* pm, const gp_noise* noise, const void* Y, int64_t ldy,
+                            int32_t ncols, void* out) {
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
+    RC(check_joint_args(xs, post->d, noise));
+    if (!Y) return set_arg_err(5, "Y is NULL");
+    if (ldy < xs->n) return set_arg_err(6, "ldy < n");
+    if (ncols < 1) return set_arg_err(7, "ncols must be >= 1");
+    if (!out) return set_arg_err(8, "out is NULL");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    DevBufs bufs(c);
+    const long R = round_up(ncols, 128);
+    int32_t rc;
+    if (post->dtype == 0) {
+        Joint<double> J;
+        rc = post_joint<double>(post, xs, pm, noise, R, bufs, J);
+        if (rc == 0) rc = joint_logpdf<double, double>(c, J, Y, ldy, ncols, out);
+    } else {
+        Joint<float> J;
+        rc = post_joint<float>(post, xs, pm, noise, R, bufs, J);
+        if (rc == 0) rc = joint_logpdf<float, float>(c, J, Y, ldy, ncols, out);
+    }
+    if (rc < 0) (void)hipStreamSynchronize(c->sm);
+    return rc;
+}
+
+int32_t gp_posterior_rand(gp_post* post, const gp_points* xs, const void* pm, const gp_noise* noise, const void* xi, int32_t ncols,
+                          void* out) {
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
+    RC(check_joint_args(xs, post->d, noise));
+    if (!xi) return set_arg_err(5, "xi is NULL");
+    if (ncols < 1) return set_arg_err(6, "ncols must be >= 1");
+    if (!out) return set_arg_err(7, "out is NULL");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    DevBufs bufs(c);
+    int32_t rc;
+    if (post->dtype == 0) {
+        Joint<double> J;
+        rc = post_joint<double>(post, xs, pm, noise, 0, bufs, J);
+        if (rc == 0) rc = joint_rand<double, double>(c, J, bufs, xi, ncols, out);
+    } else {
+        Joint<float> J;
+        rc = post_joint<float>(post, xs, pm, noise, 0, bufs, J);
+        if (rc == 0) rc = joint_rand<float, float>(c, J, bufs, xi, ncols, out);
+    }
+    if (rc < 0) (void)hipStreamSynchronize(c->sm);
+    return rc;
 }
 
 // ---- microbenchmarks / probes (tools/gpu_diag.py) ------------------------------------------------

@@ -75,6 +75,7 @@ struct GridMap {
                      // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
     int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
     long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
+    int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
 };
 // compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
 __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     const int sw = (li >> 1) & 7;
     const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
     int nk = K / BK;
-    if (g.ktri == 1) nk = min(nk, (m0 + 128) / BK);
+    if (g.ktri == 1) nk = min(nk, (g.ktri_off + m0 + 128) / BK);
     dma_wait_barrier();
 
     for (int kt = kt0; kt < nk; ++kt) {
@@ -1760,6 +1761,59 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const T* __restrict__ L, lo
     RT acc = 0;
     for (long i = i0; i < i1; ++i) acc = fma((RT)L[i * ldl + j], (RT)a[i], acc);
     atomicAdd(r + j, -acc);
+}
+
+// dst[i][j] += Σ_b (double) S[b·cstride + i·lds + j]  for row_lo <= i < n, j <= i: the split-K partial products of one chunk's
+// fp32 SYRK summed into the fp64 accumulator in ONE pass (was one launch per partial)
+template <typename T>
+__global__ __launch_bounds__(256) void add_lower_batched_kernel(const T* __restrict__ S, long cstride, int nbatch, long lds,
+                                                                 double* __restrict__ dst, long ldd, long n, long row_lo) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x, i = row_lo + blockIdx.y;
+    if (j > i || j >= n) return;
+    double acc = 0;
+    for (int b = 0; b < nbatch; ++b) acc += (double)S[(long)b * cstride + i * lds + j];
+    dst[i * ldd + j] += acc;
+}
+// One pass over row (row_lo + blockIdx.x) of Y = −B_c:  rowss[row] += Σ_c Y²  (‖B‖²_F per inducing row, fp64) and
+// cacc[row] −= Σ_c Y·b  (c = B b_y)                                         src/sparse_approximations.jl:66-71, 251
+template <typename T>
+__global__ __launch_bounds__(256) void ystats_kernel(const T* __restrict__ Y, long ldy, long ncols, const T* __restrict__ b,
+                                                      long row_lo, double* __restrict__ cacc, double* __restrict__ rowss) {
+    __shared__ double red[2][4];
+    const long row = row_lo + blockIdx.x;
+    const T* y = Y + row * ldy;
+    double ss = 0, dot = 0;
+    for (long c = threadIdx.x; c < ncols; c += 256) {
+        const double v = (double)y[c];
+        ss = fma(v, v, ss);
+        dot = fma(v, (double)b[c], dot);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o, 64);
+        dot += __shfl_xor(dot, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = ss;
+        red[1][threadIdx.x >> 6] = dot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rowss[row] += red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        cacc[row] -= red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+// A[i][i] += v[i] for i < n   (Σy* on the diagonal of a predictive covariance, src/finite_gp_projection.jl:133-136)
+template <typename T>
+__global__ __launch_bounds__(256) void diag_add_kernel(T* __restrict__ A, long lda, const T* __restrict__ v, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[i * lda + i] += v[i];
+}
+// out[s][i] += m[i] for i < n  (rows of length ldv)
+template <typename T>
+__global__ __launch_bounds__(256) void add_rowvec_kernel(T* __restrict__ out, long ldv, const T* __restrict__ m, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[(long)blockIdx.y * ldv + i] += m[i];
 }
 
 // MFMA layout / rate probe: D = A·B for one 16×16×4 tile (A row-major 16×4, B row-major 4×16).

@@ -1,8 +1,9 @@
 // vfe.hpp — VFE / DTC sparse approximation on the device (included by gpmi355.hip).
 //
 // Reference: posterior(::Union{VFE,DTC}, fx, y)      src/sparse_approximations.jl:58-75
+//            update_posterior (new observations)      :87-121      update_posterior (new pseudo-points)  :131-176
 //            approx_log_evidence / elbo              :248-254 (VFE), :282-286 (DTC), :289-305
-//            predictive mean / var                   :183-185, :192-195, :212-217
+//            predictive mean / cov / var / joint      :183-217
 //
 // Formulation (S = Σy^-1/2 diagonal, L_z L_zᵀ = K_zz + jitter·I, so U = L_zᵀ), the reference's own:
 //   B = U⁻ᵀ (S K_xz)ᵀ,  D = B Bᵀ + I = Λ_ε,  c = B b_y,  m_ε = Λ_ε \ c,  α = U \ m_ε.
@@ -12,49 +13,86 @@
 //     Xc  = S_c K(x_c, z)                   kmat with a row scale          (CH × M, dtype T)
 //     Y   = −inv(L_z) Xcᵀ = −B_c            gemm_nt_dma, beta0 + ktri      (M × CH, data points contiguous)
 //     D_acc −= Y Yᵀ                         MFMA gemm (NT), fp64 accumulation (SYRK over the data points)
-//     c_acc −= Y b_c                        rowdot_sub
+//     c_acc −= Y b_c,  rowss += rowsumsq(Y) ystats (one pass over Y)
 //   (T = f32 or f64).  The M×M side (K_zz, both Choleskys, all vector solves) is always fp64, and so are the
 //   accumulators of the N-long reductions (D_acc, c_acc, ‖B‖²_F): in fp32 mode the operands stream in fp32 through
-//   the fp32 MFMA, whose chain is flushed into fp64 every 256 data points; L_z is rounded to fp32 for the streamed
-//   TRSM only.  ‖A‖²_F = tr(B Bᵀ) = −tr(D_acc) (ELBO trace term, :251).
+//   the fp32 MFMA in K = 2 048 partial products that are summed into the fp64 accumulator; L_z is rounded to fp32 for
+//   the streamed TRSM only.  ‖A‖²_F = tr(B Bᵀ) = Σ rowss (ELBO trace term, :251).
+//
+// The handle keeps what the reference keeps in its cache (:73, :118): the scaled observations x, Σy^-1/2 and b_y (small
+// N-vectors; B_εf itself is never stored), so that both update_posterior forms continue from the resident state:
+//   new observations   -> stream only the new points into D_acc / c_acc / rowss, re-finalise the M×M side
+//   new pseudo-points  -> bordered Cholesky of K_zz (update_chol, src/util/common_covmat_ops.jl:38-42), then re-stream
+//                         the retained observations computing ONLY the new block rows of B Bᵀ, B b_y and ‖B‖²
 #pragma once
 
-struct gp_vfe {
-    gp_ctx* ctx;
-    int dtype;
-    long m, mp, ld;
-    int d, kind;
-    double variance;
-    int nscale;
-    std::vector<double> scale;
-    void *Lz, *Ld;  // mp × ld doubles (+128 slack rows)
-    size_t L_bytes;
-    void* zs;  // scaled inducing inputs, double [d][mp]
-    size_t zs_bytes;
-    void *alpha, *meps;  // double [mp]
-    size_t vec_bytes;
-    // streaming state kept for update_posterior (new observations, src/sparse_approximations.jl:87-121): the accumulators
-    // of the N-long reductions before the M×M finalisation, and what the chunk loop needs (inv(L_z), scaled z in T)
-    int approx;
-    long n_obs;
-    void *Dacc, *cacc, *Li, *zsT;
-    size_t D_bytes, c_bytes, Li_bytes, zsT_bytes;
-    double logdet_sy, dd, tr_kff, trZ;
+struct ObsSeg {  // one batch of observations, device resident: T xs[d][npad] (scaled), T rs[npad] = σ⁻¹, T b[npad] = σ⁻¹δ
+    gp_ctx* ctx = nullptr;
+    void *xs = nullptr, *rs = nullptr, *b = nullptr;
+    long n = 0, npad = 0;
+    ~ObsSeg() {  // runs under the ctx lock (gp_vfe_free / error paths of a locked call)
+        ctx_release(ctx, xs, 0);
+        ctx_release(ctx, rs, 0);
+        ctx_release(ctx, b, 0);
+    }
 };
 
+struct gp_vfe {
+    gp_ctx* ctx = nullptr;
+    int dtype = 0;
+    long m = 0, mp = 0, ld = 0;
+    int d = 0, kind = 0;
+    double variance = 1, jitter = 0;
+    int nscale = 0;
+    std::vector<double> scale;
+    void *Lz = nullptr, *Ld = nullptr;  // (mp + 256) × ld doubles: chol(K_zz + jitter I), Λ_ε factor
+    void* zs = nullptr;                 // scaled inducing inputs, double [d][mp]
+    void* vec = nullptr;                // double [4][mp]: rows c, m_ε, α, spare
+    int approx = 0;
+    long n_obs = 0;
+    // streaming state before the M×M finalisation: −B Bᵀ (lower), B b_y, per-row ‖B‖², inv(L_z) and scaled z in T
+    void *Dacc = nullptr, *cacc = nullptr, *rowss = nullptr, *Li = nullptr, *zsT = nullptr;
+    std::vector<std::shared_ptr<ObsSeg>> segs;  // every observation seen so far (shared between a posterior and its updates)
+    double logdet_sy = 0, dd = 0, tr_kff = 0, trZ = 0;
+};
+
+static void vfe_release(gp_vfe* p) {  // under the ctx lock
+    gp_ctx* c = p->ctx;
+    ctx_release(c, p->Lz, 0);
+    ctx_release(c, p->Ld, 0);
+    ctx_release(c, p->zs, 0);
+    ctx_release(c, p->vec, 0);
+    ctx_release(c, p->Dacc, 0);
+    ctx_release(c, p->cacc, 0);
+    ctx_release(c, p->rowss, 0);
+    ctx_release(c, p->Li, 0);
+    ctx_release(c, p->zsT, 0);
+    p->segs.clear();
+}
+
+enum { VFE_FIT = 0, VFE_UPDATE = 1, VFE_APPEND = 2 };
+
+// mode VFE_FIT:    x, y, noise, z, jitter given; prev == NULL
+// mode VFE_UPDATE: x, y, noise = the NEW observations; z == NULL; kernel / jitter / z from prev
+// mode VFE_APPEND: z = the NEW pseudo-points; x == NULL; everything else from prev
 template <typename T>
 static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_points* z, const gp_noise* noise,
                             double jitter, const void* mean_or_null, const void* yv, int approx, gp_vfe* out,
-                            double* objective, const gp_vfe* prev = nullptr) {
-    // prev != NULL: continue the streamed reductions of an existing fit with the new observations (x, y) — z, k, jitter
-    // are then taken from prev (z == NULL)
-    const long n = x->n, m = prev ? prev->m : z->n, mp = round_up(m, 128);
-    const int d = x->d;
-    const long CH = 8192;                       // columns (data points) per streamed chunk
-    const long npad = round_up(n, CH);
+                            double* objective, const gp_vfe* prev = nullptr, int mode = VFE_FIT) {
+    const long m_old = prev ? prev->m : 0;
+    const long m2 = (mode == VFE_APPEND) ? z->n : 0;
+    const long m = mode == VFE_FIT ? z->n : m_old + m2;
+    const long mp = round_up(m, 128);
+    const int d = prev ? prev->d : x->d;
+    const long CH = c->vfe_chunk;               // data points per streamed chunk
+    constexpr long KS = 2048;                   // fp32: data points per fp32 partial product
+    const int NBAT = (int)(CH / KS);
+    const long n = x ? x->n : 0, npad = round_up(std::max(n, 1L), CH);
     const long ld = mp + c->ldpad;              // M×M matrices and the CH×M chunk
     const T* y = (const T*)yv;
     const T* mean = (const T*)mean_or_null;
+    constexpr bool is_f64 = sizeof(T) == 8;
+    if (prev) jitter = prev->jitter;
 
     c->ev_used = 0;
     c->gemm_recs.clear();
@@ -64,96 +102,207 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(ctx_scal(c, 16 + 128));
 
     // ---- host marshalling
-    std::vector<T> xs_h, zsT_h;
-    scale_points<T>(k, x, npad, xs_h);
-    if (!prev) scale_points<T>(k, z, mp, zsT_h);
-    else zsT_h.assign((size_t)d * mp, T(0));
-    std::vector<double> zsD_h(zsT_h.begin(), zsT_h.end());
-    std::vector<T> rs_h((size_t)npad, T(0)), b_h((size_t)npad, T(0));  // s_i = σ_i⁻¹ ; b_i = s_i δ_i  (b_y, :66)
+    std::vector<T> xs_h, znew_h;
     double logdet_sy = prev ? prev->logdet_sy : 0, dd = prev ? prev->dd : 0, tr_kff = prev ? prev->tr_kff : 0;
-    for (long i = 0; i < n; ++i) {
-        const double s2 = noise->kind == 0 ? noise->s : (double)((const T*)noise->diag)[i];
-        if (!(s2 > 0)) return 1 + (int32_t)i;  // chol(Σy) fails at i (reference :61 / :296)
-        const double delta = (double)(T)(y[i] - (mean ? mean[i] : T(0)));
-        const double si = 1.0 / std::sqrt(s2);
-        rs_h[i] = (T)si;
-        b_h[i] = (T)(delta * si);
-        logdet_sy += std::log(s2);
-        dd += (double)b_h[i] * (double)b_h[i];
-        tr_kff += k->variance / s2;  // tr_Cf_invΣy :307-313
+    std::vector<T> rs_h, b_h;
+    if (x) {
+        scale_points<T>(k, x, npad, xs_h);
+        rs_h.assign((size_t)npad, T(0));  // s_i = σ_i⁻¹
+        b_h.assign((size_t)npad, T(0));   // b_i = s_i δ_i  (b_y, :66)
+        for (long i = 0; i < n; ++i) {
+            const double s2 = noise->kind == 0 ? noise->s : (double)((const T*)noise->diag)[i];
+            if (!(s2 > 0)) return 1 + (int32_t)i;  // chol(Σy) fails at i (reference :61 / :296)
+            const double delta = (double)(T)(y[i] - (mean ? mean[i] : T(0)));
+            const double si = 1.0 / std::sqrt(s2);
+            rs_h[i] = (T)si;
+            b_h[i] = (T)(delta * si);
+            logdet_sy += std::log(s2);
+            dd += (double)b_h[i] * (double)b_h[i];
+            tr_kff += k->variance / s2;  // tr_Cf_invΣy :307-313
+        }
     }
+    const long m2p = round_up(std::max(m2, 1L), 128);
+    const long znp = mode == VFE_FIT ? mp : m2p;  // leading dimension of the freshly scaled inducing inputs
+    if (z) scale_points<T>(k, z, znp, znew_h);
+    std::vector<double> znewD_h(znew_h.begin(), znew_h.end());
     std::vector<double> jit_h((size_t)mp, 0.0);
     for (long i = 0; i < m; ++i) jit_h[i] = jitter;
 
-    const size_t xs_b = sizeof(T) * xs_h.size(), zsT_b = sizeof(T) * zsT_h.size(), zsD_b = sizeof(double) * zsD_h.size();
-    const size_t rs_b = sizeof(T) * (size_t)npad, D_b = sizeof(double) * (size_t)(mp + 128) * ld;
+    const size_t zsT_b = sizeof(T) * (size_t)d * mp, zsD_b = sizeof(double) * (size_t)d * mp;
+    const size_t D_b = sizeof(double) * (size_t)(mp + 128) * ld;
     const long ldy = CH + c->ldpad;             // Y = −B_c (M × CH)
     const size_t X_b = sizeof(T) * (size_t)(CH + 128) * ld, L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
     const size_t Y_b = sizeof(T) * (size_t)(mp + 128) * ldy, Li_b = sizeof(T) * (size_t)(mp + 128) * ld;
     const size_t vT_b = sizeof(double) * (size_t)mp, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
-    void *xs_v = 0, *zsT_v = 0, *zsD_v = 0, *rs_v = 0, *b_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *LzT_v = 0, *cT_v = 0,
-         *vec_v = 0, *jit_v = 0, *Y_v = 0, *Li_v = 0, *I_v = 0, *S_v = 0;
-    constexpr bool is_f64 = sizeof(T) == 8;
-    RC(ctx_alloc(c, xs_b, &xs_v));
-    RC(ctx_alloc(c, zsT_b, &zsT_v));
-    RC(ctx_alloc(c, zsD_b, &zsD_v));
-    RC(ctx_alloc(c, rs_b, &rs_v));
-    RC(ctx_alloc(c, rs_b, &b_v));
-    RC(ctx_alloc(c, D_b, &D_v));
-    RC(ctx_alloc(c, X_b, &X_v));
-    RC(ctx_alloc(c, L_b, &Lz_v));
-    RC(ctx_alloc(c, L_b, &Ld_v));
-    RC(ctx_alloc(c, Y_b, &Y_v));
-    RC(ctx_alloc(c, Li_b, &Li_v));
-    RC(ctx_alloc(c, L_b, &I_v));
-    if (!is_f64) RC(ctx_alloc(c, 4 * Li_b, &S_v));
-    RC(ctx_alloc(c, vT_b, &cT_v));
-    RC(ctx_alloc(c, vD_b, &vec_v));
-    RC(ctx_alloc(c, jit_b, &jit_v));
+    void *zsT_v = 0, *zsD_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *cT_v = 0, *rss_v = 0, *vec_v = 0, *jit_v = 0, *Y_v = 0,
+         *Li_v = 0, *I_v = 0, *S_v = 0, *zn_v = 0, *znD_v = 0;
+    DevBufs bufs(c);
+    std::shared_ptr<ObsSeg> seg;
+    if (x) {
+        seg = std::make_shared<ObsSeg>();
+        seg->ctx = c;
+        seg->n = n;
+        seg->npad = npad;
+        RC(ctx_alloc(c, sizeof(T) * xs_h.size(), &seg->xs));
+        RC(ctx_alloc(c, sizeof(T) * (size_t)npad, &seg->rs));
+        RC(ctx_alloc(c, sizeof(T) * (size_t)npad, &seg->b));
+    }
+    RC(bufs.get(zsT_b, &zsT_v));
+    RC(bufs.get(zsD_b, &zsD_v));
+    RC(bufs.get(D_b, &D_v));
+    RC(bufs.get(X_b, &X_v));
+    RC(bufs.get(L_b, &Lz_v));
+    RC(bufs.get(L_b, &Ld_v));
+    RC(bufs.get(Y_b, &Y_v));
+    RC(bufs.get(Li_b, &Li_v));
+    if (mode != VFE_UPDATE) RC(bufs.get(L_b, &I_v));
+    if (!is_f64) RC(bufs.get((size_t)NBAT * Li_b, &S_v));
+    RC(bufs.get(vT_b, &cT_v));
+    RC(bufs.get(vT_b, &rss_v));
+    RC(bufs.get(vD_b, &vec_v));
+    RC(bufs.get(jit_b, &jit_v));
+    if (z && mode == VFE_APPEND) {
+        RC(bufs.get(sizeof(T) * znew_h.size(), &zn_v));
+        RC(bufs.get(sizeof(double) * znewD_h.size(), &znD_v));
+    }
     double* Lz = (double*)Lz_v;
     double* Ld = (double*)Ld_v;
     double* vec = (double*)vec_v;  // rows: [0] c , [1] w→m_ε , [2] α , [3] spare
     double scal_h[16] = {0};
+    std::vector<double> rss_h((size_t)mp, 0.0);
     int info_h = 0;
     hipStream_t s = c->sm;
-    const double trZ_prev = prev ? prev->trZ : 0.0;
-    if (prev && prev->D_bytes != D_b) return set_arg_err(1, "stale gp_vfe state");
+    if (prev && mode == VFE_UPDATE && (prev->mp != mp || prev->ld != ld)) return set_arg_err(1, "stale gp_vfe state");
+    for (auto& sg : (prev ? prev->segs : std::vector<std::shared_ptr<ObsSeg>>()))
+        if (sg->npad % CH) return set_arg_err(1, "gp_vfe was built with a different vfe_chunk");
     const long n_all = (prev ? prev->n_obs : 0) + n;
+    // rows of D_acc / c_acc / rowss that the streamed pass (re)computes: everything for a fit / new observations (the
+    // accumulators continue), the block rows from the first new pseudo-point's 128-tile on for an append
+    const long row_lo = (mode == VFE_APPEND) ? (m_old / 128) * 128 : 0;
+
+    // one chunk loop over a batch of observations: rows >= row_lo of D_acc, c_acc, rowss
+    auto stream_seg = [&](const ObsSeg& sg) -> int32_t {
+        for (long c0 = 0; c0 < sg.npad; c0 += CH) {
+            if (c0 >= sg.n) break;  // nothing but padding in the remaining chunks
+            GridMap g = plain_map(0, c0, 0);
+            dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
+            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, (T*)X_v, ld, (const T*)sg.xs, sg.npad, (const T*)zsT_v, mp, d,
+                               k->kind, (T)k->variance, (const T*)nullptr, sg.n, m, 0, g, (const T*)nullptr, (const T*)sg.rs);
+            HIPCHK(hipGetLastError());
+            {
+                GridMap gy = plain_map(0, 0, 0);
+                gy.beta0 = 1;
+                gy.ktri = 1;
+                RC(launch_gemm<T>(c, s, (T*)Y_v, ldy, (const T*)Li_v, ld, (const T*)X_v, ld, mp, CH, mp, gy));   // Y = −B_c
+            }
+            hipLaunchKernelGGL(ystats_kernel<T>, dim3((unsigned)(mp - row_lo)), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
+                               (const T*)sg.b + c0, row_lo, (double*)cT_v, (double*)rss_v);   // c += B_c b_c ; ‖B‖² rows (fp64)
+            HIPCHK(hipGetLastError());
+            const T* Yr = (const T*)Y_v + row_lo * ldy;
+            if constexpr (is_f64) {
+                RC((launch_gemm<T, double>(c, s, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Y_v, ldy, mp - row_lo, mp, CH,
+                                           plain_map(1, row_lo, 0))));
+            } else {
+                // fp32: the chunk's SYRK runs on the LDS-DMA kernel into fp32 scratch — NBAT partial products over K = 2 048 data
+                // points each in ONE launch (blockIdx.z) — which one pass then adds into the fp64 accumulator: fp64 sums across
+                // partials and chunks, fp32 MFMA within a partial
+                GridMap gs = plain_map(1, row_lo, 0);
+                gs.beta0 = 1;
+                gs.nbatch = NBAT;
+                gs.cstride = (long)(mp + 128) * ld;
+                RC(launch_gemm<T>(c, s, (T*)S_v + row_lo * ld, ld, Yr, ldy, (const T*)Y_v, ldy, mp - row_lo, mp, KS, gs));
+                hipLaunchKernelGGL(add_lower_batched_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(mp - row_lo)), dim3(256),
+                                   0, s, (const T*)S_v, gs.cstride, NBAT, ld, (double*)D_v, ld, mp, row_lo);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        return 0;
+    };
 
     int32_t rc = [&]() -> int32_t {
         HIPCHK(hipEventRecord(c->ev_phase[0], s));
-        HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), xs_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(zsT_v, zsT_h.data(), zsT_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(zsD_v, zsD_h.data(), zsD_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(rs_v, rs_h.data(), rs_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(b_v, b_h.data(), rs_b, hipMemcpyHostToDevice, s));
+        if (x) {
+            HIPCHK(hipMemcpyAsync(seg->xs, xs_h.data(), sizeof(T) * xs_h.size(), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(seg->rs, rs_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(seg->b, b_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, s));
+        }
         HIPCHK(hipMemcpyAsync(jit_v, jit_h.data(), jit_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), s));
         HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * 16, s));
         HIPCHK(hipMemsetAsync(D_v, 0, D_b, s));
         HIPCHK(hipMemsetAsync(cT_v, 0, vT_b, s));
+        HIPCHK(hipMemsetAsync(rss_v, 0, vT_b, s));
         HIPCHK(hipMemsetAsync(vec_v, 0, vD_b, s));
-        if (prev) {  // resume: factor of K_zz, its inverse, the scaled inducing inputs and the running sums come from prev
+        if (mode == VFE_UPDATE) {  // resume: factor of K_zz, its inverse, the scaled inducing inputs and the running sums come from prev
             HIPCHK(hipMemcpyAsync(Lz_v, prev->Lz, L_b, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(Li_v, prev->Li, Li_b, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(zsT_v, prev->zsT, zsT_b, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(zsD_v, prev->zs, zsD_b, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(D_v, prev->Dacc, D_b, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(cT_v, prev->cacc, vT_b, hipMemcpyDeviceToDevice, s));
-            HIPCHK(hipMemcpyAsync(c->scal_dev + 4, &trZ_prev, sizeof(double), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(rss_v, prev->rowss, vT_b, hipMemcpyDeviceToDevice, s));
         } else {
-        // ---- L_z = chol(K_zz + jitter I), fp64                                                    :62
-        {
-            GridMap g = plain_map(1, 0, 0);
-            dim3 grid((unsigned)(mp / 128), (unsigned)(mp / 128));
-            hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Lz, ld, (const double*)zsD_v, mp,
-                               (const double*)zsD_v, mp, d, k->kind, k->variance, (const double*)jit_v, m, m, 1, g,
-                               (const double*)nullptr, (const double*)nullptr);
-            HIPCHK(hipGetLastError());
-        }
-        RC(potrf_full<double>(c, Lz, ld, mp, mp, c->info_dev, m, c->scal_dev + 0));
-        // ---- inv(L_z): W = I · L_z⁻ᵀ (upper), transposed into Ld's storage (free until the SYRK is done), rounded to T
-        {
+            if (mode == VFE_FIT) {
+                HIPCHK(hipMemcpyAsync(zsT_v, znew_h.data(), zsT_b, hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(zsD_v, znewD_h.data(), zsD_b, hipMemcpyHostToDevice, s));
+                // ---- L_z = chol(K_zz + jitter I), fp64                                                :62
+                GridMap g = plain_map(1, 0, 0);
+                dim3 grid((unsigned)(mp / 128), (unsigned)(mp / 128));
+                hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Lz, ld, (const double*)zsD_v, mp,
+                                   (const double*)zsD_v, mp, d, k->kind, k->variance, (const double*)jit_v, m, m, 1, g,
+                                   (const double*)nullptr, (const double*)nullptr);
+                HIPCHK(hipGetLastError());
+                RC(potrf_full<double>(c, Lz, ld, mp, mp, c->info_dev, m, c->scal_dev + 0));
+            } else {  // VFE_APPEND: z = vcat(z_old, z_new); U = update_chol(U11, C12, C22)               :131-141
+                const long mpo = prev->mp, ldo = prev->ld;
+                HIPCHK(hipMemcpyAsync(zn_v, znew_h.data(), sizeof(T) * znew_h.size(), hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(znD_v, znewD_h.data(), sizeof(double) * znewD_h.size(), hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemsetAsync(zsT_v, 0, zsT_b, s));
+                HIPCHK(hipMemsetAsync(zsD_v, 0, zsD_b, s));
+                HIPCHK(hipMemcpy2DAsync(zsT_v, sizeof(T) * mp, prev->zsT, sizeof(T) * mpo, sizeof(T) * m_old, d, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpy2DAsync((T*)zsT_v + m_old, sizeof(T) * mp, zn_v, sizeof(T) * m2p, sizeof(T) * m2, d, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpy2DAsync(zsD_v, sizeof(double) * mp, prev->zs, sizeof(double) * mpo, sizeof(double) * m_old, d, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpy2DAsync((double*)zsD_v + m_old, sizeof(double) * mp, znD_v, sizeof(double) * m2p, sizeof(double) * m2, d, hipMemcpyDeviceToDevice, s));
+                // X = K(z_new, z_old) L11⁻ᵀ = U12ᵀ (in Ld's storage, free until the finalisation), S = C22 + jitter − U12ᵀU12 (in I's)
+                double* Xb = Ld;
+                double* Sb = (double*)I_v;
+                const long ldx = ldo, lds = m2p + c->ldpad;
+                {
+                    GridMap g = plain_map(0, 0, 0);
+                    dim3 grid((unsigned)(mpo / 128), (unsigned)(m2p / 128));
+                    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Xb, ldx, (const double*)znD_v, m2p,
+                                       (const double*)prev->zs, mpo, d, k->kind, k->variance, (const double*)nullptr, m2, m_old, 0, g,
+                                       (const double*)nullptr, (const double*)nullptr);
+                    HIPCHK(hipGetLastError());
+                }
+                RC(trsm_rec<double>(c, s, Xb, ldx, m2p, (const double*)prev->Lz, ldo, mpo));
+                {
+                    GridMap g = plain_map(1, 0, 0);
+                    dim3 grid((unsigned)(m2p / 128), (unsigned)(m2p / 128));
+                    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Sb, lds, (const double*)znD_v, m2p,
+                                       (const double*)znD_v, m2p, d, k->kind, k->variance, (const double*)jit_v, m2, m2, 1, g,
+                                       (const double*)nullptr, (const double*)nullptr);
+                    HIPCHK(hipGetLastError());
+                }
+                RC(launch_gemm<double>(c, s, Sb, lds, Xb, ldx, Xb, ldx, m2p, m2p, mpo, plain_map(1, 0, 0)));
+                RC(potrf_full<double>(c, Sb, lds, m2p, m2p, c->info_dev, m2, c->scal_dev + 0));
+                HIPCHK(hipMemsetAsync(Lz_v, 0, L_b, s));
+                HIPCHK(hipMemcpy2DAsync(Lz, sizeof(double) * ld, prev->Lz, sizeof(double) * ldo, sizeof(double) * m_old, m_old, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpy2DAsync(Lz + m_old * ld, sizeof(double) * ld, Xb, sizeof(double) * ldx, sizeof(double) * m_old, m2, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpy2DAsync(Lz + m_old * ld + m_old, sizeof(double) * ld, Sb, sizeof(double) * lds, sizeof(double) * m2, m2, hipMemcpyDeviceToDevice, s));
+                if (mp > m) {
+                    hipLaunchKernelGGL(pad_identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)(mp - m)), dim3(256), 0, s,
+                                       Lz, ld, m, mp);
+                    HIPCHK(hipGetLastError());
+                }
+                // the finished block rows of the accumulators carry over (rows < row_lo; D_acc is lower, so columns < row_lo too)
+                if (row_lo > 0) {
+                    HIPCHK(hipMemcpy2DAsync(D_v, sizeof(double) * ld, prev->Dacc, sizeof(double) * ldo, sizeof(double) * row_lo, row_lo, hipMemcpyDeviceToDevice, s));
+                    HIPCHK(hipMemcpyAsync(cT_v, prev->cacc, sizeof(double) * row_lo, hipMemcpyDeviceToDevice, s));
+                    HIPCHK(hipMemcpyAsync(rss_v, prev->rowss, sizeof(double) * row_lo, hipMemcpyDeviceToDevice, s));
+                }
+            }
+            // ---- inv(L_z): W = I · L_z⁻ᵀ (upper), transposed into Ld's storage (free until the SYRK is done), rounded to T
             double* Iw = (double*)I_v;
             HIPCHK(hipMemsetAsync(I_v, 0, L_b, s));
             hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
@@ -166,48 +315,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                                (T*)Li_v, (long)mp * ld, 1.0);
             HIPCHK(hipGetLastError());
         }
-        }  // !prev
         HIPCHK(hipEventRecord(c->ev_phase[1], s));
-        // ---- streamed pass over the N data points                                                :64-71
-        for (long c0 = 0; c0 < npad; c0 += CH) {
-            GridMap g = plain_map(0, c0, 0);
-            dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
-            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, (T*)X_v, ld, (const T*)xs_v, npad, (const T*)zsT_v, mp, d,
-                               k->kind, (T)k->variance, (const T*)nullptr, n, m, 0, g, (const T*)nullptr, (const T*)rs_v);
-            HIPCHK(hipGetLastError());
-            {
-                GridMap gy = plain_map(0, 0, 0);
-                gy.beta0 = 1;
-                gy.ktri = 1;
-                RC(launch_gemm<T>(c, s, (T*)Y_v, ldy, (const T*)Li_v, ld, (const T*)X_v, ld, mp, CH, mp, gy));   // Y = −B_c
-            }
-            hipLaunchKernelGGL(sumsq_accum_kernel<T>, dim3((unsigned)mp), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
-                               c->scal_dev + 4);                                                   // ‖A‖²_F in fp64
-            HIPCHK(hipGetLastError());
-            if constexpr (is_f64) {
-                RC((launch_gemm<T, double>(c, s, (double*)D_v, ld, (const T*)Y_v, ldy, (const T*)Y_v, ldy, mp, mp, CH,
-                                           plain_map(1, 0, 0))));
-            } else {
-                // fp32: the chunk's SYRK runs on the LDS-DMA kernel into an fp32 scratch (−Y Yᵀ over this chunk's 8 192 data
-                // points only), which is then added into the fp64 accumulator — fp64 sums across chunks, fp32 MFMA within
-                // four K = 2 048 partial products in ONE launch (blockIdx.z): 4 × 528 lower tiles fill the 512 workgroup
-                // slots four times over instead of 1.03 times; the partials are summed into the fp64 accumulator below
-                constexpr long KS = 2048;
-                constexpr int NB4 = (int)(8192 / KS);
-                GridMap gs = plain_map(1, 0, 0);
-                gs.beta0 = 1;
-                gs.nbatch = NB4;
-                gs.cstride = (long)(mp + 128) * ld;
-                RC(launch_gemm<T>(c, s, (T*)S_v, ld, (const T*)Y_v, ldy, (const T*)Y_v, ldy, mp, mp, KS, gs));
-                for (int b = 0; b < NB4; ++b) {
-                    hipLaunchKernelGGL(add_lower_to_f64_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0,
-                                       s, (const T*)S_v + (long)b * gs.cstride, ld, (double*)D_v, ld, mp);
-                    HIPCHK(hipGetLastError());
-                }
-            }
-            hipLaunchKernelGGL(rowdot_sub_kernel<T>, dim3((unsigned)mp), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
-                               (const T*)b_v + c0, (double*)cT_v);                                 // cT −= Y b_c = +B_c b_c
-            HIPCHK(hipGetLastError());
+        // ---- streamed pass over the data points                                                   :64-71
+        if (mode == VFE_APPEND) {
+            for (auto& sg : prev->segs) RC(stream_seg(*sg));
+        } else {
+            RC(stream_seg(*seg));
         }
         hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s,
                            (const double*)cT_v, vec, mp, 1.0);                                                              // c = B b_y
@@ -231,6 +344,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         HIPCHK(hipEventRecord(c->ev_phase[3], s));
         HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(scal_h, c->scal_dev, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(rss_h.data(), rss_v, vT_b, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         float ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[1]));
@@ -242,69 +356,158 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         c->tm.total_ms = ms;
         c->tm.gemm_ms = 0;
         c->tm.gemm_flops = 0;
+        c->tm.gemm_bytes = 0;
         c->tm.gemm_launches = (int64_t)c->gemm_recs.size();
         for (auto& r : c->gemm_recs) {
             HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
             c->tm.gemm_ms += ms;
             c->tm.gemm_flops += r.flops;
+            c->tm.gemm_bytes += r.bytes;
         }
         return 0;
     }();
     if (rc != 0) {
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
+        return rc;
     }
-    ctx_release(c, xs_v, xs_b);
-    ctx_release(c, rs_v, rs_b);
-    ctx_release(c, b_v, rs_b);
-    ctx_release(c, X_v, X_b);
-    ctx_release(c, Y_v, Y_b);
-    ctx_release(c, I_v, L_b);
-    ctx_release(c, S_v, 4 * Li_b);
-    ctx_release(c, jit_v, jit_b);
-    if (rc == 0 && info_h != 0) rc = info_h;
-    if (rc != 0 || !out) {
-        ctx_release(c, Lz_v, L_b);
-        ctx_release(c, Ld_v, L_b);
-        ctx_release(c, zsD_v, zsD_b);
-        ctx_release(c, vec_v, vD_b);
-        ctx_release(c, D_v, D_b);
-        ctx_release(c, cT_v, vT_b);
-        ctx_release(c, Li_v, Li_b);
-        ctx_release(c, zsT_v, zsT_b);
-        if (rc != 0) return rc;
-    }
+    // a failing factorisation: K_zz (+ the bordered block of an append) or Λ_ε — reported like the reference's cholesky calls
+    if (info_h != 0) return (mode == VFE_APPEND && info_h <= m2) ? (int32_t)(m_old + info_h) : info_h;
     // objective: dtc = -½ (N log2π + logdet Σy + logdet Λ_ε + ‖δ_s‖² − ‖Λ_ε.U⁻ᵀ A δ_s‖²)          :302-303
-    //            elbo = dtc − ½ (tr(K_ff Σy⁻¹) − ‖A‖²_F),  ‖A‖²_F = tr(D − I)                      :251
-    const double logdet_lam = 2.0 * scal_h[1], trZ = scal_h[4], quad = scal_h[3];  // trZ = ‖B‖²_F = ‖A‖²_F
+    //            elbo = dtc − ½ (tr(K_ff Σy⁻¹) − ‖A‖²_F),  ‖A‖²_F = ‖B‖²_F                          :251
+    double trZ = 0;
+    for (long i = 0; i < m; ++i) trZ += rss_h[i];
+    const double logdet_lam = 2.0 * scal_h[1], quad = scal_h[3];
     double obj = -0.5 * ((double)n_all * LOG2PI + logdet_sy + logdet_lam + dd - quad);
     if (approx == 0) obj -= 0.5 * (tr_kff - trZ);
     if (objective) *objective = obj;
     if (out) {
+        out->ctx = c;
         out->dtype = k->dtype;
         out->m = m; out->mp = mp; out->ld = ld; out->d = d; out->kind = k->kind;
-        out->variance = k->variance; out->nscale = k->nscale;
+        out->variance = k->variance; out->nscale = k->nscale; out->jitter = jitter;
         out->scale.clear();
         if (k->scale && k->nscale > 0) out->scale.assign(k->scale, k->scale + k->nscale);
-        out->Lz = Lz_v; out->Ld = Ld_v; out->L_bytes = L_b;
-        out->zs = zsD_v; out->zs_bytes = zsD_b;
-        out->alpha = vec + 2 * mp; out->meps = vec + mp; out->vec_bytes = vD_b;
-        // keep the base pointer of the vector block for release
-        out->alpha = (void*)vec;  // block base; α at +2mp, m_ε at +mp
+        out->Lz = bufs.keep(Lz_v);
+        out->Ld = bufs.keep(Ld_v);
+        out->zs = bufs.keep(zsD_v);
+        out->vec = bufs.keep(vec_v);
         out->approx = approx;
         out->n_obs = n_all;
-        out->Dacc = D_v; out->D_bytes = D_b;
-        out->cacc = cT_v; out->c_bytes = vT_b;
-        out->Li = Li_v; out->Li_bytes = Li_b;
-        out->zsT = zsT_v; out->zsT_bytes = zsT_b;
+        out->Dacc = bufs.keep(D_v);
+        out->cacc = bufs.keep(cT_v);
+        out->rowss = bufs.keep(rss_v);
+        out->Li = bufs.keep(Li_v);
+        out->zsT = bufs.keep(zsT_v);
+        out->segs.clear();
+        if (prev) out->segs = prev->segs;
+        if (seg) out->segs.push_back(seg);
         out->logdet_sy = logdet_sy; out->dd = dd; out->tr_kff = tr_kff; out->trZ = trZ;
     }
     return 0;
 }
 
+// Joint predictive distribution of the approximate posterior at x* on the device (always fp64 on the M side):
+//   A = U⁻ᵀ K_z*  ->  rows X1 = K_*z L_z⁻ᵀ,  X2 = X1 L_D⁻ᵀ;   cov = K** − X1 X1ᵀ + X2 X2ᵀ (+ Σy*)        :187-190, :205-210
 template <typename T>
-static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, int what, void* mean_out, void* var_out) {
+static int32_t vfe_joint(gp_vfe* p, const gp_points* xs, const void* pm, const gp_noise* noise, long R, DevBufs& bufs,
+                         Joint<double>& J) {
     gp_ctx* c = p->ctx;
+    SkScope sk(c);
+    const long m = p->m, mp = p->mp, ld = p->ld;
+    const long ns = xs->n, nsp = round_up(ns, 128);
+    const int d = p->d;
+    gp_kernel k{};
+    k.kind = p->kind; k.dtype = 0; k.variance = p->variance; k.nscale = p->nscale;
+    k.scale = p->scale.empty() ? nullptr : p->scale.data();
+    std::vector<T> xsT;
+    scale_points<T>(&k, xs, nsp, xsT);  // inputs arrive in T; scale in T (as the fit did), then widen
+    std::vector<double> xs_h(xsT.begin(), xsT.end()), nz_h;
+    noise_to<double, T>(noise, ns, nsp, nz_h);
+    const double* vec = (const double*)p->vec;
+    const long ldc = nsp + c->ldpad;
+    const size_t X_b = sizeof(double) * (size_t)(nsp + 128) * ld;
+    void *xs_v = 0, *nz_v = 0, *m_v = 0, *X1_v = 0, *X2_v = 0, *X2n_v = 0;
+    RC(bufs.get(sizeof(double) * xs_h.size(), &xs_v));
+    RC(bufs.get(sizeof(double) * (size_t)nsp, &nz_v));
+    RC(bufs.get(sizeof(double) * (size_t)nsp, &m_v));
+    RC(bufs.get(X_b, &X1_v));
+    RC(bufs.get(X_b, &X2_v));
+    RC(bufs.get(X_b, &X2n_v));
+    RC(bufs.get(sizeof(double) * (size_t)(nsp + R + 128) * ldc, &J.C));
+    J.ns = ns; J.nsp = nsp; J.ld = ldc; J.R = R;
+    double* X1 = (double*)X1_v;
+    double* X2 = (double*)X2_v;
+    double* Cm = (double*)J.C;
+    hipStream_t s = c->sm;
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    std::vector<double> m_h((size_t)ns);
+    HIPCHK(hipMemcpyAsync(xs_v, xs_h.data(), sizeof(double) * xs_h.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(nz_v, nz_h.data(), sizeof(double) * (size_t)nsp, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kvec_kernel<double>, dim3((unsigned)ns), dim3(256), 0, s, (const double*)xs_v, nsp, (const double*)p->zs, mp, d,
+                       p->kind, p->variance, m, vec + 2 * mp, (double*)m_v);                                     // K_*z α
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(m_h.data(), m_v, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    {
+        GridMap g = plain_map(0, 0, 0);
+        dim3 grid((unsigned)(mp / 128), (unsigned)(nsp / 128));
+        hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, X1, ld, (const double*)xs_v, nsp, (const double*)p->zs, mp, d,
+                           p->kind, p->variance, (const double*)nullptr, ns, m, 0, g, (const double*)nullptr, (const double*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    RC(trsm_rec<double>(c, s, X1, ld, nsp, (const double*)p->Lz, ld, mp));
+    HIPCHK(hipMemcpyAsync(X2_v, X1_v, X_b, hipMemcpyDeviceToDevice, s));
+    RC(trsm_rec<double>(c, s, X2, ld, nsp, (const double*)p->Ld, ld, mp));
+    {
+        const long cnt = (long)(nsp + 128) * ld;
+        hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const double*)X2,
+                           (double*)X2n_v, cnt, -1.0);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        GridMap g = plain_map(1, 0, 0);
+        dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
+        hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Cm, ldc, (const double*)xs_v, nsp, (const double*)xs_v, nsp, d,
+                           p->kind, p->variance, (const double*)nz_v, ns, ns, 1, g, (const double*)nullptr, (const double*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemsetAsync(Cm + nsp * ldc, 0, sizeof(double) * (size_t)(R + 128) * ldc, s));
+    RC(launch_gemm<double>(c, s, Cm, ldc, X1, ld, X1, ld, nsp, nsp, mp, plain_map(1, 0, 0)));                     // − AᵀA
+    RC(launch_gemm<double>(c, s, Cm, ldc, (const double*)X2n_v, ld, X2, ld, nsp, nsp, mp, plain_map(1, 0, 0)));  // + (Λ_ε.U⁻ᵀA)ᵀ(·)
+    HIPCHK(hipStreamSynchronize(s));
+    const T* prior = (const T*)pm;
+    J.mean.resize((size_t)ns);
+    for (long i = 0; i < ns; ++i) J.mean[i] = (prior ? (double)prior[i] : 0.0) + m_h[i];
+    return 0;
+}
+
+template <typename T>
+static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, int what, void* mean_out, void* var_out,
+                                void* cov_out) {
+    gp_ctx* c = p->ctx;
+    if (what & 4) {  // full covariance (+ mean): the joint, copied out and mirrored on the host                :187-190, :205-210
+        DevBufs bufs(c);
+        Joint<double> J;
+        int32_t rc = vfe_joint<T>(p, xs, pm, nullptr, 0, bufs, J);
+        if (rc != 0) {
+            (void)hipStreamSynchronize(c->sm);
+            return rc;
+        }
+        const long ns = J.ns;
+        std::vector<double> Ch((size_t)ns * ns);
+        HIPCHK(hipMemcpy2DAsync(Ch.data(), sizeof(double) * ns, J.C, sizeof(double) * J.ld, sizeof(double) * ns, ns, hipMemcpyDeviceToHost,
+                                c->sm));
+        HIPCHK(hipStreamSynchronize(c->sm));
+        T* co = (T*)cov_out;
+        for (long i = 0; i < ns; ++i)
+            for (long j = 0; j <= i; ++j) co[i + j * ns] = co[j + i * ns] = (T)Ch[(size_t)i * ns + j];
+        if (what & 1)
+            for (long i = 0; i < ns; ++i) ((T*)mean_out)[i] = (T)J.mean[i];
+        if (what & 2)
+            for (long i = 0; i < ns; ++i) ((T*)var_out)[i] = (T)Ch[(size_t)i * ns + i];
+        return 0;
+    }
     const long m = p->m, mp = p->mp, ld = p->ld;
     const long ns = xs->n, nsp = round_up(ns, 128);
     const int d = p->d;
@@ -315,13 +518,14 @@ static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, 
     std::vector<T> xsT;
     scale_points<T>(&k, xs, nsp, xsT);
     std::vector<double> xs_h(xsT.begin(), xsT.end());
-    const double* vec = (const double*)p->alpha;
+    const double* vec = (const double*)p->vec;
     const size_t xs_b = sizeof(double) * xs_h.size(), X_b = sizeof(double) * (size_t)(nsp + 128) * ld,
                  o_b = sizeof(double) * (size_t)nsp * 3;
     void *xs_v = 0, *X_v = 0, *o_v = 0;
-    RC(ctx_alloc(c, xs_b, &xs_v));
-    RC(ctx_alloc(c, X_b, &X_v));
-    RC(ctx_alloc(c, o_b, &o_v));
+    DevBufs bufs(c);
+    RC(bufs.get(xs_b, &xs_v));
+    RC(bufs.get(X_b, &X_v));
+    RC(bufs.get(o_b, &o_v));
     double* X = (double*)X_v;
     double* o = (double*)o_v;
     hipStream_t s = c->sm;
@@ -353,11 +557,10 @@ static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, 
         HIPCHK(hipStreamSynchronize(s));
         return 0;
     }();
-    if (rc != 0) (void)hipStreamSynchronize(s);
-    ctx_release(c, xs_v, xs_b);
-    ctx_release(c, X_v, X_b);
-    ctx_release(c, o_v, o_b);
-    if (rc != 0) return rc;
+    if (rc != 0) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
     const T* prior = (const T*)pm;
     if (what & 1)
         for (long i = 0; i < ns; ++i) ((T*)mean_out)[i] = (T)((prior ? (double)prior[i] : 0.0) + oh[i]);

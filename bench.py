@@ -48,38 +48,63 @@ def se_rows(xi: np.ndarray, x: np.ndarray) -> np.ndarray:
 
 
 def cpu_baseline(n_full: int, d: int):
-    """Oracle (NumPy/SciPy -> OpenBLAS LAPACK, the routines Julia's cholesky reaches) timed on this box's
-    host cores on a bounded sample: the fused pair at N = 4096 and N = 8192 points of the same workload,
-    extrapolated to n_full with t = a·N³ + b·N² (the reference itself would do the Gram + Cholesky twice)."""
+    """Oracle (NumPy/SciPy -> OpenBLAS LAPACK, the routines Julia's cholesky reaches) timed on this box's host cores on a
+    bounded sample of the same workload: the in-place fused pair (one Fortran-ordered N×N, dpotrf('U') in place — SURVEY.md
+    §8(d)) at N = 8 192, 16 384 and 32 768 points, Gram / potrf / solves timed separately, extrapolated to n_full with
+    t = a·N³ + b·N² (least squares).  `value` is the fused pair (one Gram + one dpotrf: what the engine does);
+    `two_factorisations` is the pair as the reference executes it (logpdf and posterior each rebuild and refactor the Gram
+    matrix).  The full-size run of the same oracle on an MI355X box's host (tools/fullsize_parity.py) is quoted
+    from profiles/r2/fullsize_parity.jsonl when that record is present."""
     from oracle import gp_oracle as o
 
+    pools, cores = [], os.cpu_count() or 1
     try:
         from threadpoolctl import threadpool_info
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        pools = [{k: p.get(k) for k in ("user_api", "internal_api", "version", "num_threads", "threading_layer")}
+                 for p in threadpool_info()]
+        cores = max([p.get("num_threads") or 1 for p in pools] + [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        pass
+    gram_threads = min(32, os.cpu_count() or 1)
     x, y = synth_inputs(n_full, d, 4)
     f = o.GP(o.Kernel(o.SE))
-    ts = {}
-    for n in (4096, 8192):
-        fx = o.FiniteGP(f, x[:n], 0.01)
+    sizes = [nn for nn in (8192, 16384, 32768) if nn <= n_full]
+    rows, ts = [], []
+    for nn in sizes:
+        tm = {}
         t0 = time.perf_counter()
-        o.logpdf_and_posterior(fx, y[:n])
-        ts[n] = time.perf_counter() - t0
-    n1, n2 = 4096.0, 8192.0
-    A = np.array([[n1**3, n1**2], [n2**3, n2**2]])
-    a, b = np.linalg.solve(A, np.array([ts[4096], ts[8192]]))
-    if a <= 0 or b < 0:  # degenerate fit: fall back to pure cubic from the larger sample
-        a, b = ts[8192] / n2**3, 0.0
+        o.logpdf_and_posterior_inplace(o.FiniteGP(f, x[:nn], 0.01), y[:nn], threads=gram_threads, timings=tm)
+        ts.append(time.perf_counter() - t0)
+        rows.append({"n": nn, "pair_s": ts[-1], **{k: round(v, 4) for k, v in tm.items()},
+                     "potrf_gflops": nn**3 / 3 / tm["potrf_s"] / 1e9})
+    A = np.array([[float(nn)**3, float(nn)**2] for nn in sizes])
+    coef, *_ = np.linalg.lstsq(A, np.array(ts), rcond=None)
+    a, b = coef
+    if a <= 0 or b < 0:  # degenerate fit: pure cubic through the largest sample
+        a, b = ts[-1] / float(sizes[-1])**3, 0.0
     t_full = a * n_full**3 + b * n_full**2
-    return {
+    last = rows[-1]
+    t_twice = t_full + (last["gram_s"] + last["potrf_s"]) / last["pair_s"] * t_full
+    out = {
         "value": n_full / t_full, "unit": "points/s", "cores": int(cores), "kind": "port",
-        "sample": (f"fused logpdf+posterior pair (one Gram + one dpotrf) of the oracle at N=4096 ({ts[4096]:.2f}s) and "
-                   f"N=8192 ({ts[8192]:.2f}s) points of the same workload, extrapolated to N={n_full} with "
-                   f"t=a*N^3+b*N^2 -> {t_full:.0f}s; the reference's own logpdf+posterior does this work twice"),
-        "measured_points_per_s_at_8192": 8192 / ts[8192],
+        "sample": (f"in-place fused logpdf+posterior pair of the oracle (one Gram + one dpotrf) at N={sizes} points of the "
+                   f"same workload ({', '.join(f'{t:.2f}s' for t in ts)}), extrapolated to N={n_full} with t=a*N^3+b*N^2 -> "
+                   f"{t_full:.0f}s"),
+        "samples": rows, "gram_threads": gram_threads, "threadpools": pools,
+        "two_factorisations": {"value": n_full / t_twice, "unit": "points/s",
+                               "note": "the reference's own logpdf(fx,y) + posterior(fx,y) assemble and factor K twice"},
     }
+    rec_path = ROOT / "profiles" / "r2" / "fullsize_parity.jsonl"
+    if rec_path.exists():
+        for line in rec_path.read_text().splitlines():
+            r = json.loads(line)
+            if r.get("config") == "C4" and r.get("n") == n_full:
+                out["measured_full_run"] = {"source": "profiles/r2/fullsize_parity.jsonl (tools/fullsize_parity.py on an MI355X box's host)",
+                                            "pair_s": r["oracle_pair_s"], "phases_s": r["oracle_phases_s"],
+                                            "points_per_s_fused": r["oracle_points_per_s_fused"],
+                                            "points_per_s_two_factorisations": r["oracle_points_per_s_two_factorisations"]}
+    return out
 
 
 def pmc_traffic(n: int) -> dict:
@@ -87,14 +112,16 @@ def pmc_traffic(n: int) -> dict:
     (tools/gpu_pmc_bench.sh -> profiles/r1/pmc_bench_summary.json; FETCH_SIZE and WRITE_SIZE are reported in KiB and
     FETCH_SIZE is doubled, the gfx950 correction for 16-B/lane streaming reads of MI355X_MICROARCH.md §HBM).
     PMC cannot be sampled from inside the timed run, so this is null when the summary is absent or for another N."""
-    path = ROOT / "profiles" / "r1" / "pmc_bench_summary.json"
+    path = ROOT / "profiles" / "r2" / "pmc_bench_summary.json"
+    if not path.exists():
+        path = ROOT / "profiles" / "r1" / "pmc_bench_summary.json"
     if n != 65536 or not path.exists():
         return {"traffic": None}
     s = json.loads(path.read_text())
     rd = 2.0 * s["FETCH_SIZE"]["avg"] * 1024.0
     wr = s["WRITE_SIZE"]["avg"] * 1024.0
     return {"traffic": rd + wr, "traffic_detail": {"unit": "bytes per launch (average over the bench's MFMA GEMM launches)",
-                                                   "read": rd, "write": wr, "source": "profiles/r1/pmc_bench_summary.json"}}
+                                                   "read": rd, "write": wr, "source": str(path.relative_to(ROOT))}}
 
 
 def main():
@@ -158,9 +185,7 @@ def main():
 
         for _ in range(args.warmup):
             step().data.C.free()
-        ctx.set_param("time_kernels", 1)
-        gemm_ms = gemm_flops = gemm_bytes = 0.0
-        gemm_launches = 0
+        # ---- the timed region: the production configuration (no per-kernel instrumentation)
         phases = {"assemble_ms": 0.0, "potrf_ms": 0.0, "solve_ms": 0.0}
         barrier()
         t0 = time.perf_counter()
@@ -169,25 +194,32 @@ def main():
             if post is not None:
                 post.data.C.free()
             post = step()
-            tm = ctx.timings()
-            gemm_ms += tm["gemm_ms"]
-            gemm_flops += tm["gemm_flops"]
-            gemm_bytes += tm.get("gemm_bytes", 0.0)
-            gemm_launches += tm["gemm_launches"]
+            tm = ctx.timings()  # four phase events recorded by every call (not per-kernel)
             for kname in phases:
                 phases[kname] += tm[kname] / args.steps
         barrier()
         dt = time.perf_counter() - t0
-        ctx.set_param("time_kernels", 0)
         logpdf_val, alpha = float(post.logpdf_value), post.data.alpha
-        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # ---- separate, untimed instrumented pass: every MFMA GEMM launch bracketed by HIP events on its own stream
+        post.data.C.free()
+        ctx.set_param("time_kernels", 1)
+        post = step()
+        tm = ctx.timings()
+        ctx.set_param("time_kernels", 0)
+        gemm_ms, gemm_flops, gemm_bytes, gemm_launches = tm["gemm_ms"], tm["gemm_flops"], tm.get("gemm_bytes", 0.0), tm["gemm_launches"]
+        kernel_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         mfma_ceiling = agp._lib.C.c_double()
         agp._lib.check(ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, agp._lib.C.byref(mfma_ceiling)))
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, **pmc_traffic(n),
-                    "algorithmic_bytes_per_launch_avg": gemm_bytes / max(gemm_launches, 1),
+        pair_tf = f_pair(n) / (dt / args.steps) / 1e12
+        # roofline: the SURVEY.md §8(d) number — F_pair / t_pair over the whole job — with the dominant kernel's own rate beside it
+        roofline = {"bound": "mfma", "achieved": pair_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": pair_tf / FP64_MFMA_PEAK_TFLOPS, **pmc_traffic(n),
+                    "definition": "achieved = (N^3/3 + 3N^2) / wall time of one pair (SURVEY.md 8(d)); kernel_* = the dominant kernel alone",
                     "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands)",
-                    "launches_per_step": gemm_launches / max(args.steps, 1),
+                    "kernel_achieved": kernel_tflops, "kernel_frac": kernel_tflops / FP64_MFMA_PEAK_TFLOPS,
+                    "kernel_timing": "separate untimed pass with time_kernels=1 (HIP events around each launch on its stream)",
+                    "algorithmic_bytes_per_launch_avg": gemm_bytes / max(gemm_launches, 1),
+                    "launches_per_step": gemm_launches,
                     "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                     "flops_per_launch_avg": gemm_flops / max(gemm_launches, 1),
                     "measured_mfma_f64_ceiling_tflops": mfma_ceiling.value}

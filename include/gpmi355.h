@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GPMI355_ABI_VERSION 1
+#define GPMI355_ABI_VERSION 2
 
 typedef struct gp_ctx gp_ctx;   /* device + streams + workspace                          */
 typedef struct gp_post gp_post; /* PosteriorGP state: device-resident factor, alpha, x   */
@@ -106,8 +106,13 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail (gemm_nt_sk_kernel)           default 0
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (same speed on one large
  *                    launch, 4-7 % slower over a whole factorisation; leaves room for concurrent kernels)   default 0
- *   "ldpad"          row padding in elements (multiple of 16)                             default 32 */
+ *   "ldpad"          row padding in elements (multiple of 16)                             default 32
+ *   "vfe_chunk"      data points per streamed VFE chunk (multiple of 2048)                default 8192
+ *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
+/* Return every cached (free) device block of the ctx to the HIP allocator — e.g. after freeing an N = 65 536 posterior
+ * (34 GB) when another allocator in the process needs the memory. */
+int32_t gp_ctx_trim(gp_ctx* ctx);
 int32_t gp_get_timings(gp_ctx* ctx, gp_timings* out);
 const char* gp_last_error(void);
 int32_t gp_abi_version(void);
@@ -137,7 +142,16 @@ int32_t gp_posterior_fit(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, co
  * mean = m(x*) + K_*x α;  var = k** - colsumsq(U⁻ᵀ K_x*);  cov = K** - VᵀV. */
 int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* prior_mean_xs_or_null,
                              int32_t what, void* mean_out, void* var_out, void* cov_out);
-/* logpdf(post(x*, Σy*), y*) is not separate: predict + host.  */
+/* logpdf(post(x*, Σy*), Y*) on the device: the FiniteGP-over-PosteriorGP path of the reference — mean_and_cov
+ * (src/exact_gpr_posterior.jl:78-83) + Σy* (src/finite_gp_projection.jl:133-136), cholesky (:308), logdet + _sqmahal
+ * (:310, :325-326).  Y: ns × ncols column-major, leading dimension ldy; out: ncols entries.  The N*×N* predictive
+ * covariance is built and factored in HBM against the resident N×N factor; nothing is refitted. */
+int32_t gp_posterior_logpdf(gp_post* post, const gp_points* xs, const void* prior_mean_xs_or_null, const gp_noise* noise,
+                            const void* Y, int64_t ldy, int32_t ncols, void* out);
+/* rand(rng, post(x*, Σy*), ncols) with the standard normals supplied by the caller (src/finite_gp_projection.jl:233-237):
+ * out[:, s] = m* + chol(C*).U' xi[:, s]; xi and out are ns × ncols column-major (leading dimension ns). */
+int32_t gp_posterior_rand(gp_post* post, const gp_points* xs, const void* prior_mean_xs_or_null, const gp_noise* noise,
+                          const void* xi, int32_t ncols, void* out);
 
 /* Value and gradient of logpdf(f(x, Σy), y) — the pullback a ChainRules rrule for the accelerated logpdf needs (the
  * reference differentiates logpdf by AD: test/finite_gp_projection.jl:152-178 and the examples).  One factorisation, then
@@ -182,9 +196,22 @@ int32_t gp_vfe_fit(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp
  * re-finalised — equal to refitting on all observations.  objective_out: ELBO / DTC evidence of all observations. */
 int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, const void* mean2_or_null, const void* y2,
                       gp_vfe** out, void* objective_out_or_null);
-/* mean_and_var / mean (src/sparse_approximations.jl:183-217).  what: bit0 mean, bit1 var. */
+/* update_posterior(f_post_approx, fz) — append pseudo-points (src/sparse_approximations.jl:131-176): bordered Cholesky of
+ * K_zz against the resident factor (update_chol, src/util/common_covmat_ops.jl:38-42), then the retained observations are
+ * streamed once more to form ONLY the new block rows of B Bᵀ / B b_y / ‖B‖²_F (the reference keeps B_εf, x, Σy, b_y in its
+ * cache for this; here x, Σy^-1/2 and b_y stay on the device and B is never stored).  jitter of the new points = the old
+ * one.  `old` stays valid.  objective_out: ELBO / DTC evidence with the enlarged pseudo-point set. */
+int32_t gp_vfe_append(gp_vfe* old, const gp_points* z2, gp_vfe** out, void* objective_out_or_null);
+/* mean / var / cov / mean_and_var / mean_and_cov (src/sparse_approximations.jl:183-217).  what: bit0 mean, bit1 var,
+ * bit2 full cov (ns×ns column-major) = K** − AᵀA + (Λ_ε.U⁻ᵀA)ᵀ(Λ_ε.U⁻ᵀA). */
 int32_t gp_vfe_predict(gp_vfe* post, const gp_points* xs, const void* prior_mean_xs_or_null, int32_t what,
-                       void* mean_out, void* var_out);
+                       void* mean_out, void* var_out, void* cov_out);
+/* logpdf(f_post_approx(x*, Σy*), Y*) and rand(...) — same contracts as gp_posterior_logpdf / gp_posterior_rand. */
+int32_t gp_vfe_logpdf(gp_vfe* post, const gp_points* xs, const void* prior_mean_xs_or_null, const gp_noise* noise,
+                      const void* Y, int64_t ldy, int32_t ncols, void* out);
+int32_t gp_vfe_rand(gp_vfe* post, const gp_points* xs, const void* prior_mean_xs_or_null, const gp_noise* noise,
+                    const void* xi, int32_t ncols, void* out);
+int64_t gp_vfe_m(gp_vfe* post); /* number of pseudo-points */
 /* α = U \ m_ε (length M) and m_ε — cache fields of src/sparse_approximations.jl:73. */
 int32_t gp_vfe_get(gp_vfe* post, void* alpha_out_or_null, void* m_eps_out_or_null);
 int32_t gp_vfe_free(gp_vfe* post);

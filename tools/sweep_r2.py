@@ -1,0 +1,83 @@
+"""Round-2 parameter sweeps on one MI355X (timings only; parity is the test-suite's job): outer panel width / look-ahead /
+stream-K for the mid-size exact configs, chunk size for the VFE config.  One JSON line per measurement."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import abstractgps_jl_amd as agp  # noqa: E402
+
+
+def synth(n, d, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d))
+    return X, np.sin(X.sum(axis=1)) + 0.1 * rng.standard_normal(n)
+
+
+def exact(tag, n, d, seed, kernel, params, reps=3):
+    x, y = synth(n, d, seed)
+    ctx = agp.default_context(0)
+    for k, v in params.items():
+        ctx.set_param(k, v)
+    fx = agp.GP(kernel)(agp.RowVecs(x), 0.01)
+    best = None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        post = agp.posterior(fx, y)
+        dt = time.perf_counter() - t0
+        tm = ctx.timings()
+        post.data.C.free()
+        if _ > 0 and (best is None or dt < best[0]):
+            best = (dt, tm)
+    dt, tm = best
+    print(json.dumps({"config": tag, "n": n, "params": params, "pair_ms": round(dt * 1e3, 3),
+                      "pair_tflops": round((n**3 / 3 + 3 * n**2) / dt / 1e12, 2),
+                      "phases_ms": {k: round(tm[k], 3) for k in ("assemble_ms", "potrf_ms", "solve_ms")}}), flush=True)
+
+
+def vfe(params, n=262144, m=4096, d=3, reps=2):
+    rng = np.random.default_rng(5)
+    X = (rng.uniform(0, 1, (n, d)) * 4).astype(np.float32)
+    y = (np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    z = X[rng.permutation(n)[:m]].copy()
+    ctx = agp.default_context(0)
+    for k, v in params.items():
+        ctx.set_param(k, v)
+    f = agp.GP(agp.SqExponentialKernel())
+    fx = f(agp.RowVecs(X), np.float32(0.1))
+    approx = agp.VFE(f(agp.RowVecs(z), 1e-4))
+    best = None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        post = agp.posterior(approx, fx, y)
+        dt = time.perf_counter() - t0
+        tm = ctx.timings()
+        if _ > 0 and (best is None or dt < best[0]):
+            best = (dt, tm, float(post.objective))
+        del post
+    dt, tm, obj = best
+    flops = 2.0 * n * m * m + 2.0 * m**3 / 3
+    print(json.dumps({"config": "C5", "params": params, "fit_ms": round(dt * 1e3, 3), "fit_tflops_fp32": round(flops / dt / 1e12, 2),
+                      "frac_of_157.3": round(flops / dt / 157.3e12, 4), "elbo": obj,
+                      "phases_ms": {k: round(tm[k], 3) for k in ("assemble_ms", "potrf_ms")}}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["C2", "C3", "C5"]
+    base = {"nb": 2048, "lookahead": 1, "gemm_streamk": 0}
+    if "C2" in which:
+        for p in ({}, {"nb": 512}, {"nb": 1024}, {"nb": 4096}, {"nb": 1024, "gemm_streamk": 1}, {"lookahead": 0}, {"nb": 1024, "lookahead": 0}):
+            exact("C2", 16384, 3, 2, agp.SqExponentialKernel(), {**base, **p})
+    if "C3" in which:
+        for p in ({}, {"nb": 1024}, {"nb": 4096}):
+            exact("C3", 32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5), {**base, **p}, reps=2)
+    for k, v in base.items():
+        agp.default_context(0).set_param(k, v)
+    if "C5" in which:
+        for ch in (8192, 16384, 32768):
+            vfe({"vfe_chunk": ch})
+        agp.default_context(0).set_param("vfe_chunk", 8192)
