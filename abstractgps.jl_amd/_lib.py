@@ -43,6 +43,8 @@ PK, PP, PN, PG = C.POINTER(gp_kernel), C.POINTER(gp_points), C.POINTER(gp_noise)
 # name -> (restype, argtypes); must cover every function declared in include/gpmi355.h
 PROTOTYPES = {
     "gp_ctx_create": (i32, [C.POINTER(vp), i32, vp]),
+    "gp_ctx_create_multi": (i32, [C.POINTER(vp), C.POINTER(i32), i32, i32, i32, i32]),
+    "gp_ctx_multi_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "gp_ctx_destroy": (i32, [vp]),
     "gp_ctx_set_param": (i32, [vp, C.c_char_p, i64]),
     "gp_get_timings": (i32, [vp, C.POINTER(gp_timings)]),

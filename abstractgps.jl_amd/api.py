@@ -200,15 +200,29 @@ def _input_dtype(x):
 # Engine context (one per device)
 # --------------------------------------------------------------------------------------------
 class Context:
-    """gp_ctx wrapper.  `stream` = a raw hipStream_t (int) to issue main-stream work on, or None."""
+    """gp_ctx wrapper.  `stream` = a raw hipStream_t (int) to issue main-stream work on, or None.
+    `devices=[d0, d1, ...]` builds a multi-device context (gp_ctx_create_multi): fp64 logpdf / posterior fits are then
+    partitioned 2D block-cyclically over those devices inside the library (grid P×Q, 0 = chosen for the fabric; block nb);
+    listing one device several times gives virtual ranks (the whole schedule on one GPU)."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, devices=None, P: int = 0, Q: int = 0, nb: int = 0):
         self.lib = _lib.load()
         h = C.c_void_p()
-        check(self.lib.gp_ctx_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None))
+        if devices is not None:
+            devs = (C.c_int32 * len(devices))(*[int(v) for v in devices])
+            check(self.lib.gp_ctx_create_multi(C.byref(h), devs, len(devices), int(P), int(Q), int(nb)))
+            device = int(devices[0])
+        else:
+            check(self.lib.gp_ctx_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None))
         self.handle = h
         self.device = device
         self._fin = weakref.finalize(self, self.lib.gp_ctx_destroy, h)
+
+    def multi_info(self) -> dict:
+        v = [C.c_int32() for _ in range(5)]
+        check(self.lib.gp_ctx_multi_info(self.handle, *[C.byref(t) for t in v]))
+        P, Q, nb, comm, depth = (t.value for t in v)
+        return {"P": P, "Q": Q, "nb": nb, "comm": {0: "none", 1: "rccl", 2: "copies"}.get(comm, str(comm)), "lookahead_depth": depth}
 
     def set_param(self, name: str, value: int) -> None:
         check(self.lib.gp_ctx_set_param(self.handle, name.encode(), int(value)))

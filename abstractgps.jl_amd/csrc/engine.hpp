@@ -1,0 +1,232 @@
+// engine.hpp — internal interface shared by the translation units of libgpmi355.so:
+//   gpmi355.hip  kernels (kernels.hpp), the single-device engine and the C ABI
+//   multi.hip    the multi-device 2D block-cyclic driver (host code only: RCCL / peer copies + calls into the engine)
+// Nothing here is part of the public ABI (include/gpmi355.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <mutex>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gpmi355.h"
+
+namespace gpmi {
+// 2D block-cyclic bookkeeping shared by kmat and gemm: local absolute index -> global index.
+struct GridMap {
+    int lower;       // 1: skip tiles strictly above the global diagonal
+    int P, p, Q, q;  // process grid / my coordinates (1,0,1,0 on a single GPU)
+    long nb;         // distribution block in elements (multiple of 128); ignored when P=Q=1
+    long row0, col0; // local absolute index of the region's first row / column
+    int compact;     // 1: 1-D grid enumerating only the tiles on/below the diagonal (single-GPU lower mode)
+                     // 2 / 3: XCD-aware super-tile order (rectangular / lower trapezoid), see xcd_tile()
+    int tn, dt;      // compact: number of tile columns, diagonal offset in tiles (row tile i has min(tn, i+dt+1) tiles)
+    int tm;          // number of tile rows (modes 2, 3)
+    int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
+    int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
+                     // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
+    int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
+    long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
+    int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
+};
+}  // namespace gpmi
+
+// ---- errors (thread-local text behind gp_last_error) ---------------------------------------------
+int32_t set_hip_err(hipError_t e, const char* what, int line);
+int32_t set_arg_err(int i, const char* msg);
+int32_t set_err_text(int32_t status, const std::string& msg);  // returns status
+#define HIPCHK(expr)                                                   \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return set_hip_err(e_, #expr, __LINE__); \
+    } while (0)
+#define RC(expr)                \
+    do {                        \
+        int32_t rc_ = (expr);   \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+static const double LOG2PI = 1.8378770664093454835606594728112;
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct FreeBlock {
+    void* p;
+    size_t bytes;
+};
+
+struct gp_ctx {
+    int device = 0;
+    hipStream_t sm = nullptr;  // main stream (trailing updates, assembly, solves)
+    hipStream_t sp = nullptr;  // panel stream (look-ahead)
+    bool own_sm = false;
+    std::mutex mu;
+    long nb = 2048;        // outer panel width
+    int lookahead = 1;
+    int time_kernels = 0;
+    int gemm_variant = 0;
+    int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
+    int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
+    int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
+    int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
+    int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
+                           // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
+    int num_cus = 256;
+    long sk_max_tiles = 4096;  // stream-K only for launches of at most this many tiles (8 rounds): the persistent kernel is
+                           // ~5 % slower than hardware dispatch on large launches, where the tail does not matter anyway
+    int sk_u1 = 0;         // stream-K for the U1 update of the look-ahead schedule (measured: no effect)
+    int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there
+                           // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
+    long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
+                           // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
+    bool gemm_pad_set = false;
+    int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
+    int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
+    long xcd_min_tiles = 256;
+    long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
+    gp_timings tm{};
+    std::vector<FreeBlock> pool;               // cached free device blocks (true sizes)
+    std::unordered_map<void*, size_t> blk;     // true size of every block handed out by ctx_alloc
+    size_t pool_bytes = 0;
+    size_t pool_cap = (size_t)96 << 30;        // bytes kept in the cache at most ("pool_cap_mb"; gp_ctx_trim drops it all)
+    long vfe_chunk = 8192;                     // data points per streamed VFE chunk (multiple of 2048)
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct GemmRec {
+        hipEvent_t a, b;
+        double flops, bytes;
+        long M, N, K;
+        int stream;  // 0 main, 1 panel
+    };
+    std::vector<GemmRec> gemm_recs;
+    hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* info_dev = nullptr;
+    int* ticket_dev = nullptr;   // load tickets of panel64_kernel ([0]: main stream, [32]: panel stream)
+    void* w_ws = nullptr;        // I − inv(L_jj) tiles for the MFMA triangular solve (trtri_64 output)
+    size_t w_ws_bytes = 0;
+    void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
+    double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
+    long scal_cap = 0;
+    std::atomic<int> refs{1};
+    bool dead = false;
+    struct gp_multi* multi = nullptr;  // non-null: a multi-device context (multi.hip); this ctx then is rank 0's device context
+};
+
+struct SkScope {
+    gp_ctx* c;
+    explicit SkScope(gp_ctx* c_) : c(c_) { ++c->sk_scope; }
+    ~SkScope() { --c->sk_scope; }
+};
+
+
+// ---- handle registry ------------------------------------------------------------------------------
+extern std::mutex g_reg_mu;
+extern std::set<void*> g_live;
+void reg_add(void* p);
+bool reg_take(void* p);
+bool reg_has(void* p);
+void ctx_unref(gp_ctx* c);
+int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out);
+void ctx_release(gp_ctx* c, void* p, size_t requested);
+int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing);
+int32_t ctx_scal(gp_ctx* c, long n);
+// Validates a handle (gp_ctx / gp_post / gp_vfe) and locks its ctx without racing a concurrent *_free / gp_ctx_destroy from
+// another thread: the ctx is pinned under the registry mutex, locked, and the handle is checked again under the ctx lock
+// (every *_free removes its handle from the registry BEFORE it takes the ctx lock to release the buffers).
+struct Guard {
+    gp_ctx* c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    bool ok = false;
+    static gp_ctx* ctx_of(gp_ctx* h) { return h; }
+    template <class H> static gp_ctx* ctx_of(H* h) { return h->ctx; }
+    template <class H> explicit Guard(H* h) {
+        {
+            std::lock_guard<std::mutex> l(g_reg_mu);
+            if (!h || !g_live.count((void*)h)) return;
+            c = ctx_of(h);
+            c->refs++;
+        }
+        lk = std::unique_lock<std::mutex>(c->mu);
+        ok = reg_has((void*)h) && !c->dead;
+    }
+    ~Guard() {
+        if (lk.owns_lock()) lk.unlock();
+        if (c) ctx_unref(c);
+    }
+};
+
+// RAII owner of the device blocks of one call: everything still owned when it goes out of scope returns to the ctx cache
+// (every early-return / error path included); keep() hands a block over to a handle.
+struct DevBufs {
+    gp_ctx* c;
+    std::vector<void*> v;
+    explicit DevBufs(gp_ctx* c_) : c(c_) {}
+    DevBufs(const DevBufs&) = delete;
+    int32_t get(size_t bytes, void** out) {
+        *out = nullptr;
+        int32_t rc = ctx_alloc(c, bytes ? bytes : 16, out);
+        if (rc == 0) v.push_back(*out);
+        return rc;
+    }
+    void* keep(void* p) {
+        for (auto& q : v)
+            if (q == p) q = nullptr;
+        return p;
+    }
+    ~DevBufs() {
+        for (void* q : v)
+            if (q) ctx_release(c, q, 0);
+    }
+};
+
+// ---- posterior handle -----------------------------------------------------------------------------
+struct gp_multi;
+struct gp_multi_post;  // multi.hip: block-cyclic pieces of a factor that has not been gathered yet
+struct gp_post {
+    gp_ctx* ctx;
+    int dtype;
+    long n, np, ld, mtot;
+    int d;
+    int kind;
+    double variance;
+    int nscale;
+    std::vector<double> scale;
+    void* A;
+    size_t A_bytes;  // factor (+ RHS rows)
+    void* xs;
+    size_t xs_bytes;  // scaled train inputs [d][np]
+    void* alpha;
+    size_t alpha_bytes;  // [np]
+    double logdet_half;  // Σ log L_ii
+    gp_multi_post* pieces = nullptr;  // multi-device fit: the factor still lives as block-cyclic pieces (A == nullptr until gathered)
+};
+
+// ---- engine entry points used by multi.hip (fp64; work is issued on stream s of ctx c and not synchronised) ----
+namespace gpmi {
+GridMap plain_map(int lower, long row0, long col0);
+int32_t eng_assemble(gp_ctx* c, hipStream_t s, int kind, double variance, const double* x_dev, long n_valid, long n_pad, int d,
+                     const double* noise_dev, GridMap g, double* a_loc, long lda, long m_loc, long n_loc);
+int32_t eng_potrf(gp_ctx* c, hipStream_t s, double* a, long lda, long m, long n, int* info_dev, long col0, long n_valid,
+                  double* logdet_dev);
+int32_t eng_trsm(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* l, long ldl, long n);
+int32_t eng_gemm_nt(gp_ctx* c, hipStream_t s, double* cm, long ldc, const double* a, long lda, const double* b, long ldb, long m,
+                    long n, long k, GridMap g);
+int32_t eng_trsv(gp_ctx* c, hipStream_t s, const double* l, long ldl, long np, double* r, long ldr, int nrhs, bool forward);
+int32_t eng_gemv_t(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nrows, long ncols, const double* a, double* r);
+int32_t eng_rowsumsq(gp_ctx* c, hipStream_t s, const double* x, long ldx, long nrows, long ncols, double* out_dev);
+int32_t eng_add_vec(gp_ctx* c, hipStream_t s, double* dst, const double* src, long n);  // dst += src
+}  // namespace gpmi
+
+// ---- multi-device contexts (multi.hip) --------------------------------------------------------------
+void multi_destroy(gp_multi* m);
+int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null,
+                  const void* Y, long ldy, int ncols, double* logpdf_out, gp_post* post, void* alpha_out);
+int32_t multi_gather(gp_post* post);  // block-cyclic pieces -> one row-major factor on the ctx's first device
+void multi_post_release(gp_post* post);
+int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v);  // 1 = not a multi parameter

@@ -6,8 +6,7 @@
 //   of the factorisation)  ->  backward substitution  ->  logpdf scalar and α.
 // Mirrors, on the device, reference src/finite_gp_projection.jl:306-311 and
 // src/exact_gpr_posterior.jl:29-35, 60-90 (see include/gpmi355.h for the per-entry citations).
-#include "kernels.hpp"
-#include "../../include/gpmi355.h"
+#include "kernels.hpp"  // includes engine.hpp (shared structs, registry, error helpers)
 
 #include <algorithm>
 #include <atomic>
@@ -29,146 +28,40 @@ using namespace gpmi;
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int32_t set_hip_err(hipError_t e, const char* what, int line) {
+int32_t set_err_text(int32_t status, const std::string& msg) {
+    g_err = msg;
+    return status;
+}
+int32_t set_hip_err(hipError_t e, const char* what, int line) {
     char buf[512];
     snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), what, line);
     g_err = buf;
     return -1000 - (int)e;
 }
-static int32_t set_arg_err(int i, const char* msg) {
+int32_t set_arg_err(int i, const char* msg) {
     g_err = std::string("invalid argument ") + std::to_string(i) + ": " + msg;
     return -i;
 }
-#define HIPCHK(expr)                                                   \
-    do {                                                               \
-        hipError_t e_ = (expr);                                        \
-        if (e_ != hipSuccess) return set_hip_err(e_, #expr, __LINE__); \
-    } while (0)
-#define RC(expr)                \
-    do {                        \
-        int32_t rc_ = (expr);   \
-        if (rc_ != 0) return rc_; \
-    } while (0)
-
-static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
-static const double LOG2PI = 1.8378770664093454835606594728112;
-
-// ------------------------------------------------------------------------------------------------
-// handles
-// ------------------------------------------------------------------------------------------------
-struct FreeBlock {
-    void* p;
-    size_t bytes;
-};
-
-struct gp_ctx {
-    int device = 0;
-    hipStream_t sm = nullptr;  // main stream (trailing updates, assembly, solves)
-    hipStream_t sp = nullptr;  // panel stream (look-ahead)
-    bool own_sm = false;
-    std::mutex mu;
-    long nb = 2048;        // outer panel width
-    int lookahead = 1;
-    int time_kernels = 0;
-    int gemm_variant = 0;
-    int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
-    int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
-    int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
-    int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
-    int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
-                           // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
-    int num_cus = 256;
-    long sk_max_tiles = 4096;  // stream-K only for launches of at most this many tiles (8 rounds): the persistent kernel is
-                           // ~5 % slower than hardware dispatch on large launches, where the tail does not matter anyway
-    int sk_u1 = 0;         // stream-K for the U1 update of the look-ahead schedule (measured: no effect)
-    int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there
-                           // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
-    long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
-                           // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
-    bool gemm_pad_set = false;
-    int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
-    int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
-    long xcd_min_tiles = 256;
-    long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
-    gp_timings tm{};
-    std::vector<FreeBlock> pool;               // cached free device blocks (true sizes)
-    std::unordered_map<void*, size_t> blk;     // true size of every block handed out by ctx_alloc
-    size_t pool_bytes = 0;
-    size_t pool_cap = (size_t)96 << 30;        // bytes kept in the cache at most ("pool_cap_mb"; gp_ctx_trim drops it all)
-    long vfe_chunk = 8192;                     // data points per streamed VFE chunk (multiple of 2048)
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    struct GemmRec {
-        hipEvent_t a, b;
-        double flops, bytes;
-        long M, N, K;
-        int stream;  // 0 main, 1 panel
-    };
-    std::vector<GemmRec> gemm_recs;
-    hipEvent_t ev_phase[4] = {nullptr, nullptr, nullptr, nullptr};
-    int* info_dev = nullptr;
-    int* ticket_dev = nullptr;   // load tickets of panel64_kernel ([0]: main stream, [32]: panel stream)
-    void* w_ws = nullptr;        // I − inv(L_jj) tiles for the MFMA triangular solve (trtri_64 output)
-    size_t w_ws_bytes = 0;
-    void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
-    double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
-    long scal_cap = 0;
-    std::atomic<int> refs{1};
-    bool dead = false;
-};
-
-struct SkScope {
-    gp_ctx* c;
-    explicit SkScope(gp_ctx* c_) : c(c_) { ++c->sk_scope; }
-    ~SkScope() { --c->sk_scope; }
-};
-
-static std::mutex g_reg_mu;
-static std::set<void*> g_live;
-static void reg_add(void* p) {
+std::mutex g_reg_mu;
+std::set<void*> g_live;
+void reg_add(void* p) {
     std::lock_guard<std::mutex> l(g_reg_mu);
     g_live.insert(p);
 }
-static bool reg_take(void* p) {
+bool reg_take(void* p) {
     std::lock_guard<std::mutex> l(g_reg_mu);
     return g_live.erase(p) > 0;
 }
-static bool reg_has(void* p) {
+bool reg_has(void* p) {
     std::lock_guard<std::mutex> l(g_reg_mu);
     return g_live.count(p) > 0;
 }
-static void ctx_unref(gp_ctx* c);
-// Validates a handle (gp_ctx / gp_post / gp_vfe) and locks its ctx without racing a concurrent *_free / gp_ctx_destroy from
-// another thread: the ctx is pinned under the registry mutex, locked, and the handle is checked again under the ctx lock
-// (every *_free removes its handle from the registry BEFORE it takes the ctx lock to release the buffers).
-struct Guard {
-    gp_ctx* c = nullptr;
-    std::unique_lock<std::mutex> lk;
-    bool ok = false;
-    static gp_ctx* ctx_of(gp_ctx* h) { return h; }
-    template <class H> static gp_ctx* ctx_of(H* h) { return h->ctx; }
-    template <class H> explicit Guard(H* h) {
-        {
-            std::lock_guard<std::mutex> l(g_reg_mu);
-            if (!h || !g_live.count((void*)h)) return;
-            c = ctx_of(h);
-            c->refs++;
-        }
-        lk = std::unique_lock<std::mutex>(c->mu);
-        ok = reg_has((void*)h) && !c->dead;
-    }
-    ~Guard() {
-        if (lk.owns_lock()) lk.unlock();
-        if (c) ctx_unref(c);
-    }
-};
-
 static void pool_drop(gp_ctx* c, size_t i) {
     c->pool_bytes -= c->pool[i].bytes;
     (void)hipFree(c->pool[i].p);
     c->pool.erase(c->pool.begin() + i);
 }
-static int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out) {
+int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out) {
     size_t best = (size_t)-1;
     int bi = -1;
     for (size_t i = 0; i < c->pool.size(); ++i)
@@ -193,7 +86,7 @@ static int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out) {
     c->blk[*out] = bytes;
     return 0;
 }
-static void ctx_release(gp_ctx* c, void* p, size_t /*requested*/) {
+void ctx_release(gp_ctx* c, void* p, size_t /*requested*/) {
     if (!p) return;
     size_t bytes = 0;
     auto it = c->blk.find(p);
@@ -210,30 +103,7 @@ static void ctx_release(gp_ctx* c, void* p, size_t /*requested*/) {
     // bound the cache by bytes and by count (a VFE fit alone cycles through ~16 buffers); oldest blocks go first
     while (c->pool.size() > 1 && (c->pool_bytes > c->pool_cap || c->pool.size() > 48)) pool_drop(c, 0);
 }
-// RAII owner of the device blocks of one call: everything still owned when it goes out of scope returns to the ctx cache
-// (every early-return / error path included); keep() hands a block over to a handle.
-struct DevBufs {
-    gp_ctx* c;
-    std::vector<void*> v;
-    explicit DevBufs(gp_ctx* c_) : c(c_) {}
-    DevBufs(const DevBufs&) = delete;
-    int32_t get(size_t bytes, void** out) {
-        *out = nullptr;
-        int32_t rc = ctx_alloc(c, bytes ? bytes : 16, out);
-        if (rc == 0) v.push_back(*out);
-        return rc;
-    }
-    void* keep(void* p) {
-        for (auto& q : v)
-            if (q == p) q = nullptr;
-        return p;
-    }
-    ~DevBufs() {
-        for (void* q : v)
-            if (q) ctx_release(c, q, 0);
-    }
-};
-static void ctx_unref(gp_ctx* c) {
+void ctx_unref(gp_ctx* c) {
     if (--c->refs != 0) return;
     (void)hipSetDevice(c->device);
     for (auto& b : c->pool) (void)hipFree(b.p);
@@ -250,7 +120,7 @@ static void ctx_unref(gp_ctx* c) {
     if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
     delete c;
 }
-static int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing) {
+int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing) {
     // timing events are separate objects (created on demand, pooled)
     if (c->ev_used == c->ev_pool.size()) {
         hipEvent_t e;
@@ -261,7 +131,7 @@ static int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing) {
     *out = c->ev_pool[c->ev_used++];
     return 0;
 }
-static int32_t ctx_scal(gp_ctx* c, long n) {
+int32_t ctx_scal(gp_ctx* c, long n) {
     if (c->scal_cap >= n) return 0;
     if (c->scal_dev) (void)hipFree(c->scal_dev);
     c->scal_cap = round_up(n, 1024);
@@ -374,7 +244,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
     return 0;
 }
 
-static GridMap plain_map(int lower, long row0, long col0) {
+GridMap gpmi::plain_map(int lower, long row0, long col0) {
     GridMap g;
     g.lower = lower;
     g.P = 1; g.p = 0; g.Q = 1; g.q = 0;
@@ -663,6 +533,56 @@ static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// engine entry points for multi.hip (declared in engine.hpp)
+// ------------------------------------------------------------------------------------------------
+int32_t gpmi::eng_assemble(gp_ctx* c, hipStream_t s, int kind, double variance, const double* x_dev, long n_valid, long n_pad, int d,
+                           const double* noise_dev, GridMap g, double* a_loc, long lda, long m_loc, long n_loc) {
+    (void)c;
+    dim3 grid((unsigned)(n_loc / 128), (unsigned)(m_loc / 128));
+    if (grid.x == 0 || grid.y == 0) return 0;
+    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d, kind, variance,
+                       noise_dev, n_valid, n_valid, 1, g, (const double*)nullptr, (const double*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int32_t gpmi::eng_potrf(gp_ctx* c, hipStream_t s, double* a, long lda, long m, long n, int* info_dev, long col0, long n_valid,
+                        double* logdet_dev) {
+    return potrf_rec<double>(c, s, a, lda, 0, n, m, info_dev, col0, n_valid, logdet_dev);
+}
+int32_t gpmi::eng_trsm(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* l, long ldl, long n) {
+    return trsm_rec_v<double>(c, s, x, ldx, m, l, ldl, n);
+}
+int32_t gpmi::eng_gemm_nt(gp_ctx* c, hipStream_t s, double* cm, long ldc, const double* a, long lda, const double* b, long ldb,
+                          long m, long n, long k, GridMap g) {
+    return launch_gemm<double>(c, s, cm, ldc, a, lda, b, ldb, m, n, k, g);
+}
+int32_t gpmi::eng_trsv(gp_ctx* c, hipStream_t s, const double* l, long ldl, long np, double* r, long ldr, int nrhs, bool forward) {
+    return trsv<double>(c, s, l, ldl, np, r, ldr, nrhs, forward);
+}
+int32_t gpmi::eng_gemv_t(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nrows, long ncols, const double* a, double* r) {
+    (void)c;
+    if (nrows <= 0 || ncols <= 0) return 0;
+    hipLaunchKernelGGL(gemv_t_kernel<double>, dim3((unsigned)((ncols + 255) / 256), (unsigned)((nrows + 63) / 64)), dim3(256), 0, s, l,
+                       ldl, nrows, ncols, a, r);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int32_t gpmi::eng_rowsumsq(gp_ctx* c, hipStream_t s, const double* x, long ldx, long nrows, long ncols, double* out_dev) {
+    (void)c;
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(rowsumsq_kernel<double>, dim3((unsigned)nrows), dim3(256), 0, s, x, ldx, ncols, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int32_t gpmi::eng_add_vec(gp_ctx* c, hipStream_t s, double* dst, const double* src, long n) {
+    (void)c;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side input marshalling
 // ------------------------------------------------------------------------------------------------
 template <typename T> static T pt_get(const gp_points* x, long i, int dd) {
@@ -705,23 +625,6 @@ static void scale_points(const gp_kernel* k, const gp_points* x, long ldx, std::
 // ------------------------------------------------------------------------------------------------
 // posterior handle
 // ------------------------------------------------------------------------------------------------
-struct gp_post {
-    gp_ctx* ctx;
-    int dtype;
-    long n, np, ld, mtot;
-    int d;
-    int kind;
-    double variance;
-    int nscale;
-    std::vector<double> scale;
-    void* A;
-    size_t A_bytes;  // factor (+ RHS rows)
-    void* xs;
-    size_t xs_bytes;  // scaled train inputs [d][np]
-    void* alpha;
-    size_t alpha_bytes;  // [np]
-    double logdet_half;  // Σ log L_ii
-};
 
 template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k, const T* xs_dev, long ldx, int d,
                                                   const T* noise_dev, long n, long np, T* A, long ld) {
@@ -1392,13 +1295,18 @@ int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null) {
 
 int32_t gp_ctx_destroy(gp_ctx* c) {
     if (!c || !reg_take(c)) return set_arg_err(1, "not a live gp_ctx");
+    gp_multi* multi = nullptr;
     {
         std::lock_guard<std::mutex> l(c->mu);
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
         c->dead = true;
+        multi = c->multi;
+        c->multi = nullptr;
     }
+    if (multi) multi_destroy(multi);  // rank contexts, comm streams, RCCL communicators (factor pieces still alive keep their rank ctx)
+    (void)hipSetDevice(c->device);
     ctx_unref(c);
     return 0;
 }
@@ -1407,6 +1315,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
     if (!name) return set_arg_err(2, "name is NULL");
     std::lock_guard<std::mutex> l(c->mu);
+    if (c->multi && multi_set_param(c, name, v) == 0) return 0;  // (generic names are forwarded to the rank contexts too)
     if (!strcmp(name, "nb")) c->nb = (v <= 0) ? 0 : round_up(v, 128);
     else if (!strcmp(name, "lookahead")) c->lookahead = v != 0;
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
@@ -1425,6 +1334,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
+    else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }
@@ -1513,8 +1423,14 @@ int32_t gp_logpdf(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     std::lock_guard<std::mutex> l(c->mu);
     HIPCHK(hipSetDevice(c->device));
     FitOut fo;
-    int32_t rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr)
-                               : fit_impl<float>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr);
+    int32_t rc;
+    if (c->multi) {  // 2D block-cyclic over the ctx's devices (multi.hip)
+        fo.logpdf.assign((size_t)ncols, 0.0);
+        rc = multi_fit(c, k, x, noise, mean, Y, ldy, ncols, fo.logpdf.data(), nullptr, nullptr);
+    } else {
+        rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr)
+                           : fit_impl<float>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr);
+    }
     if (rc != 0) return rc;
     for (int s = 0; s < ncols; ++s) {
         if (k->dtype == 0) ((double*)out)[s] = fo.logpdf[s];
@@ -1534,8 +1450,14 @@ int32_t gp_posterior_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     gp_post* p = new gp_post();
     p->ctx = c;
     FitOut fo;
-    int32_t rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out)
-                               : fit_impl<float>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out);
+    int32_t rc;
+    if (c->multi) {
+        fo.logpdf.assign(1, 0.0);
+        rc = multi_fit(c, k, x, noise, mean, y, x->n, 1, fo.logpdf.data(), p, alpha_out);
+    } else {
+        rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out)
+                           : fit_impl<float>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out);
+    }
     if (rc != 0) {
         delete p;
         return rc;
@@ -1562,6 +1484,7 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
     if ((what & 4) && !cov_out) return set_arg_err(7, "cov_out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    if (what & 6) RC(multi_gather(post));  // multi-device fit: the factor is assembled on this device on first need
     return post->dtype == 0 ? predict_impl<double>(post, xs, pm, what, mean_out, var_out, cov_out)
                             : predict_impl<float>(post, xs, pm, what, mean_out, var_out, cov_out);
 }
@@ -1590,6 +1513,7 @@ int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* n
     *out = nullptr;
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    RC(multi_gather(old));
     gp_post* p = new gp_post();
     double lp = 0;
     int32_t rc = old->dtype == 0 ? update_impl<double>(old, x2, noise2, delta_all, p, alpha_out, &lp)
@@ -1616,6 +1540,7 @@ int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, vo
     if (!out) return set_arg_err(4, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    RC(multi_gather(post));
     return post->dtype == 0 ? factor_mul_impl<double>(post, xi, ncols, out) : factor_mul_impl<float>(post, xi, ncols, out);
 }
 
@@ -1631,6 +1556,7 @@ int32_t gp_posterior_get_factor(gp_post* post, void* U_out) {
     if (!U_out) return set_arg_err(2, "U_out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    RC(multi_gather(post));
     const size_t es = post->dtype == 0 ? 8 : 4;
     const long n = post->n;
     // device row j (row-major lower L[j][0..j]) == host column j of the column-major upper U
@@ -1649,6 +1575,7 @@ int32_t gp_posterior_free(gp_post* post) {
     {
         std::lock_guard<std::mutex> l(c->mu);  // waits for any call still using the handle (Guard re-checks the registry under this lock)
         (void)hipSetDevice(c->device);
+        multi_post_release(post);
         ctx_release(c, post->A, post->A_bytes);
         ctx_release(c, post->xs, post->xs_bytes);
         ctx_release(c, post->alpha, post->alpha_bytes);
@@ -1872,6 +1799,7 @@ int32_t gp_posterior_logpdf(gp_post* post, const gp_points* xs, const void* pm, 
     if (!out) return set_arg_err(8, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    RC(multi_gather(post));
     DevBufs bufs(c);
     const long R = round_up(ncols, 128);
     int32_t rc;
@@ -1898,6 +1826,7 @@ int32_t gp_posterior_rand(gp_post* post, const gp_points* xs, const void* pm, co
     if (!out) return set_arg_err(7, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    RC(multi_gather(post));
     DevBufs bufs(c);
     int32_t rc;
     if (post->dtype == 0) {

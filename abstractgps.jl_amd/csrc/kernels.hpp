@@ -15,6 +15,7 @@
 //   kvec_kernel        K_*x α without materialising K_*x                    src/exact_gpr_posterior.jl:60-62
 #pragma once
 #include <hip/hip_runtime.h>
+#include "engine.hpp"
 #ifndef GPMI_GEMM_SCHED
 #define GPMI_GEMM_SCHED 1  // explicit MFMA / LDS interleave of the gemm k loop (sched_group_barrier)
 #endif
@@ -60,23 +61,7 @@ template <> struct Tr<float> {
     __device__ static inline int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
 
-// 2D block-cyclic bookkeeping shared by kmat and gemm: local absolute index -> global index.
-struct GridMap {
-    int lower;       // 1: skip tiles strictly above the global diagonal
-    int P, p, Q, q;  // process grid / my coordinates (1,0,1,0 on a single GPU)
-    long nb;         // distribution block in elements (multiple of 128); ignored when P=Q=1
-    long row0, col0; // local absolute index of the region's first row / column
-    int compact;     // 1: 1-D grid enumerating only the tiles on/below the diagonal (single-GPU lower mode)
-                     // 2 / 3: XCD-aware super-tile order (rectangular / lower trapezoid), see xcd_tile()
-    int tn, dt;      // compact: number of tile columns, diagonal offset in tiles (row tile i has min(tn, i+dt+1) tiles)
-    int tm;          // number of tile rows (modes 2, 3)
-    int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
-    int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
-                     // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
-    int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
-    long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
-    int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
-};
+// (struct GridMap lives in engine.hpp: it is shared with the host-only translation units)
 // compact lower-trapezoid enumeration: block b -> (bi, bj); rows i < tri have i+dt+1 tiles, the rest tn
 __device__ __forceinline__ void compact_tile(const GridMap& g, int b, int& bi, int& bj) {
     const int tri = (g.tn - g.dt) > 0 ? (g.tn - g.dt) : 0;  // rows of the triangular part (may exceed the grid's rows)
@@ -1802,6 +1787,11 @@ __global__ __launch_bounds__(256) void ystats_kernel(const T* __restrict__ Y, lo
         rowss[row] += red[0][0] + red[0][1] + red[0][2] + red[0][3];
         cacc[row] -= red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
+}
+// dst[i] += src[i]
+__global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ dst, const double* __restrict__ src, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
 }
 // A[i][i] += v[i] for i < n   (Σy* on the diagonal of a predictive covariance, src/finite_gp_projection.jl:133-136)
 template <typename T>

@@ -1,0 +1,968 @@
+// multi.hip — multi-device 2D block-cyclic driver of the logpdf + posterior pair, INSIDE libgpmi355 (host code only).
+//
+// The reference has no distributed path; its caller is ONE Julia process calling posterior(fx, y)
+// (src/exact_gpr_posterior.jl:29-35) / logpdf(fx, y) (src/finite_gp_projection.jl:306-311).  So the N devices of a node are
+// driven from that one process: gp_ctx_create_multi builds R = P·Q rank contexts (one device each, or several "virtual" ranks
+// sharing a device for tests), and gp_posterior_fit / gp_logpdf on such a ctx run the SPMD schedule below with ONE HOST
+// THREAD PER RANK.  Every numeric step is a call into the single-device engine (engine.hpp: eng_*), i.e. the same HIP
+// kernels as the 1-GPU path under the block-cyclic predicate (GridMap).
+//
+// Layout: K + Σy in NB×NB blocks, block (i, j) on rank (i mod P, j mod Q), lower blocks only; the y − m rows ride along as an
+// extra block row on process row 0 (forward substitution inside the factorisation).
+//
+// Schedule per block column k (look-ahead depth d, default 2; three streams per rank: main / panel / comm):
+//   panel stream : columns k+1..k+d are kept out of the bulk update; column k+1 gets panel k's update FIRST, is factored
+//                  (diagonal owner: Cholesky of the NB×NB block -> L_kk to the P−1 column peers; all owners X ← X L_kk⁻ᵀ)
+//                  and published; columns k+2..k+d get panel k's update behind it
+//   comm stream  : exchange(k+1) — every rank fetches exactly the panel blocks it consumes: its own process row's piece as
+//                  the A operand (rows in local row order) and the blocks of its own process column as the B operand (rows in
+//                  local COLUMN order — laid out in consumer order, no gather copy).  Volume per rank ≈ panel·(1/P + 1/Q)
+//   main stream  : bulk(k) — ONE MFMA GEMM over all local columns right of the look-ahead window
+// Transport ("comm" parameter): 1 = RCCL grouped ncclSend/ncclRecv between distinct peers (every pair has its own xGMI link:
+// the transfers of one step run on several links at once — a ring broadcast would be bound by one), 2 = peer copies pulled by
+// the consumer (hipMemcpy2DAsync over xGMI; the only mode possible for virtual ranks sharing one device), 0 = auto.
+// Default grid for ndev devices: P = ndev, Q = 1 — on a full-mesh point-to-point fabric the per-link volume is what bounds
+// the exchange: a rank then receives (P−1)/P of each panel spread evenly over P−1 links (≈2.2 GB per link at N = 65 536 on 8
+// devices, against ≈10.7 GB on the busiest link of a 2×4 grid); any P×Q can be requested.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace gpmi;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, loaded lazily (the single-device path never touches it)
+// ------------------------------------------------------------------------------------------------
+typedef void* ncclComm_t_;
+struct Rccl {
+    void* h = nullptr;
+    int (*CommInitAll)(ncclComm_t_*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string err;
+    bool load() {
+        if (h) return ok;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) {
+            err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "?");
+            h = (void*)1;
+            return false;
+        }
+#define GPMI_SYM(field, name)                                 \
+    field = (decltype(field))dlsym(h, name);                  \
+    if (!field) {                                             \
+        err = std::string("librccl lacks ") + name;           \
+        return false;                                         \
+    }
+        GPMI_SYM(CommInitAll, "ncclCommInitAll");
+        GPMI_SYM(CommDestroy, "ncclCommDestroy");
+        GPMI_SYM(GroupStart, "ncclGroupStart");
+        GPMI_SYM(GroupEnd, "ncclGroupEnd");
+        GPMI_SYM(Send, "ncclSend");
+        GPMI_SYM(Recv, "ncclRecv");
+        GPMI_SYM(GetErrorString, "ncclGetErrorString");
+#undef GPMI_SYM
+        ok = true;
+        return true;
+    }
+};
+constexpr int NCCL_FLOAT64 = 8;  // ncclDataType_t::ncclFloat64 (rccl.h)
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+// ------------------------------------------------------------------------------------------------
+// cross-thread event: the producer rank records it on one of its streams and publishes the fit sequence number; a consumer
+// (another rank's host thread) waits for the publication on the HOST, then makes ITS stream wait for the event on the device
+// ------------------------------------------------------------------------------------------------
+struct XEvent {
+    hipEvent_t ev = nullptr;
+    std::atomic<long> gen{0};
+};
+
+constexpr long RHS_ROWS = 128;
+
+}  // namespace
+
+struct MRank {
+    int r = 0, p = 0, q = 0, device = 0;
+    gp_ctx* c = nullptr;       // rank context: main stream c->sm, panel stream c->sp
+    hipStream_t sc = nullptr;  // comm stream
+    ncclComm_t_ comm = nullptr;
+    std::vector<XEvent> ready, lkk, accr, alr;  // per block column k (see fit_rank)
+    std::vector<hipEvent_t> own;                 // own-thread events (arrived / bulk_done / la_done), pooled
+    // per-fit state (device pointers owned through DevBufs of the rank thread; shared with peers for the pulls)
+    double* A = nullptr;
+    long ld = 0, m_loc = 0, n_loc = 0;
+    double* Lkk = nullptr;
+    double* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* acc = nullptr;       // backward sweep: per local column partial sums
+    double* alpha_blk = nullptr; // backward sweep: α blocks computed by this rank (diagonal owner), indexed by global block
+    int32_t rc = 0;
+    std::string err;
+    double gemm_ms = 0, gemm_flops = 0;
+    long gemm_launches = 0;
+    double t_ms = 0;
+};
+
+struct gp_multi {
+    int P = 1, Q = 1, R = 1;
+    long nb = 1024;
+    int depth = 2;   // look-ahead depth (columns kept ahead of the bulk update)
+    int comm = 2;    // 1 RCCL, 2 peer copies
+    bool virt = false;  // several ranks share a device
+    std::vector<MRank> ranks;
+    std::atomic<int> abort{0};
+    long seq = 0;    // fit sequence number (XEvent generations)
+    std::string comm_note;
+};
+
+struct gp_multi_post {
+    gp_multi* m = nullptr;
+    long n = 0, npad = 0, nblk = 0, nb = 0;
+    struct Piece {
+        gp_ctx* c;
+        void* A;
+        long ld, m_loc, n_loc;
+    };
+    std::vector<Piece> pieces;  // one per rank
+};
+
+namespace {
+
+inline long nlb_before(long k, long p, long P) { return k >= p ? (k - p) / P + 1 : 0; }  // #global blocks i <= k with i ≡ p (mod P)
+
+struct Dims {
+    long n, npad, nblk, NB, nlb_r, nlb_c, LDP;
+    int d;
+};
+
+#define MCHK(expr)                                                          \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) return set_hip_err(e_, #expr, __LINE__);      \
+    } while (0)
+
+// ---- helpers of one rank thread ---------------------------------------------------------------------------------
+struct RankRun {
+    gp_multi* M;
+    MRank* me;
+    Dims dm;
+    long seq;
+    size_t own_used = 0;
+
+    int32_t own_event(hipEvent_t* out) {
+        if (own_used == me->own.size()) {
+            hipEvent_t e;
+            MCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            me->own.push_back(e);
+        }
+        *out = me->own[own_used++];
+        return 0;
+    }
+    int32_t publish(XEvent& x, hipStream_t s) {
+        MCHK(hipEventRecord(x.ev, s));
+        x.gen.store(seq, std::memory_order_release);
+        return 0;
+    }
+    // make stream s of THIS rank wait for x of another rank's thread
+    int32_t await(XEvent& x, hipStream_t s) {
+        long spins = 0;
+        while (x.gen.load(std::memory_order_acquire) < seq) {
+            if (M->abort.load(std::memory_order_relaxed)) return set_err_text(-1999, "multi-device fit aborted: another rank failed");
+            if (++spins > 64) std::this_thread::yield();
+        }
+        MCHK(hipStreamWaitEvent(s, x.ev, 0));
+        return 0;
+    }
+    // 2-D block copy into one of my buffers from a buffer of rank src (possibly on another device), on my stream s
+    int32_t pull(hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols) {
+        if (rows <= 0 || cols <= 0) return 0;
+        MCHK(hipMemcpy2DAsync(dst, sizeof(double) * dld, src, sizeof(double) * sld, sizeof(double) * cols, rows, hipMemcpyDefault, s));
+        return 0;
+    }
+};
+
+int32_t nccl_err(int rc, const char* what) {
+    if (rc == 0) return 0;
+    return set_err_text(-1998, std::string("RCCL error in ") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+}
+#define NCHK(expr) RC(nccl_err((expr), #expr))
+
+// The whole pair on one rank.  Y-columns ride as RHS rows; alpha (column 0) only when want_alpha.
+int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double variance, const double* xs_h, const double* noise_h,
+                 const double* rhs_h /* ncols × npad */, int ncols, bool want_alpha, bool keep, double* alpha_host /* npad, pinned */,
+                 double* scal_out /* [0] Σlog L_ii, [1] unused, [8+s] ‖z_s‖² partial */, int* info_out, DevBufs& bufs, long seq) {
+    const int P = M->P, Q = M->Q, p = me->p, q = me->q, depth = M->depth;
+    const long NB = dm.NB, nblk = dm.nblk, npad = dm.npad, n = dm.n, LDP = dm.LDP;
+    const long nlb_r = dm.nlb_r, nlb_c = dm.nlb_c;
+    const bool rhs_row = (p == 0);
+    const long m_loc = nlb_r * NB + (rhs_row ? RHS_ROWS : 0), n_loc = nlb_c * NB;
+    const long ld = n_loc + 32;
+    const int NBUF = depth + 1;
+    gp_ctx* c = me->c;
+    hipStream_t sm = c->sm, sp = c->sp, sc = me->sc;
+    RankRun rr{M, me, dm, seq};
+    MCHK(hipSetDevice(me->device));
+    const bool rccl = (M->comm == 1);
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    if (!c->info_dev) MCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    RC(ctx_scal(c, 8 + RHS_ROWS));
+
+    // ---- buffers
+    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0;
+    void* Ab_v[4] = {0, 0, 0, 0};
+    void* Bb_v[4] = {0, 0, 0, 0};
+    void* St_v[4] = {0, 0, 0, 0};
+    const size_t A_b = sizeof(double) * (size_t)(m_loc + 128) * ld;
+    RC(bufs.get(A_b, &A_v));
+    RC(bufs.get(sizeof(double) * (size_t)dm.d * npad, &xs_v));
+    RC(bufs.get(sizeof(double) * (size_t)npad, &nz_v));
+    RC(bufs.get(sizeof(double) * (size_t)(NB + 128) * LDP, &Lkk_v));
+    RC(bufs.get(sizeof(double) * (size_t)(n_loc + 128), &acc_v));
+    RC(bufs.get(sizeof(double) * (size_t)npad, &ab_v));
+    RC(bufs.get(sizeof(double) * (size_t)NB * (P + 1), &tmp_v));
+    for (int s = 0; s < NBUF; ++s) {
+        if (Q > 1) RC(bufs.get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &Ab_v[s]));
+        RC(bufs.get(sizeof(double) * (size_t)(n_loc + 128) * LDP, &Bb_v[s]));
+        if (rccl) RC(bufs.get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &St_v[s]));
+    }
+    double* A = (double*)A_v;
+    me->A = A; me->ld = ld; me->m_loc = m_loc; me->n_loc = n_loc;
+    me->Lkk = (double*)Lkk_v;
+    me->acc = (double*)acc_v;
+    me->alpha_blk = (double*)ab_v;
+    for (int s = 0; s < 4; ++s) me->stage[s] = (double*)St_v[s];
+
+    GridMap g = plain_map(1, 0, 0);
+    g.P = P; g.p = p; g.Q = Q; g.q = q; g.nb = NB;
+
+    auto rows_from = [&](long gblk, int pp) { return nlb_before(gblk - 1, pp, P) * NB; };  // first local row (process row pp) with global block >= gblk
+    auto mloc_of = [&](int pp) { return nlb_r * NB + (pp == 0 ? RHS_ROWS : 0); };
+    auto cols_from = [&](long gblk) { return nlb_before(gblk - 1, q, Q) * NB; };             // first local column with global block >= gblk
+    auto rank_of = [&](int pp, int qq) -> MRank& { return M->ranks[(size_t)pp * Q + qq]; };
+
+    // ---- upload + assemble
+    MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)dm.d * npad, hipMemcpyHostToDevice, sm));
+    MCHK(hipMemcpyAsync(nz_v, noise_h, sizeof(double) * (size_t)npad, hipMemcpyHostToDevice, sm));
+    MCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), sm));
+    MCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * (8 + RHS_ROWS), sm));
+    MCHK(hipMemsetAsync(acc_v, 0, sizeof(double) * (size_t)(n_loc + 128), sm));
+    MCHK(hipMemsetAsync(A + nlb_r * NB * ld, 0, sizeof(double) * (size_t)(m_loc - nlb_r * NB + 128) * ld, sm));  // RHS + slack rows
+    for (int s = 0; s < NBUF; ++s) {  // slack rows of the operand buffers are over-read by the GEMM: keep them finite
+        if (Ab_v[s]) MCHK(hipMemsetAsync(Ab_v[s], 0, sizeof(double) * (size_t)(m_loc + 128) * LDP, sm));
+        MCHK(hipMemsetAsync(Bb_v[s], 0, sizeof(double) * (size_t)(n_loc + 128) * LDP, sm));
+        if (St_v[s]) MCHK(hipMemsetAsync(St_v[s], 0, sizeof(double) * (size_t)(m_loc + 128) * LDP, sm));
+    }
+    MCHK(hipMemsetAsync(Lkk_v, 0, sizeof(double) * (size_t)(NB + 128) * LDP, sm));
+    RC(eng_assemble(c, sm, kind, variance, (const double*)xs_v, n, npad, dm.d, (const double*)nz_v, g, A, ld, nlb_r * NB, n_loc));
+    if (rhs_row) {  // RHS rows: δ_sᵀ restricted to my local columns (global block lj·Q + q)
+        for (int s = 0; s < ncols; ++s)
+            for (long lj = 0; lj < nlb_c; ++lj)
+                MCHK(hipMemcpyAsync(A + (nlb_r * NB + s) * ld + lj * NB, rhs_h + (size_t)s * npad + (lj * Q + q) * NB, sizeof(double) * NB,
+                                    hipMemcpyHostToDevice, sm));
+    }
+    hipEvent_t ev_asm;
+    RC(rr.own_event(&ev_asm));
+    MCHK(hipEventRecord(ev_asm, sm));
+    MCHK(hipStreamWaitEvent(sp, ev_asm, 0));
+    MCHK(hipStreamWaitEvent(sc, ev_asm, 0));
+
+    std::vector<hipEvent_t> arrived((size_t)nblk, nullptr), bulk_done((size_t)nblk, nullptr), la_done((size_t)nblk, nullptr);
+
+    // A operand of panel i for my rows: my own matrix columns when I sit in the owner column, else the fetched copy
+    auto a_operand = [&](long i, const double** ptr, long* lda) {
+        if (q == (int)(i % Q)) {
+            *ptr = A + (i / Q) * NB;
+            *lda = ld;
+        } else {
+            *ptr = (const double*)Ab_v[i % NBUF];
+            *lda = LDP;
+        }
+    };
+    // C[rows >= global block gr0, local columns [c_lo, c_hi)] -= panel_i(rows) · panel_i(cols)ᵀ   (lower part only)
+    auto update = [&](hipStream_t s, long i, long gr0, long c_lo, long c_hi) -> int32_t {
+        const long r0 = rows_from(gr0, p);
+        const long mrows = m_loc - r0, ncolsu = c_hi - c_lo;
+        if (mrows <= 0 || ncolsu <= 0) return 0;
+        const double* ap;
+        long lda;
+        a_operand(i, &ap, &lda);
+        GridMap gm = g;
+        gm.row0 = r0;
+        gm.col0 = c_lo;
+        const size_t before = c->gemm_recs.size();
+        RC(eng_gemm_nt(c, s, A + r0 * ld + c_lo, ld, ap + r0 * lda, lda, (const double*)Bb_v[i % NBUF] + c_lo * LDP, LDP, mrows, ncolsu, NB, gm));
+        if (c->gemm_recs.size() > before) {  // exact algorithmic flops of this launch: local elements on/below the global diagonal × 2·NB
+            double cnt = 0;
+            for (long lj = c_lo / NB; lj < c_hi / NB; ++lj) {
+                const long gj = lj * Q + q;
+                for (long li = r0 / NB; li < nlb_r; ++li) {
+                    const long gi = li * P + p;
+                    cnt += gi > gj ? (double)NB * NB : (gi == gj ? (double)NB * (NB + 1) / 2 : 0.0);
+                }
+                if (rhs_row) cnt += (double)RHS_ROWS * NB;
+            }
+            c->gemm_recs.back().flops = 2.0 * NB * cnt;
+        }
+        return 0;
+    };
+
+    hipEvent_t lkk_free = nullptr;  // RCCL: my L_kk image may be overwritten again after this event
+    // factor block column k on its owners (panel stream) and publish it
+    auto panel = [&](long k) -> int32_t {
+        const int pk = (int)(k % P), qk = (int)(k % Q);
+        if (q != qk) return 0;
+        const long c0 = (k / Q) * NB;
+        if (P == 1) {
+            const long r0 = k * NB;  // (k / P) * NB
+            RC(eng_potrf(c, sp, A + r0 * ld + c0, ld, m_loc - r0, NB, c->info_dev, k * NB, n, c->scal_dev));
+        } else {
+            const double* lkk_ptr;
+            long lkk_ld;
+            // (RCCL: every collective of a rank is issued on ITS comm stream, in the same global order on all ranks — L_kk(k),
+            //  then exchange(k) — and chained to the panel stream by events)
+            if (p == pk) {
+                const long r0 = (k / P) * NB;
+                RC(eng_potrf(c, sp, A + r0 * ld + c0, ld, NB, NB, c->info_dev, k * NB, n, c->scal_dev));
+                lkk_ptr = A + r0 * ld + c0;
+                lkk_ld = ld;
+                if (rccl) {  // contiguous image for the sends
+                    if (lkk_free) MCHK(hipStreamWaitEvent(sp, lkk_free, 0));
+                    RC(rr.pull(sp, me->Lkk, LDP, lkk_ptr, ld, NB, NB));
+                    hipEvent_t e;
+                    RC(rr.own_event(&e));
+                    MCHK(hipEventRecord(e, sp));
+                    MCHK(hipStreamWaitEvent(sc, e, 0));
+                    NCHK(g_rccl.GroupStart());
+                    for (int pp = 0; pp < P; ++pp)
+                        if (pp != pk) NCHK(g_rccl.Send(me->Lkk, (size_t)NB * LDP, NCCL_FLOAT64, rank_of(pp, qk).r, me->comm, sc));
+                    NCHK(g_rccl.GroupEnd());
+                    RC(rr.own_event(&lkk_free));
+                    MCHK(hipEventRecord(lkk_free, sc));
+                }
+                RC(rr.publish(me->lkk[k], sp));
+            } else {
+                MRank& own = rank_of(pk, qk);
+                if (rccl) {
+                    if (lkk_free) MCHK(hipStreamWaitEvent(sc, lkk_free, 0));  // the previous L_kk image has been consumed by my trsm
+                    NCHK(g_rccl.Recv(me->Lkk, (size_t)NB * LDP, NCCL_FLOAT64, own.r, me->comm, sc));
+                    hipEvent_t e;
+                    RC(rr.own_event(&e));
+                    MCHK(hipEventRecord(e, sc));
+                    MCHK(hipStreamWaitEvent(sp, e, 0));
+                } else {
+                    RC(rr.await(own.lkk[k], sp));
+                    RC(rr.pull(sp, me->Lkk, LDP, own.A + (k / P) * NB * own.ld + c0, own.ld, NB, NB));
+                }
+                lkk_ptr = me->Lkk;
+                lkk_ld = LDP;
+            }
+            const long r0b = rows_from(k + 1, p);
+            if (m_loc - r0b > 0) RC(eng_trsm(c, sp, A + r0b * ld + c0, ld, m_loc - r0b, lkk_ptr, lkk_ld, NB));
+            if (rccl && p != pk) {
+                RC(rr.own_event(&lkk_free));
+                MCHK(hipEventRecord(lkk_free, sp));
+            }
+        }
+        if (rccl) {  // contiguous image of my piece (rows below k, all of them incl. RHS rows) for the sends of exchange(k)
+            const long r0b = rows_from(k + 1, p);
+            RC(rr.pull(sp, me->stage[k % NBUF] + r0b * LDP, LDP, A + r0b * ld + c0, ld, m_loc - r0b, NB));
+        }
+        RC(rr.publish(me->ready[k], sp));
+        return 0;
+    };
+
+    // fetch what I consume of panel k into buffer set k % NBUF (comm stream)
+    auto exchange = [&](long k) -> int32_t {
+        const int qk = (int)(k % Q);
+        const int s = (int)(k % NBUF);
+        if (k - NBUF >= 0) {  // the set's previous panel must have been consumed
+            if (bulk_done[k - NBUF]) MCHK(hipStreamWaitEvent(sc, bulk_done[k - NBUF], 0));
+            if (la_done[k - NBUF]) MCHK(hipStreamWaitEvent(sc, la_done[k - NBUF], 0));
+        }
+        double* Ab = (double*)Ab_v[s];
+        double* Bb = (double*)Bb_v[s];
+        if (!rccl) {
+            // A part: my process row's piece, rows in local row order (nothing to fetch when I own the column)
+            if (q != qk) {
+                MRank& src = rank_of(p, qk);
+                const long r0 = rows_from(k + 1, p);
+                RC(rr.await(src.ready[k], sc));
+                RC(rr.pull(sc, Ab + r0 * LDP, LDP, src.A + r0 * src.ld + (k / Q) * NB, src.ld, m_loc - r0, NB));
+            }
+            // B part: the global blocks of my process column, rows in local column order
+            for (int pp = 0; pp < P; ++pp) {
+                MRank& src = rank_of(pp, qk);
+                bool waited = false;
+                for (long lj = nlb_before(k, q, Q); lj < nlb_c; ++lj) {
+                    const long gj = lj * Q + q;
+                    if ((int)(gj % P) != pp) continue;
+                    if (!waited) {
+                        RC(rr.await(src.ready[k], sc));
+                        waited = true;
+                    }
+                    RC(rr.pull(sc, Bb + lj * NB * LDP, LDP, src.A + (gj / P) * NB * src.ld + (k / Q) * NB, src.ld, NB, NB));
+                }
+            }
+        } else {
+            // the same transfers as matched ncclSend / ncclRecv pairs of ONE group per rank (all peers progress concurrently);
+            // both sides enumerate (source process row, destination rank, block) in the same order
+            if (q == qk) MCHK(hipStreamWaitEvent(sc, me->ready[k].ev, 0));  // my own piece (recorded by this thread on sp)
+            NCHK(g_rccl.GroupStart());
+            for (int pp = 0; pp < P; ++pp) {
+                MRank& src = rank_of(pp, qk);
+                const long r0s = rows_from(k + 1, pp), ms = mloc_of(pp);
+                for (int dp = 0; dp < P; ++dp)
+                    for (int dq = 0; dq < Q; ++dq) {
+                        MRank& dst = rank_of(dp, dq);
+                        const bool i_send = (&src == me), i_recv = (&dst == me);
+                        if (!i_send && !i_recv) continue;
+                        if (dp == pp && dq != qk && ms - r0s > 0) {  // A part
+                            if (i_send) NCHK(g_rccl.Send(me->stage[s] + r0s * LDP, (size_t)(ms - r0s) * LDP, NCCL_FLOAT64, dst.r, me->comm, sc));
+                            if (i_recv) NCHK(g_rccl.Recv(Ab + r0s * LDP, (size_t)(ms - r0s) * LDP, NCCL_FLOAT64, src.r, me->comm, sc));
+                        }
+                        for (long lj = nlb_before(k, dq, Q); lj < nlb_c; ++lj) {  // B part
+                            const long gj = lj * Q + dq;
+                            if ((int)(gj % P) != pp) continue;
+                            const long srow = (gj / P) * NB;
+                            if (i_send && i_recv) {
+                                RC(rr.pull(sc, Bb + lj * NB * LDP, LDP, me->stage[s] + srow * LDP, LDP, NB, NB));
+                            } else if (i_send) {
+                                NCHK(g_rccl.Send(me->stage[s] + srow * LDP, (size_t)NB * LDP, NCCL_FLOAT64, dst.r, me->comm, sc));
+                            } else {
+                                NCHK(g_rccl.Recv(Bb + lj * NB * LDP, (size_t)NB * LDP, NCCL_FLOAT64, src.r, me->comm, sc));
+                            }
+                        }
+                    }
+            }
+            NCHK(g_rccl.GroupEnd());
+        }
+        RC(rr.own_event(&arrived[k]));
+        MCHK(hipEventRecord(arrived[k], sc));
+        return 0;
+    };
+
+    // look-ahead update of block column j with panel i on the panel stream
+    auto la_update = [&](long j, long i) -> int32_t {
+        if (q != (int)(j % Q)) return 0;
+        MCHK(hipStreamWaitEvent(sp, arrived[i], 0));
+        const long first = std::max(0L, j - depth);
+        if (i == first && first - 1 >= 0 && bulk_done[first - 1]) MCHK(hipStreamWaitEvent(sp, bulk_done[first - 1], 0));
+        const long c0 = (j / Q) * NB;
+        return update(sp, i, j, c0, c0 + NB);
+    };
+
+    RC(panel(0));
+    RC(exchange(0));
+    for (long k = 0; k < nblk; ++k) {
+        if (k + 1 < nblk) {
+            RC(la_update(k + 1, k));  // column k+1 first: it is on the critical path
+            RC(panel(k + 1));
+            RC(exchange(k + 1));
+            for (long j = k + 2; j <= std::min(k + depth, nblk - 1); ++j) RC(la_update(j, k));
+        }
+        RC(rr.own_event(&la_done[k]));
+        MCHK(hipEventRecord(la_done[k], sp));
+        // bulk of the trailing update: every local column right of the look-ahead window
+        MCHK(hipStreamWaitEvent(sm, arrived[k], 0));
+        const long gfirst = k + depth + 1;
+        if (gfirst < nblk) RC(update(sm, k, gfirst, cols_from(gfirst), n_loc));
+        else if (rhs_row) {
+            // no matrix columns left, nothing to do (RHS rows were updated with their columns)
+        }
+        RC(rr.own_event(&bulk_done[k]));
+        MCHK(hipEventRecord(bulk_done[k], sm));
+    }
+    // join the panel stream into the main stream
+    {
+        hipEvent_t e;
+        RC(rr.own_event(&e));
+        MCHK(hipEventRecord(e, sp));
+        MCHK(hipStreamWaitEvent(sm, e, 0));
+        RC(rr.own_event(&e));
+        MCHK(hipEventRecord(e, sc));
+        MCHK(hipStreamWaitEvent(sm, e, 0));
+    }
+    // ---- ‖z_s‖² over my local columns of the RHS rows
+    if (rhs_row) RC(eng_rowsumsq(c, sm, A + nlb_r * NB * ld, ld, ncols, n_loc, c->scal_dev + 8));
+
+    // ---- backward substitution α = L⁻ᵀ z (column 0), block sweep from the last block column
+    if (want_alpha) {
+        double* acc = me->acc;
+        double* tmp = (double*)tmp_v;
+        for (long k = nblk - 1; k >= 0; --k) {
+            const int pk = (int)(k % P), qk = (int)(k % Q);
+            const long c0 = (k / Q) * NB;
+            if (q == qk) {
+                if (rhs_row) RC(eng_add_vec(c, sm, acc + c0, A + nlb_r * NB * ld + c0, NB));  // + z_k from the RHS row
+                if (p == pk) {
+                    double* ak = me->alpha_blk + k * NB;
+                    MCHK(hipMemcpyAsync(ak, acc + c0, sizeof(double) * NB, hipMemcpyDeviceToDevice, sm));
+                    for (int pp = 0; pp < P; ++pp) {  // + the partial sums of the other process rows
+                        if (pp == pk) continue;
+                        MRank& src = rank_of(pp, qk);
+                        if (rccl) {
+                            NCHK(g_rccl.Recv(tmp + (size_t)pp * NB, (size_t)NB, NCCL_FLOAT64, src.r, me->comm, sm));
+                        } else {
+                            RC(rr.await(src.accr[k], sm));
+                            RC(rr.pull(sm, tmp + (size_t)pp * NB, NB, src.acc + c0, NB, 1, NB));
+                        }
+                        RC(eng_add_vec(c, sm, ak, tmp + (size_t)pp * NB, NB));
+                    }
+                    RC(eng_trsv(c, sm, A + (k / P) * NB * ld + c0, ld, NB, ak, NB, 1, false));
+                    MCHK(hipMemcpyAsync(alpha_host + k * NB, ak, sizeof(double) * NB, hipMemcpyDeviceToHost, sm));
+                    if (rccl) {
+                        NCHK(g_rccl.GroupStart());
+                        for (int qq = 0; qq < Q; ++qq)
+                            if (qq != qk) NCHK(g_rccl.Send(ak, (size_t)NB, NCCL_FLOAT64, rank_of(pk, qq).r, me->comm, sm));
+                        NCHK(g_rccl.GroupEnd());
+                    }
+                    RC(rr.publish(me->alr[k], sm));
+                } else {
+                    if (rccl) NCHK(g_rccl.Send(acc + c0, (size_t)NB, NCCL_FLOAT64, rank_of(pk, qk).r, me->comm, sm));
+                    RC(rr.publish(me->accr[k], sm));
+                }
+            }
+            if (p == pk && k > 0) {  // my block row k: acc_j −= L[k][j]ᵀ α_k for my local columns j < k
+                const long ncb = nlb_before(k - 1, q, Q);
+                if (ncb > 0) {
+                    const double* ak;
+                    if (q == qk) {
+                        ak = me->alpha_blk + k * NB;
+                    } else {
+                        MRank& own = rank_of(pk, qk);
+                        double* dst = tmp + (size_t)P * NB;
+                        if (rccl) {
+                            NCHK(g_rccl.Recv(dst, (size_t)NB, NCCL_FLOAT64, own.r, me->comm, sm));
+                        } else {
+                            RC(rr.await(own.alr[k], sm));
+                            RC(rr.pull(sm, dst, NB, own.alpha_blk + k * NB, NB, 1, NB));
+                        }
+                        ak = dst;
+                    }
+                    RC(eng_gemv_t(c, sm, A + (k / P) * NB * ld, ld, NB, ncb * NB, ak, acc));
+                }
+            } else if (rccl && p == pk && k == 0) {
+                // nothing to receive: block row 0 has no columns left of the diagonal
+            }
+        }
+    }
+    // ---- results of this rank
+    MCHK(hipMemcpyAsync(info_out, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, sm));
+    MCHK(hipMemcpyAsync(scal_out, c->scal_dev, sizeof(double) * (8 + RHS_ROWS), hipMemcpyDeviceToHost, sm));
+    MCHK(hipStreamSynchronize(sm));
+    MCHK(hipStreamSynchronize(sp));
+    MCHK(hipStreamSynchronize(sc));
+    me->gemm_ms = me->gemm_flops = 0;
+    me->gemm_launches = (long)c->gemm_recs.size();
+    for (auto& r : c->gemm_recs) {
+        float ms = 0;
+        MCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        me->gemm_ms += ms;
+        me->gemm_flops += r.flops;
+    }
+    if (keep) bufs.keep(A_v);
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// entry points (engine.hpp)
+// ------------------------------------------------------------------------------------------------
+void multi_destroy(gp_multi* m) {
+    if (!m) return;
+    for (auto& rk : m->ranks) {
+        (void)hipSetDevice(rk.device);
+        if (rk.comm && g_rccl.ok) (void)g_rccl.CommDestroy(rk.comm);
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr})
+            for (auto& x : *v)
+                if (x.ev) (void)hipEventDestroy(x.ev);
+        for (auto e : rk.own) (void)hipEventDestroy(e);
+        if (rk.sc) (void)hipStreamDestroy(rk.sc);
+        if (rk.c) (void)gp_ctx_destroy(rk.c);
+    }
+    delete m;
+}
+
+int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
+    gp_multi* m = c->multi;
+    if (!m) return 1;
+    if (!strcmp(name, "lookahead_depth")) {
+        m->depth = (int)std::min<int64_t>(3, std::max<int64_t>(1, v));
+        return 0;
+    }
+    if (!strcmp(name, "dist_nb")) {
+        m->nb = std::max<int64_t>(128, (v + 127) / 128 * 128);
+        return 0;
+    }
+    // every other parameter also goes to the rank contexts (kernel variants, timing switches)
+    for (auto& rk : m->ranks) (void)gp_ctx_set_param(rk.c, name, v);
+    return 1;
+}
+
+extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int32_t ndev, int32_t P, int32_t Q, int32_t nb) {
+    if (!out) return set_arg_err(1, "out is NULL");
+    *out = nullptr;
+    if (!devices || ndev < 1) return set_arg_err(2, "devices / ndev");
+    if (P <= 0 && Q <= 0) {
+        P = ndev;  // full-mesh point-to-point fabric: as many distinct peers per exchange as possible (see the header comment)
+        Q = 1;
+    } else if (P <= 0) {
+        P = ndev / Q;
+    } else if (Q <= 0) {
+        Q = ndev / P;
+    }
+    if (P * Q != ndev) return set_arg_err(4, "P * Q must equal ndev");
+    if (nb <= 0) nb = 1024;
+    if (nb % 128) return set_arg_err(6, "nb must be a multiple of 128");
+    int devcount = 0;
+    MCHK(hipGetDeviceCount(&devcount));
+    bool dup = false;
+    for (int i = 0; i < ndev; ++i) {
+        if (devices[i] < 0 || devices[i] >= devcount) return set_arg_err(2, "no such device (fewer GPUs visible than requested)");
+        for (int j = 0; j < i; ++j) dup = dup || devices[i] == devices[j];
+    }
+    gp_ctx* main_ctx = nullptr;
+    RC(gp_ctx_create(&main_ctx, devices[0], nullptr));
+    gp_multi* m = new gp_multi();
+    m->P = P; m->Q = Q; m->R = ndev; m->nb = nb; m->virt = dup;
+    m->ranks.resize((size_t)ndev);
+    int32_t rc = 0;
+    for (int r = 0; r < ndev && rc == 0; ++r) {
+        MRank& rk = m->ranks[r];
+        rk.r = r; rk.p = r / Q; rk.q = r % Q; rk.device = devices[r];
+        rc = gp_ctx_create(&rk.c, devices[r], nullptr);
+        if (rc != 0) break;
+        if (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&rk.sc, hipStreamNonBlocking) != hipSuccess) {
+            rc = set_err_text(-1997, "could not create the comm stream of a rank");
+            break;
+        }
+        for (int j = 0; j < ndev; ++j) {  // peer access for the direct copies (errors: already enabled / same device — ignored)
+            if (devices[j] != devices[r]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[r], devices[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    // transport: RCCL between distinct devices unless told otherwise (GPMI_COMM=rccl|p2p); virtual ranks can only copy
+    const char* want = getenv("GPMI_COMM");
+    m->comm = 2;
+    if (rc == 0 && !dup && ndev > 1 && !(want && !strcmp(want, "p2p"))) {
+        std::lock_guard<std::mutex> l(g_rccl_mu);
+        if (g_rccl.load()) {
+            std::vector<ncclComm_t_> comms((size_t)ndev, nullptr);
+            std::vector<int> devs(devices, devices + ndev);
+            const int nrc = g_rccl.CommInitAll(comms.data(), ndev, devs.data());
+            if (nrc == 0) {
+                for (int r = 0; r < ndev; ++r) m->ranks[r].comm = comms[r];
+                m->comm = 1;
+                m->comm_note = "RCCL grouped send/recv over xGMI (ncclCommInitAll)";
+            } else {
+                m->comm_note = std::string("peer copies (ncclCommInitAll failed: ") + g_rccl.GetErrorString(nrc) + ")";
+            }
+        } else {
+            m->comm_note = "peer copies (" + g_rccl.err + ")";
+        }
+        if (want && !strcmp(want, "rccl") && m->comm != 1) rc = set_err_text(-1996, "GPMI_COMM=rccl but RCCL is unavailable: " + m->comm_note);
+    } else if (rc == 0) {
+        m->comm_note = dup ? "same-device copies (virtual ranks)" : (ndev > 1 ? "peer copies (GPMI_COMM=p2p)" : "single rank");
+    }
+    if (rc != 0) {
+        multi_destroy(m);
+        (void)gp_ctx_destroy(main_ctx);
+        return rc;
+    }
+    (void)hipSetDevice(devices[0]);
+    main_ctx->multi = m;
+    *out = main_ctx;
+    return 0;
+}
+
+extern "C" int32_t gp_ctx_multi_info(gp_ctx* c, int32_t* P, int32_t* Q, int32_t* nb, int32_t* comm, int32_t* depth) {
+    Guard gd(c);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_ctx");
+    gp_multi* m = c->multi;
+    if (P) *P = m ? m->P : 1;
+    if (Q) *Q = m ? m->Q : 1;
+    if (nb) *nb = m ? (int32_t)m->nb : 0;
+    if (comm) *comm = m ? m->comm : 0;
+    if (depth) *depth = m ? m->depth : 0;
+    return 0;
+}
+
+// fit on a multi-device ctx (called with the main ctx locked).  fp64 only.
+int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null, const void* Yv,
+                  long ldy, int ncols, double* logpdf_out, gp_post* post, void* alpha_out) {
+    gp_multi* M = c->multi;
+    if (k->dtype != 0) return set_arg_err(2, "multi-device contexts compute in fp64 (kernel dtype must be 0)");
+    if (ncols > RHS_ROWS) return set_arg_err(8, "at most 128 right-hand sides on a multi-device ctx");
+    const int P = M->P, Q = M->Q, R = M->R;
+    const long n = x->n, NB = M->nb;
+    const int d = x->d;
+    long lcm = (long)P * Q;
+    for (long a = P, b = Q; b;) {
+        const long t = a % b;
+        a = b;
+        b = t;
+        if (!b) lcm = (long)P * Q / a;
+    }
+    long nblk = (n + NB - 1) / NB;
+    nblk = (nblk + lcm - 1) / lcm * lcm;  // every rank owns the same number of block rows / columns
+    Dims dm{n, nblk * NB, nblk, NB, nblk / P, nblk / Q, NB + 32, d};
+    const long npad = dm.npad;
+    const double* Y = (const double*)Yv;
+    const double* mean = (const double*)mean_or_null;
+
+    // ---- host marshalling (once, shared read-only by the rank threads)
+    std::vector<double> xs_h((size_t)d * npad, 0.0), noise_h((size_t)npad, 0.0), rhs_h((size_t)ncols * npad, 0.0);
+    auto pt = [&](long i, int dd) -> double {
+        const double* pd = (const double*)x->data;
+        return x->layout == 0 ? pd[i] : (x->layout == 1 ? pd[(long)dd + i * x->d] : pd[i + (long)dd * x->n]);
+    };
+    for (int dd = 0; dd < d; ++dd) {
+        const double s = k->nscale == 1 ? k->scale[0] : (k->nscale > 1 ? k->scale[dd] : 1.0);
+        for (long i = 0; i < n; ++i) xs_h[(size_t)dd * npad + i] = s * pt(i, dd);
+    }
+    for (long i = 0; i < n; ++i) noise_h[i] = noise->kind == 0 ? noise->s : ((const double*)noise->diag)[i];
+    for (int s = 0; s < ncols; ++s)
+        for (long i = 0; i < n; ++i) rhs_h[(size_t)s * npad + i] = Y[(size_t)s * ldy + i] - (mean ? mean[i] : 0.0);
+    double* alpha_pin = nullptr;
+    MCHK(hipSetDevice(c->device));
+    MCHK(hipHostMalloc((void**)&alpha_pin, sizeof(double) * (size_t)npad, hipHostMallocPortable));
+    memset(alpha_pin, 0, sizeof(double) * (size_t)npad);
+
+    // ---- events sized for this nblk
+    for (auto& rk : M->ranks) {
+        (void)hipSetDevice(rk.device);
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr}) {
+            if ((long)v->size() < nblk) {
+                std::vector<XEvent> nv((size_t)nblk);
+                for (size_t i = 0; i < v->size(); ++i) {
+                    nv[i].ev = (*v)[i].ev;
+                    nv[i].gen.store((*v)[i].gen.load());
+                }
+                for (size_t i = v->size(); i < (size_t)nblk; ++i)
+                    if (hipEventCreateWithFlags(&nv[i].ev, hipEventDisableTiming) != hipSuccess) {
+                        (void)hipHostFree(alpha_pin);
+                        return set_err_text(-1995, "hipEventCreate failed");
+                    }
+                v->swap(nv);
+            }
+        }
+    }
+    (void)hipSetDevice(c->device);
+    const long seq = ++M->seq;
+    M->abort.store(0);
+    const bool keep = post != nullptr;
+
+    std::vector<std::vector<double>> scal((size_t)R, std::vector<double>(8 + RHS_ROWS, 0.0));
+    std::vector<int> infos((size_t)R, 0);
+    std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
+    for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
+    auto t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < R; ++r)
+            th.emplace_back([&, r]() {
+                MRank& rk = M->ranks[r];
+                std::lock_guard<std::mutex> l(rk.c->mu);
+                rk.rc = fit_rank(M, &rk, dm, k->kind, k->variance, xs_h.data(), noise_h.data(), rhs_h.data(), ncols, keep, keep, alpha_pin,
+                                 scal[r].data(), &infos[r], *bufs[r], seq);
+                if (rk.rc != 0) {
+                    rk.err = gp_last_error();
+                    M->abort.store(1);
+                    (void)hipStreamSynchronize(rk.c->sm);
+                    (void)hipStreamSynchronize(rk.c->sp);
+                    (void)hipStreamSynchronize(rk.sc);
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipSetDevice(c->device);
+    int32_t rc = 0;
+    for (int r = 0; r < R; ++r)
+        if (M->ranks[r].rc != 0 && M->ranks[r].rc != -1999) {
+            rc = set_err_text(M->ranks[r].rc, "rank " + std::to_string(r) + ": " + M->ranks[r].err);
+            break;
+        }
+    if (rc == 0)
+        for (int r = 0; r < R; ++r)
+            if (M->ranks[r].rc != 0) rc = set_err_text(M->ranks[r].rc, M->ranks[r].err);
+    int info = 0;  // the FIRST failing leading minor (LAPACK dpotrf info; PosDefException(info) in the reference)
+    for (int r = 0; r < R; ++r)
+        if (infos[r] > 0 && (info == 0 || infos[r] < info)) info = infos[r];
+    if (rc == 0 && info != 0) rc = info;
+    if (rc != 0) {
+        for (int r = 0; r < R; ++r) {
+            std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
+            (void)hipSetDevice(M->ranks[r].device);
+            bufs[r].reset();
+        }
+        (void)hipSetDevice(c->device);
+        (void)hipHostFree(alpha_pin);
+        return rc;
+    }
+    double logdet_half = 0;
+    std::vector<double> ss((size_t)ncols, 0.0);
+    for (int r = 0; r < R; ++r) {
+        logdet_half += scal[r][0];
+        for (int s = 0; s < ncols; ++s) ss[s] += scal[r][8 + s];
+    }
+    const double LOG2PI_ = 1.8378770664093454835606594728112;
+    for (int s = 0; s < ncols; ++s) logpdf_out[s] = -0.5 * ((double)n * LOG2PI_ + 2.0 * logdet_half + ss[s]);
+    // timings of rank 0 for gp_get_timings (bench roofline)
+    c->tm = gp_timings{};
+    c->tm.total_ms = wall_ms;
+    c->tm.potrf_ms = wall_ms;
+    c->tm.gemm_ms = M->ranks[0].gemm_ms;
+    c->tm.gemm_flops = M->ranks[0].gemm_flops;
+    c->tm.gemm_launches = M->ranks[0].gemm_launches;
+
+    if (post) {
+        if (alpha_out) memcpy(alpha_out, alpha_pin, sizeof(double) * (size_t)n);
+        // the posterior handle: inputs + α on the ctx's first device in the single-device layout; the factor stays as pieces
+        const long np = (n + 127) / 128 * 128;
+        DevBufs mb(c);
+        void *xs_v = 0, *al_v = 0;
+        int32_t rc2 = mb.get(sizeof(double) * (size_t)d * np, &xs_v);
+        if (rc2 == 0) rc2 = mb.get(sizeof(double) * (size_t)np, &al_v);
+        if (rc2 == 0) {
+            std::vector<double> xs1((size_t)d * np, 0.0), al1((size_t)np, 0.0);
+            for (int dd = 0; dd < d; ++dd) memcpy(&xs1[(size_t)dd * np], &xs_h[(size_t)dd * npad], sizeof(double) * (size_t)n);
+            memcpy(al1.data(), alpha_pin, sizeof(double) * (size_t)n);
+            if (hipMemcpy(xs_v, xs1.data(), sizeof(double) * xs1.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(al_v, al1.data(), sizeof(double) * al1.size(), hipMemcpyHostToDevice) != hipSuccess)
+                rc2 = set_err_text(-1994, "upload of the posterior vectors failed");
+        }
+        if (rc2 != 0) {
+            for (int r = 0; r < R; ++r) {
+                std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
+                (void)hipSetDevice(M->ranks[r].device);
+                bufs[r].reset();
+            }
+            (void)hipSetDevice(c->device);
+            (void)hipHostFree(alpha_pin);
+            return rc2;
+        }
+        gp_multi_post* mp = new gp_multi_post();
+        mp->m = M; mp->n = n; mp->npad = npad; mp->nblk = nblk; mp->nb = NB;
+        for (int r = 0; r < R; ++r) {
+            MRank& rk = M->ranks[r];
+            mp->pieces.push_back({rk.c, rk.A, rk.ld, rk.m_loc, rk.n_loc});
+            rk.c->refs++;  // the piece keeps its rank context alive
+        }
+        post->ctx = c;
+        post->dtype = 0;
+        post->n = n; post->np = np; post->ld = np + c->ldpad; post->mtot = np + 128; post->d = d;
+        post->kind = k->kind; post->variance = k->variance; post->nscale = k->nscale;
+        post->scale.clear();
+        if (k->scale && k->nscale > 0) post->scale.assign(k->scale, k->scale + k->nscale);
+        post->A = nullptr; post->A_bytes = 0;
+        post->xs = mb.keep(xs_v); post->xs_bytes = sizeof(double) * (size_t)d * np;
+        post->alpha = mb.keep(al_v); post->alpha_bytes = sizeof(double) * (size_t)np;
+        post->logdet_half = logdet_half;
+        post->pieces = mp;
+    }
+    for (int r = 0; r < R; ++r) {  // everything but the kept factor pieces goes back to the rank caches
+        std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
+        (void)hipSetDevice(M->ranks[r].device);
+        bufs[r].reset();
+    }
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(alpha_pin);
+    return 0;
+}
+
+void multi_post_release(gp_post* post) {
+    gp_multi_post* mp = post->pieces;
+    if (!mp) return;
+    for (auto& pc : mp->pieces) {
+        {
+            std::lock_guard<std::mutex> l(pc.c->mu);
+            (void)hipSetDevice(pc.c->device);
+            ctx_release(pc.c, pc.A, 0);
+        }
+        ctx_unref(pc.c);
+    }
+    (void)hipSetDevice(post->ctx->device);
+    delete mp;
+    post->pieces = nullptr;
+}
+
+// Block-cyclic pieces -> the single-device row-major lower factor on the ctx's first device (288 GB of HBM hold the 34 GB of
+// N = 65 536 many times over), so that everything downstream of a fit — predictive variances / covariances, sequential
+// updates, sampling, held-out logpdf — runs on the resident factor exactly as after a single-device fit.  Called with the
+// main ctx locked.
+int32_t multi_gather(gp_post* post) {
+    gp_multi_post* mp = post->pieces;
+    if (!mp) return 0;
+    gp_ctx* c = post->ctx;
+    gp_multi* M = mp->m;
+    const long NB = mp->nb, np = post->np, ld = post->ld, mtot = post->mtot;
+    const int P = M->P, Q = M->Q;
+    MCHK(hipSetDevice(c->device));
+    void* A_v = nullptr;
+    const size_t A_b = sizeof(double) * (size_t)(mtot + 128) * ld;
+    RC(ctx_alloc(c, A_b, &A_v));
+    double* A = (double*)A_v;
+    int32_t rc = [&]() -> int32_t {
+        MCHK(hipMemsetAsync(A + np * ld, 0, sizeof(double) * (size_t)(mtot - np + 128) * ld, c->sm));
+        for (size_t r = 0; r < mp->pieces.size(); ++r) {
+            auto& pc = mp->pieces[r];
+            const int p = (int)r / Q, q = (int)r % Q;
+            for (long li = 0; li * NB < pc.m_loc && li < mp->nblk / P; ++li) {
+                const long gi = li * P + p;
+                if (gi * NB >= np) continue;
+                const long rows = std::min(NB, np - gi * NB);
+                for (long lj = 0; lj < mp->nblk / Q; ++lj) {
+                    const long gj = lj * Q + q;
+                    if (gj > gi) break;
+                    const long cols = std::min(NB, np - gj * NB);
+                    if (cols <= 0) continue;
+                    MCHK(hipMemcpy2DAsync(A + gi * NB * ld + gj * NB, sizeof(double) * ld, (const double*)pc.A + li * NB * pc.ld + lj * NB,
+                                          sizeof(double) * pc.ld, sizeof(double) * cols, rows, hipMemcpyDefault, c->sm));
+                }
+            }
+        }
+        MCHK(hipStreamSynchronize(c->sm));
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        ctx_release(c, A_v, 0);
+        return rc;
+    }
+    post->A = A_v;
+    post->A_bytes = A_b;
+    multi_post_release(post);
+    return 0;
+}

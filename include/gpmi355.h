@@ -90,6 +90,18 @@ typedef struct {
 /* stream_or_null: a hipStream_t owned by the caller to issue the main-stream work on (e.g. the
  * current torch stream in the multi-process driver); NULL = the ctx creates its own. */
 int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null);
+/* Multi-device context: ONE caller thread (the Julia process of docs/src/api.md:18-30) drives ndev devices of a node.
+ * devices[r] is the HIP device of rank r = p·Q + q of the P×Q process grid over which gp_posterior_fit / gp_logpdf partition
+ * K + Σy 2D block-cyclically in nb×nb blocks (one internal host thread per rank; panel traffic by RCCL grouped send/recv over
+ * xGMI, or by peer copies — environment GPMI_COMM=rccl|p2p overrides the automatic choice).  P = Q = 0: grid chosen for the
+ * fabric (P = ndev, Q = 1 on the full-mesh xGMI node, see multi.hip); nb = 0: 1024.  The same device may be listed several
+ * times ("virtual ranks": the full schedule on one GPU with same-device copies — how CI exercises it).  Every other entry
+ * point works unchanged on such a ctx: fp64 fits are distributed, everything else (and everything downstream of a fit:
+ * predictions, updates, sampling — the factor is gathered onto devices[0] on first need) runs on devices[0].
+ * Extra parameters: "lookahead_depth" (1..3, default 2), "dist_nb". */
+int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int32_t ndev, int32_t P, int32_t Q, int32_t nb);
+/* Grid / transport of a ctx (1×1, nb 0, comm 0 for a single-device ctx).  comm: 1 RCCL, 2 peer / same-device copies. */
+int32_t gp_ctx_multi_info(gp_ctx* ctx, int32_t* P, int32_t* Q, int32_t* nb, int32_t* comm, int32_t* depth);
 int32_t gp_ctx_destroy(gp_ctx* ctx);
 /* Tuning / diagnostic parameters (all optional; the GPMI_PARAMS="name=value,..." environment variable applies the same
  * names at gp_ctx_create):
