@@ -574,6 +574,13 @@ int32_t gpmi::eng_rowsumsq(gp_ctx* c, hipStream_t s, const double* x, long ldx, 
     HIPCHK(hipGetLastError());
     return 0;
 }
+int32_t gpmi::eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols) {
+    (void)c;
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)std::min<long>(rows, 1024)), dim3(256), 0, s, dst, dld, src, sld, rows, cols);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int32_t gpmi::eng_add_vec(gp_ctx* c, hipStream_t s, double* dst, const double* src, long n) {
     (void)c;
     if (n <= 0) return 0;
@@ -1334,7 +1341,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
-    else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
+    else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }

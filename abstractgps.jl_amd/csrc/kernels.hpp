@@ -1788,6 +1788,17 @@ __global__ __launch_bounds__(256) void ystats_kernel(const T* __restrict__ Y, lo
         cacc[row] -= red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
+// dst[r][c] = src[r][c] for r < rows, c < cols (cols multiple of 2; 16-B accesses; grid-stride over rows): the 2-D block copy of
+// the multi-device driver when source and destination are directly addressable (same device, or a peer over xGMI)
+__global__ __launch_bounds__(256) void copy2d_kernel(double* __restrict__ dst, long dld, const double* __restrict__ src, long sld,
+                                                     long rows, long cols) {
+    const long c2 = cols >> 1;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const d2_t* s2 = reinterpret_cast<const d2_t*>(src + r * sld);
+        d2_t* d2 = reinterpret_cast<d2_t*>(dst + r * dld);
+        for (long c = threadIdx.x; c < c2; c += 256) d2[c] = s2[c];
+    }
+}
 // dst[i] += src[i]
 __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ dst, const double* __restrict__ src, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -138,11 +138,13 @@ struct gp_multi {
     std::vector<MRank> ranks;
     std::atomic<int> abort{0};
     long seq = 0;    // fit sequence number (XEvent generations)
+    int copy_kernel = 0;  // block copies by copy2d_kernel instead of hipMemcpy2DAsync ("copy_kernel" parameter)
+    int debug_sync = 0;   // diagnostic: host-synchronise the rank's streams after every exchange ("multi_debug_sync")
     std::string comm_note;
 };
 
 struct gp_multi_post {
-    gp_multi* m = nullptr;
+    int P = 1, Q = 1;  // (copied: the posterior may outlive the ctx's gp_multi)
     long n = 0, npad = 0, nblk = 0, nb = 0;
     struct Piece {
         gp_ctx* c;
@@ -196,12 +198,14 @@ struct RankRun {
             if (M->abort.load(std::memory_order_relaxed)) return set_err_text(-1999, "multi-device fit aborted: another rank failed");
             if (++spins > 64) std::this_thread::yield();
         }
-        MCHK(hipStreamWaitEvent(s, x.ev, 0));
+        if (M->debug_sync & 4) MCHK(hipEventSynchronize(x.ev));
+        else MCHK(hipStreamWaitEvent(s, x.ev, 0));
         return 0;
     }
     // 2-D block copy into one of my buffers from a buffer of rank src (possibly on another device), on my stream s
     int32_t pull(hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols) {
         if (rows <= 0 || cols <= 0) return 0;
+        if (M->copy_kernel && !(cols & 1)) return eng_copy2d(me->c, s, dst, dld, src, sld, rows, cols);
         MCHK(hipMemcpy2DAsync(dst, sizeof(double) * dld, src, sizeof(double) * sld, sizeof(double) * cols, rows, hipMemcpyDefault, s));
         return 0;
     }
@@ -395,6 +399,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
             RC(rr.pull(sp, me->stage[k % NBUF] + r0b * LDP, LDP, A + r0b * ld + c0, ld, m_loc - r0b, NB));
         }
         RC(rr.publish(me->ready[k], sp));
+        if (M->debug_sync & 8) MCHK(hipStreamSynchronize(sp));
         return 0;
     };
 
@@ -408,6 +413,9 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         }
         double* Ab = (double*)Ab_v[s];
         double* Bb = (double*)Bb_v[s];
+        // my own piece of panel k (when I sit in the owner column) is read straight from my matrix by my updates: arrived[k]
+        // must therefore also cover MY panel-stream work — with gcd(P, Q) > 1 a rank may fetch nothing from itself below
+        if (q == qk) MCHK(hipStreamWaitEvent(sc, me->ready[k].ev, 0));
         if (!rccl) {
             // A part: my process row's piece, rows in local row order (nothing to fetch when I own the column)
             if (q != qk) {
@@ -433,7 +441,6 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         } else {
             // the same transfers as matched ncclSend / ncclRecv pairs of ONE group per rank (all peers progress concurrently);
             // both sides enumerate (source process row, destination rank, block) in the same order
-            if (q == qk) MCHK(hipStreamWaitEvent(sc, me->ready[k].ev, 0));  // my own piece (recorded by this thread on sp)
             NCHK(g_rccl.GroupStart());
             for (int pp = 0; pp < P; ++pp) {
                 MRank& src = rank_of(pp, qk);
@@ -465,6 +472,11 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         }
         RC(rr.own_event(&arrived[k]));
         MCHK(hipEventRecord(arrived[k], sc));
+        if (M->debug_sync & 1) MCHK(hipStreamSynchronize(sc));
+        if (M->debug_sync & 2) {
+            MCHK(hipStreamSynchronize(sp));
+            MCHK(hipStreamSynchronize(sm));
+        }
         return 0;
     };
 
@@ -498,6 +510,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         }
         RC(rr.own_event(&bulk_done[k]));
         MCHK(hipEventRecord(bulk_done[k], sm));
+        if (M->debug_sync & 16) MCHK(hipStreamSynchronize(sm));
     }
     // join the panel stream into the main stream
     {
@@ -616,6 +629,14 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
     if (!m) return 1;
     if (!strcmp(name, "lookahead_depth")) {
         m->depth = (int)std::min<int64_t>(3, std::max<int64_t>(1, v));
+        return 0;
+    }
+    if (!strcmp(name, "copy_kernel")) {
+        m->copy_kernel = v != 0;
+        return 0;
+    }
+    if (!strcmp(name, "multi_debug_sync")) {
+        m->debug_sync = (int)v;
         return 0;
     }
     if (!strcmp(name, "dist_nb")) {
@@ -874,7 +895,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
             return rc2;
         }
         gp_multi_post* mp = new gp_multi_post();
-        mp->m = M; mp->n = n; mp->npad = npad; mp->nblk = nblk; mp->nb = NB;
+        mp->P = P; mp->Q = Q; mp->n = n; mp->npad = npad; mp->nblk = nblk; mp->nb = NB;
         for (int r = 0; r < R; ++r) {
             MRank& rk = M->ranks[r];
             mp->pieces.push_back({rk.c, rk.A, rk.ld, rk.m_loc, rk.n_loc});
@@ -926,9 +947,8 @@ int32_t multi_gather(gp_post* post) {
     gp_multi_post* mp = post->pieces;
     if (!mp) return 0;
     gp_ctx* c = post->ctx;
-    gp_multi* M = mp->m;
     const long NB = mp->nb, np = post->np, ld = post->ld, mtot = post->mtot;
-    const int P = M->P, Q = M->Q;
+    const int P = mp->P, Q = mp->Q;
     MCHK(hipSetDevice(c->device));
     void* A_v = nullptr;
     const size_t A_b = sizeof(double) * (size_t)(mtot + 128) * ld;

@@ -1,0 +1,141 @@
+"""GPU: the IN-LIBRARY multi-device driver (gp_ctx_create_multi, csrc/multi.hip) with virtual ranks — P×Q ranks sharing the one
+GPU of the test box, same schedule / kernels / block-cyclic predicate as on a node, same-device copies instead of xGMI
+transfers (SURVEY.md §8(e) "virtual-rank mode").  Every grid is compared with the CPU oracle at the single-GPU tolerances
+(logpdf rel <= 1e-10, α rel <= 1e-8, predictive mean abs <= 1e-8, var abs <= 1e-9), and everything downstream of a fit runs
+on the gathered factor."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _relnorm(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+GRIDS = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4), (4, 2), (2, 4), (8, 1), (3, 1), (2, 3)]
+
+
+@pytest.mark.parametrize("P,Q", GRIDS, ids=lambda v: str(v))
+def test_virtual_ranks_vs_oracle(agp, P, Q):
+    n, d, nb = 1500, 3, 128
+    x, y = o.synth_inputs(n, d, 40 + P * 10 + Q)
+    rng = np.random.default_rng(P * 100 + Q)
+    s2 = 0.02 + 0.05 * rng.random(n)
+    of = o.GP(o.Kernel(o.MATERN52, 1.4, 0.8), 0.25)
+    ofx = o.FiniteGP(of, x, s2)
+    lp_ref, opost = o.logpdf_and_posterior(ofx, y)
+    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    try:
+        info = ctx.multi_info()
+        assert (info["P"], info["Q"], info["nb"]) == (P, Q, nb) and info["comm"] == "copies"
+        f = agp.GP(0.25, 1.4 * agp.Matern52Kernel() @ agp.ScaleTransform(0.8), ctx=ctx)
+        fx = f(agp.RowVecs(x), s2)
+        assert agp.logpdf(fx, y) == pytest.approx(lp_ref, rel=1e-10)
+        Y = np.stack([y, np.cos(y), 0.3 * y], axis=1)                       # matrix Y: three RHS rows ride along
+        np.testing.assert_allclose(agp.logpdf(fx, Y), o.logpdf(ofx, Y), rtol=1e-10)
+        post = agp.posterior(fx, y)
+        assert float(post.logpdf_value) == pytest.approx(lp_ref, rel=1e-10)
+        assert _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+        xs = x[:70] + 0.04
+        np.testing.assert_allclose(post.mean(agp.RowVecs(xs)), opost.mean(xs), atol=1e-8)      # α only: no gather needed
+        m, v = post.mean_and_var(agp.RowVecs(xs))                                              # gathers the factor onto device 0
+        mo, vo = opost.mean_and_var(xs)
+        np.testing.assert_allclose(m, mo, atol=1e-8)
+        np.testing.assert_allclose(v, vo, atol=1e-9)
+        assert np.max(np.abs(post.data.C.U - opost.U)) <= 1e-10                                # C.U of the reference
+        np.testing.assert_allclose(post.cov(agp.RowVecs(xs)), opost.cov(xs), atol=1e-9)
+        ys = rng.standard_normal(70)
+        assert agp.logpdf(post(agp.RowVecs(xs), 0.1), ys) == pytest.approx(float(o.logpdf(o.FiniteGP(opost, xs, 0.1), ys)), rel=1e-9)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+@pytest.mark.parametrize("P,Q,n,nb", [(2, 2, 2300, 256), (4, 1, 1111, 128), (1, 3, 1000, 128)])
+def test_lookahead_depths_and_ragged_sizes(agp, depth, P, Q, n, nb):
+    x, y = o.synth_inputs(n, 2, 7 + depth)
+    of = o.GP(o.Kernel(o.SE, 1.0, 1.3))
+    lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, x, 0.05), y)
+    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    try:
+        ctx.set_param("lookahead_depth", depth)
+        assert ctx.multi_info()["lookahead_depth"] == depth
+        f = agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(1.3), ctx=ctx)
+        for _ in range(2):                                     # twice: the cross-rank event generations advance
+            post = agp.posterior(f(agp.RowVecs(x), 0.05), y)
+            assert float(post.logpdf_value) == pytest.approx(lp_ref, rel=1e-10)
+            assert _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+    finally:
+        ctx.close()
+
+
+def test_multi_sequential_update_and_rand_after_gather(agp):
+    """posterior(f_post(x2, σ²), y2) and rand on a posterior that was fitted block-cyclically (the factor is gathered first)."""
+    n1, n2 = 900, 300
+    x, y = o.synth_inputs(n1 + n2, 3, 5)
+    of = o.GP(o.Kernel(o.MATERN32))
+    ob = o.posterior(o.FiniteGP(of, x, 0.05), y)
+    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128)
+    try:
+        f = agp.GP(agp.Matern32Kernel(), ctx=ctx)
+        p1 = agp.posterior(f(agp.RowVecs(x[:n1]), 0.05), y[:n1])
+        p2 = agp.posterior(p1(agp.RowVecs(x[n1:]), 0.05), y[n1:])
+        assert _relnorm(p2.data.alpha, ob.alpha) <= 1e-8
+        np.testing.assert_allclose(p2.data.C.U, ob.U, atol=1e-9)
+        xi = np.random.default_rng(0).standard_normal((n1, 2))
+        fx = f(agp.RowVecs(x[:n1]), 0.05)
+        np.testing.assert_allclose(agp.rand(fx, 2, xi=xi), o.rand_from(o.FiniteGP(of, x[:n1], 0.05), xi), atol=1e-10)
+    finally:
+        ctx.close()
+
+
+def test_multi_not_positive_definite_reports_first_minor(agp):
+    """Σy with one large negative entry makes the leading minor of order 401 (and later ones) indefinite while everything
+    before it is well conditioned: PosDefException(info) must carry the FIRST failing minor, exactly as LAPACK reports it
+    through the reference's cholesky (src/finite_gp_projection.jl:308) — also when several ranks flag later columns."""
+    n = 700
+    x, y = o.synth_inputs(n, 2, 3)
+    s2 = np.full(n, 0.1)
+    s2[400] = -5.0
+    s2[650] = -7.0
+    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128)
+    one = agp.Context(0)
+    try:
+        for c in (ctx, one):
+            f = agp.GP(agp.SqExponentialKernel(), ctx=c)
+            with pytest.raises(agp.PosDefException) as ei:
+                agp.posterior(f(agp.RowVecs(x), s2), y)
+            assert ei.value.info == 401
+    finally:
+        ctx.close()
+        one.close()
+
+
+def test_multi_fp32_is_rejected_and_other_entry_points_run_on_device0(agp):
+    x, y = o.synth_inputs(600, 3, 9)
+    ctx = agp.Context(devices=[0, 0], nb=128)
+    try:
+        assert ctx.multi_info()["P"] == 2 and ctx.multi_info()["Q"] == 1       # default grid: P = ndev, Q = 1
+        f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
+        with pytest.raises(ValueError):
+            agp.logpdf(f(agp.RowVecs(x.astype(np.float32)), 0.1), y.astype(np.float32))
+        # VFE / kernelmatrix / gradients on a multi ctx run on its first device
+        z = x[:50]
+        e = agp.elbo(agp.VFE(f(agp.RowVecs(z), 1e-6)), f(agp.RowVecs(x), 0.1), y)
+        of = o.GP(o.Kernel(o.SE))
+        assert e == pytest.approx(o.elbo(of, z, 1e-6, o.FiniteGP(of, x, 0.1), y), rel=1e-8)
+        lp, g = agp.logpdf_and_grad(f(agp.RowVecs(x), 0.1), y)
+        assert lp == pytest.approx(float(o.logpdf(o.FiniteGP(of, x, 0.1), y)), rel=1e-10)
+    finally:
+        ctx.close()
+
+
+def test_more_devices_than_visible_is_an_error(agp):
+    import torch
+
+    ndev = torch.cuda.device_count()
+    with pytest.raises(ValueError):
+        agp.Context(devices=list(range(ndev + 1)))
