@@ -139,3 +139,20 @@ def test_more_devices_than_visible_is_an_error(agp):
     ndev = torch.cuda.device_count()
     with pytest.raises(ValueError):
         agp.Context(devices=list(range(ndev + 1)))
+
+
+def test_schedule_under_truly_concurrent_streams():
+    """The schedule's event dependencies under real concurrency: with the default 4 hardware queues HIP mostly serialises the
+    3·P·Q streams of the virtual ranks, which hid a missing dependency in development (a rank's own panel was not covered by
+    its `arrived` event when gcd(P, Q) > 1).  GPU_MAX_HW_QUEUES=32 has to be set before HIP initialises, hence a subprocess:
+    tools/multi_diag.py repeats logpdf / matrix-logpdf / posterior on nine grids and three look-ahead depths vs the oracle."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", DIAG_ITERS="9")
+    r = subprocess.run([sys.executable, str(root / "tools" / "multi_diag.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "FAILURES 0" in r.stdout

@@ -16,11 +16,12 @@ lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, x, 0.05), y)
 Y = np.stack([y, np.cos(y), 0.3 * y], axis=1)
 lpY = o.logpdf(o.FiniteGP(of, x, 0.05), Y)
 import os
-grids = [(2, 2), (4, 2), (2, 4), (2, 3)]
+grids = [tuple(int(v) for v in g.split('x')) for g in os.environ.get('DIAG_GRIDS', '2x2,4x2,2x4,2x3,4x1,1x4,8x1,3x1,4x4').split(',')]
 extra = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("DIAG_PARAMS", "").split(",") if kv)}
 NIT = int(os.environ.get("DIAG_ITERS", "6"))
 print("params", extra, flush=True)
-for depth in (2, 1):
+bad = 0
+for depth in (2, 1, 3):
     for P, Q in grids:
         ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
         ctx.set_param("lookahead_depth", depth)
@@ -42,4 +43,7 @@ for depth in (2, 1):
             except Exception as e:  # noqa: BLE001
                 res.append(type(e).__name__ + ":" + str(getattr(e, "info", "")))
         print(f"depth={depth} grid={P}x{Q}: {res}", flush=True)
+        bad += sum(r != "." for r in res)
         ctx.close()
+print('FAILURES', bad)
+sys.exit(1 if bad else 0)
