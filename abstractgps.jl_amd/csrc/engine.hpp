@@ -86,6 +86,7 @@ struct gp_ctx {
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
     bool gemm_pad_set = false;
+    bool gemm_pad_user = false;  // "gemm_pad_lds" was set explicitly (otherwise: 0 for fp64, 20480 for fp32)
     int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;

@@ -214,14 +214,18 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g, ntiles, (int)G2);
         } else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
-            if (c->gemm_pad_lds > 0 && !c->gemm_pad_set) {
+            // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
+            // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
+            // request of 20 KiB on top of the 64 KiB static image pins that.  "gemm_pad_lds" overrides both.
+            const long pad = c->gemm_pad_user ? c->gemm_pad_lds : (sizeof(T) == 4 ? 20480 : 0);
+            if (pad > 0 && !c->gemm_pad_set) {
                 HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
                 HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
                 c->gemm_pad_set = true;
             }
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), (size_t)c->gemm_pad_lds, s, C, ldc, A, lda, B, ldb,
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), (size_t)pad, s, C, ldc, A, lda, B, ldb,
                                (int)M, (int)N, (int)K, g);
         }
         else
@@ -1333,7 +1337,10 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
     else if (!strcmp(name, "sk_u1")) c->sk_u1 = v != 0;
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
-    else if (!strcmp(name, "gemm_pad_lds")) c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
+    else if (!strcmp(name, "gemm_pad_lds")) {
+        c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
+        c->gemm_pad_user = true;
+    }
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;

@@ -317,12 +317,20 @@ class BlockCyclicEngine:
         if p == p_rhs:
             be.rowsumsq(_sub(A, nlb_r * NB, 0), ldl, 1, n_loc, scal[1:2])
         red = torch.stack([scal[0], scal[1]])
+        # LAPACK info = the FIRST failing leading minor (PosDefException(info) in the reference): ranks that saw no failure
+        # contribute a sentinel, then MIN over ranks (after the first bad pivot NaNs make later diagonal owners flag too)
         info_f = info.to(torch.float64)
+        info_f = torch.where(info_f > 0, info_f, torch.full_like(info_f, 2.0**52))
         if self.coll:
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
-            dist.all_reduce(info_f, op=dist.ReduceOp.MAX)
+            dist.all_reduce(info_f, op=dist.ReduceOp.MIN)
         logdet_half, sq = float(red[0].item()), float(red[1].item())
-        info_v = int(info_f.item())
+        info_v = int(info_f.item()) if float(info_f.item()) < 2.0**52 else 0
+        if info_v != 0:
+            be.sync()
+            from ._lib import PosDefException
+
+            raise PosDefException(info_v)
         logpdf = -0.5 * (n * LOG2PI + 2.0 * logdet_half + sq)
 
         # ---- backward substitution  α = L⁻ᵀ z  (block sweep, last block first)

@@ -1,17 +1,21 @@
 # HipGPs.jl — Julia host shim: keeps the AbstractGP / FiniteGP / PosteriorGP surface of AbstractGPs.jl
-# and routes the logpdf / posterior hot path through `ccall` into libgpmi355.so (include/gpmi355.h).
+# and routes the logpdf / posterior hot path through `ccall` into libgpmi355.so (include/gpmi355.h, ABI v2).
 #
 # NOT EXECUTED in the build container (Julia is not installed there — SURVEY.md §0 F3); it is the
-# reference-side binding a maintainer adds (INTEGRATION.md).  abstractgps.jl_amd/api.py is its
-# line-for-line ctypes mirror and is what tests/ run.  Reference plug-in point: "subtype AbstractGP
-# and implement the FiniteGP primary API" (docs/src/api.md:18-30, 49-73).
+# reference-side binding a maintainer adds (INTEGRATION.md).  abstractgps.jl_amd/api.py is its ctypes
+# mirror (same entry points, argument meaning and errors) and is what tests/ run.  Reference plug-in point:
+# "subtype AbstractGP and implement the FiniteGP primary API" (docs/src/api.md:18-30, 49-73).
 #
 #   f   = HipGP(GP(SqExponentialKernel()))          # wraps a stock GP              src/base_gp.jl:57-64
+#   f8  = HipGP(GP(k), HipContext([0,1,2,3,4,5,6,7])) # same API, fits partitioned over 8 devices inside the library
 #   fx  = f(x, 0.01)                                # stock FiniteGP ctor           src/finite_gp_projection.jl:13-37
 #   logpdf(fx, y)                                   # -> gp_logpdf                  src/finite_gp_projection.jl:306-311
+#   Zygote.gradient(θ -> logpdf(build(θ)(x, σ²), y), θ)   # -> rrule below -> gp_logpdf_grad
 #   p   = posterior(fx, y)                          # -> gp_posterior_fit           src/exact_gpr_posterior.jl:29-35
 #   mean_and_var(p(xs)); cov(p(xs))                 # -> gp_posterior_predict       src/exact_gpr_posterior.jl:60-90
+#   logpdf(p(xs, σ²), ys); rand(rng, p(xs, σ²), 3)  # -> gp_posterior_logpdf / gp_posterior_rand   (device, no refit)
 #   posterior(VFE(f(z, 1e-6)), fx, y); elbo(...)    # -> gp_vfe_fit / gp_vfe_predict src/sparse_approximations.jl:58-75,248-254
+#   update_posterior(pa, fx2, y2); update_posterior(pa, f(z2, 1e-6))   # -> gp_vfe_update / gp_vfe_append   :87-176
 module HipGPs
 
 using AbstractGPs
@@ -20,8 +24,9 @@ using KernelFunctions
 using KernelFunctions: SqExponentialKernel, Matern12Kernel, ExponentialKernel, Matern32Kernel, Matern52Kernel,
     TransformedKernel, ScaledKernel, ScaleTransform, ARDTransform, ColVecs, RowVecs
 using LinearAlgebra, FillArrays, Statistics, StatsBase, Distributions, Random
+using ChainRulesCore
 
-export HipGP, HipPosteriorGP, HipApproxPosteriorGP, HipContext
+export HipGP, HipPosteriorGP, HipApproxPosteriorGP, HipContext, logpdf_and_grad
 
 const libgpmi355 = get(ENV, "GPMI355_LIB", joinpath(@__DIR__, "..", "csrc", "libgpmi355.so"))
 
@@ -60,6 +65,9 @@ function check(rc::Int32)
 end
 
 # ---- context ---------------------------------------------------------------------------------------
+# HipContext(device)                 one GPU
+# HipContext(devices; P, Q, nb)      several GPUs of the node driven from this one Julia process (gp_ctx_create_multi):
+#                                    fp64 logpdf / posterior fits are partitioned 2D block-cyclically inside the library
 mutable struct HipContext
     handle::Ptr{Cvoid}
     function HipContext(device::Integer=0)
@@ -69,9 +77,21 @@ mutable struct HipContext
         finalizer(c -> ccall((:gp_ctx_destroy, libgpmi355), Int32, (Ptr{Cvoid},), c.handle), c)
         return c
     end
+    function HipContext(devices::AbstractVector{<:Integer}; P::Integer=0, Q::Integer=0, nb::Integer=0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        devs = Vector{Int32}(devices)
+        check(ccall((:gp_ctx_create_multi, libgpmi355), Int32, (Ref{Ptr{Cvoid}}, Ptr{Int32}, Int32, Int32, Int32, Int32),
+            h, devs, length(devs), P, Q, nb))
+        c = new(h[])
+        finalizer(c -> ccall((:gp_ctx_destroy, libgpmi355), Int32, (Ptr{Cvoid},), c.handle), c)
+        return c
+    end
 end
 const _default_ctx = Ref{Union{Nothing,HipContext}}(nothing)
 default_context() = something(_default_ctx[], (_default_ctx[] = HipContext(0)))
+set_param!(c::HipContext, name::AbstractString, v::Integer) =
+    check(ccall((:gp_ctx_set_param, libgpmi355), Int32, (Ptr{Cvoid}, Cstring, Int64), c.handle, name, v))
+trim!(c::HipContext) = check(ccall((:gp_ctx_trim, libgpmi355), Int32, (Ptr{Cvoid},), c.handle))
 
 # ---- the GP wrapper -------------------------------------------------------------------------------
 struct HipGP{Tg<:GP} <: AbstractGP
@@ -81,7 +101,7 @@ end
 HipGP(gp::GP) = HipGP(gp, default_context())
 
 # internal AbstractGP API delegates to the wrapped GP (src/base_gp.jl:68-74) so that everything that is not
-# accelerated (rand, dense Σy, composite kernels) keeps working through the stock methods.
+# accelerated (dense Σy, composite kernels, exotic input containers) keeps working through the stock methods.
 Statistics.mean(f::HipGP, x::AbstractVector) = mean(f.gp, x)
 Statistics.cov(f::HipGP, x::AbstractVector) = cov(f.gp, x)
 Statistics.var(f::HipGP, x::AbstractVector) = var(f.gp, x)
@@ -113,19 +133,27 @@ end
 
 # ---- input / noise marshalling ---------------------------------------------------------------------
 # layout 0 Vector{T}; 1 ColVecs (D×N column-major); 2 RowVecs (N×D column-major)   src/finite_gp_projection.jl:32-37
-points(x::Vector{T}) where {T<:Union{Float32,Float64}} = (x, CPoints(pointer(x), length(x), 1, 0), T)
-function points(x::ColVecs{T,<:Matrix{T}}) where {T<:Union{Float32,Float64}}
-    return (x.X, CPoints(pointer(x.X), size(x.X, 2), size(x.X, 1), 1), T)
+# points(x, T) returns (buffer kept alive by the caller, CPoints) in eltype T, converting when needed; `nothing` for
+# containers the ABI has no layout for (vector of vectors, ...): the caller then takes the stock path.
+const HipFloat = Union{Float32,Float64}
+points(x::AbstractVector{<:Real}, ::Type{T}) where {T<:HipFloat} = (b = convert(Vector{T}, x); (b, CPoints(pointer(b), length(b), 1, 0)))
+function points(x::ColVecs, ::Type{T}) where {T<:HipFloat}
+    b = convert(Matrix{T}, x.X)
+    return (b, CPoints(pointer(b), size(b, 2), size(b, 1), 1))
 end
-function points(x::RowVecs{T,<:Matrix{T}}) where {T<:Union{Float32,Float64}}
-    return (x.X, CPoints(pointer(x.X), size(x.X, 1), size(x.X, 2), 2), T)
+function points(x::RowVecs, ::Type{T}) where {T<:HipFloat}
+    b = convert(Matrix{T}, x.X)
+    return (b, CPoints(pointer(b), size(b, 1), size(b, 2), 2))
 end
-points(::Any) = nothing
+points(::Any, ::Type) = nothing
+# element type of an input container (Float32 in -> Float32 out is a tested reference property,
+# test/finite_gp_projection.jl:180-191); anything that is not Float32 computes in Float64
+input_eltype(x::AbstractVector{<:Real}) = eltype(x)
+input_eltype(x::Union{ColVecs,RowVecs}) = eltype(x.X)
+input_eltype(::Any) = Float64
+hip_eltype(Ts...) = (T = promote_type(map(t -> t <: AbstractFloat ? t : Float64, Ts)...); T === Float32 ? Float32 : Float64)
 
-noise(Σ::Fill, ::Type{T}) where {T} = (nothing, CNoise(0, Float64(FillArrays.getindex_value(Σ)), C_NULL))
-function noise(Σ::Diagonal{<:Any,<:Fill}, ::Type{T}) where {T}
-    return (nothing, CNoise(0, Float64(FillArrays.getindex_value(Σ.diag)), C_NULL))
-end
+noise(Σ::Diagonal{<:Any,<:Fill}, ::Type{T}) where {T} = (nothing, CNoise(0, Float64(FillArrays.getindex_value(Σ.diag)), C_NULL))
 function noise(Σ::Diagonal, ::Type{T}) where {T}
     v = Vector{T}(Σ.diag)
     return (v, CNoise(1, 0.0, pointer(v)))
@@ -135,12 +163,15 @@ noise(::Any, ::Type) = nothing   # dense Σy: not accelerated
 prior_mean(f::GP{<:ZeroMean}, x, ::Type{T}) where {T} = nothing
 prior_mean(f::GP, x, ::Type{T}) where {T} = Vector{T}(mean_vector(f.mean, x))
 
-# everything one call needs, or `nothing` => use the stock AbstractGPs path
-function marshal(fx::FiniteGP{<:HipGP})
+# everything one call needs, or `nothing` => use the stock AbstractGPs path.  The compute type follows the reference's
+# promotion (src/finite_gp_projection.jl:309): T = promote_type(eltype(x), eltype(Y)), restricted to Float32 / Float64.
+function marshal(fx::FiniteGP{<:HipGP}, Ty::Type=input_eltype(fx.x))
     desc = descriptor(fx.f.gp.kernel)
-    px = points(fx.x)
-    (desc === nothing || px === nothing) && return nothing
-    xbuf, cx, T = px
+    desc === nothing && return nothing
+    T = hip_eltype(input_eltype(fx.x), Ty)
+    px = points(fx.x, T)
+    px === nothing && return nothing
+    xbuf, cx = px
     nz = noise(fx.Σy, T)
     nz === nothing && return nothing
     kind, variance, scales = desc
@@ -153,7 +184,7 @@ stock(fx::FiniteGP{<:HipGP}) = FiniteGP(fx.f.gp, fx.x, fx.Σy)
 
 # ---- logpdf (src/finite_gp_projection.jl:306-311) -------------------------------------------------
 function Distributions.logpdf(fx::FiniteGP{<:HipGP}, Y::AbstractVecOrMat{<:Real})
-    a = marshal(fx)
+    a = marshal(fx, eltype(Y))
     a === nothing && return logpdf(stock(fx), Y)
     size(Y, 1) == length(fx) || throw(DimensionMismatch("length(fx) = $(length(fx)) but Y has $(size(Y, 1)) rows"))
     T = a.T
@@ -168,10 +199,9 @@ function Distributions.logpdf(fx::FiniteGP{<:HipGP}, Y::AbstractVecOrMat{<:Real}
     return Y isa AbstractVector ? out[1] : out
 end
 
-# ---- value + gradient (what a ChainRulesCore.rrule for the accelerated logpdf returns; the reference relies on AD through
-# logpdf: test/finite_gp_projection.jl:152-178, examples/1-mauna-loa/script.jl:228-240) ------------------------------
+# ---- value + gradient: one factorisation, C⁻¹ by blocked TRSM + MFMA SYRK, one fused ½Σ(αᵢαⱼ − C⁻¹ᵢⱼ)∂Cᵢⱼ pass ----------
 function logpdf_and_grad(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
-    a = marshal(fx)
+    a = marshal(fx, eltype(y))
     a === nothing && throw(ArgumentError("kernel / noise form is not accelerated"))
     T = a.T
     yv = Vector{T}(y)
@@ -189,6 +219,56 @@ function logpdf_and_grad(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     return lp[], (variance=dvar[], scale=dscale[1:length(a.scales)], noise=a.cn.kind == 0 ? dnoise[1] : dnoise, y=dy, mean=-dy)
 end
 
+# ---- reverse-mode rule: Zygote / any ChainRules-based AD differentiates THROUGH the ccall -----------------------------------
+# The reference's users differentiate logpdf by AD (test/finite_gp_projection.jl:152-178, test/mean_function.jl:38-56,
+# examples/1-mauna-loa/script.jl:201-240); a ccall is opaque to AD, so the accelerated logpdf carries its own pullback built
+# from gp_logpdf_grad.  Tangents are structural, mirroring how `descriptor` walks the kernel:
+#   ScaledKernel.σ²  (1-vector)  <- ∂/∂variance · (total variance / σ²)      TransformedKernel.transform.s / .v  <- ∂/∂scale
+#   ConstMean.c <- Σ_i α_i        FiniteGP.Σy (Diagonal{Fill} value / Diagonal diag) <- ∂/∂σ² / ½(α_i² − C⁻¹_ii)        y <- −α
+# Inputs x (deep-kernel style models) and CustomMean parameters are not differentiated here (@not_implemented).
+kernel_tangent(k, dvar, variance, dscale) = NoTangent()
+function kernel_tangent(k::ScaledKernel, dvar, variance, dscale)
+    σ² = only(k.σ²)
+    return Tangent{typeof(k)}(; kernel=kernel_tangent(k.kernel, dvar, variance, dscale), σ²=[dvar * variance / σ²])
+end
+function kernel_tangent(k::TransformedKernel{<:Any,<:ScaleTransform}, dvar, variance, dscale)
+    return Tangent{typeof(k)}(; kernel=kernel_tangent(k.kernel, dvar, variance, dscale),
+        transform=Tangent{typeof(k.transform)}(; s=[dscale[1]]))
+end
+function kernel_tangent(k::TransformedKernel{<:Any,<:ARDTransform}, dvar, variance, dscale)
+    return Tangent{typeof(k)}(; kernel=kernel_tangent(k.kernel, dvar, variance, dscale),
+        transform=Tangent{typeof(k.transform)}(; v=collect(dscale)))
+end
+mean_tangent(::ZeroMean, dm) = NoTangent()
+mean_tangent(m::ConstMean, dm) = Tangent{typeof(m)}(; c=sum(dm))
+mean_tangent(m, dm) = ChainRulesCore.@not_implemented("HipGPs: gradients w.r.t. CustomMean parameters go through the stock path")
+noise_tangent(Σ::Diagonal{<:Any,<:Fill}, dn) = Tangent{typeof(Σ)}(; diag=Tangent{typeof(Σ.diag)}(; value=dn))
+noise_tangent(Σ::Diagonal, dn) = Tangent{typeof(Σ)}(; diag=dn)
+
+function ChainRulesCore.rrule(config::RuleConfig{>:HasReverseMode}, ::typeof(Distributions.logpdf), fx::FiniteGP{<:HipGP},
+    y::AbstractVector{<:Real})
+    desc = descriptor(fx.f.gp.kernel)
+    if desc === nothing || marshal(fx, eltype(y)) === nothing   # not accelerated: the stock path keeps its own AD
+        lp0, back = rrule_via_ad(config, (g_, x_, Σ_, y_) -> logpdf(FiniteGP(g_, x_, Σ_), y_), fx.f.gp, fx.x, fx.Σy, y)
+        return lp0, function (Δ)
+            _, dg, dx, dΣ, dy = back(Δ)
+            return NoTangent(), Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; gp=dg, ctx=NoTangent()), x=dx, Σy=dΣ), dy
+        end
+    end
+    lp, g = logpdf_and_grad(fx, y)
+    function logpdf_hip_pullback(Δ)
+        Δr = unthunk(Δ)
+        gp = fx.f.gp
+        dk = kernel_tangent(gp.kernel, Δr * g.variance, desc[2], Δr .* g.scale)
+        dgp = Tangent{typeof(gp)}(; mean=mean_tangent(gp.mean, Δr .* g.mean), kernel=dk)
+        df = Tangent{typeof(fx.f)}(; gp=dgp, ctx=NoTangent())
+        dfx = Tangent{typeof(fx)}(; f=df, x=ChainRulesCore.@not_implemented("HipGPs: no gradient w.r.t. the inputs x"),
+            Σy=noise_tangent(fx.Σy, Δr .* g.noise))
+        return NoTangent(), dfx, Δr .* g.y
+    end
+    return lp, logpdf_hip_pullback
+end
+
 # ---- posterior (src/exact_gpr_posterior.jl:29-35) -------------------------------------------------
 mutable struct DeviceCholesky          # stands where `C::Cholesky` sits in PosteriorGP.data (:34)
     handle::Ptr{Cvoid}
@@ -202,6 +282,11 @@ function Base.getproperty(C::DeviceCholesky, s::Symbol)
     check(ccall((:gp_posterior_get_factor, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), getfield(C, :handle), U))
     return UpperTriangular(U)
 end
+function device_cholesky(h::Ptr{Cvoid}, n::Int, ::Type{T}) where {T}
+    C = DeviceCholesky(h, n, T)
+    finalizer(c -> ccall((:gp_posterior_free, libgpmi355), Int32, (Ptr{Cvoid},), getfield(c, :handle)), C)
+    return C
+end
 
 struct HipPosteriorGP{Tprior<:HipGP,Tdata} <: AbstractGP
     prior::Tprior
@@ -210,7 +295,7 @@ struct HipPosteriorGP{Tprior<:HipGP,Tdata} <: AbstractGP
 end
 
 function AbstractGPs.posterior(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
-    a = marshal(fx)
+    a = marshal(fx, eltype(y))
     a === nothing && return posterior(stock(fx), y)
     length(y) == length(fx) || throw(DimensionMismatch("length(fx) != length(y)"))
     T = a.T
@@ -225,53 +310,97 @@ function AbstractGPs.posterior(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
             (Ptr{Cvoid}, Ref{CKernel}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Ref{T}),
             fx.f.ctx.handle, a.ck, a.cx, a.cn, mptr, yv, h, α, lp))
     end
-    C = DeviceCholesky(h[], length(yv), T)
-    finalizer(c -> ccall((:gp_posterior_free, libgpmi355), Int32, (Ptr{Cvoid},), getfield(c, :handle)), C)
-    return HipPosteriorGP(fx.f, (α=α, C=C, x=fx.x, δ=δ), Float64(lp[]))
+    return HipPosteriorGP(fx.f, (α=α, C=device_cholesky(h[], length(yv), T), x=fx.x, δ=δ), Float64(lp[]))
+end
+
+# inputs / noise of a FiniteGP over one of the posterior types, in the posterior's element type
+function joint_args(fx::FiniteGP, gp::GP, ::Type{T}) where {T}
+    px = points(fx.x, T)
+    px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior (use a Vector, ColVecs or RowVecs)"))
+    nz = noise(fx.Σy, T)
+    nz === nothing && throw(ArgumentError("dense Σy is not accelerated"))
+    return px[1], px[2], nz[1], nz[2], prior_mean(gp, fx.x, T)
 end
 
 # ---- sequential conditioning (src/exact_gpr_posterior.jl:46-56; update_chol src/util/common_covmat_ops.jl:38-42) ----
 function AbstractGPs.posterior(fx::FiniteGP{<:HipPosteriorGP}, y::AbstractVector{<:Real})
     post = fx.f
-    px = points(fx.x)
-    px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior"))
-    xbuf, cx, T = px
-    nz = noise(fx.Σy, T)
-    nz === nothing && throw(ArgumentError("dense Σy is not accelerated"))
-    m2 = prior_mean(post.prior.gp, fx.x, T)
+    T = getfield(post.data.C, :T)
+    xbuf, cx, nbuf, cn, m2 = joint_args(fx, post.prior.gp, T)
     δ2 = m2 === nothing ? Vector{T}(y) : Vector{T}(y) - m2                 # :48-49
     δ = vcat(post.data.δ, δ2)                                              # :52
     α = Vector{T}(undef, length(δ))
     lp = Ref{T}(zero(T))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve xbuf nz δ α begin
+    GC.@preserve xbuf nbuf δ α begin
         check(ccall((:gp_posterior_update, libgpmi355), Int32,
             (Ptr{Cvoid}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Ref{T}),
-            getfield(post.data.C, :handle), cx, nz[2], δ, h, α, lp))
+            getfield(post.data.C, :handle), cx, cn, δ, h, α, lp))
     end
-    C = DeviceCholesky(h[], length(δ), T)
-    finalizer(c -> ccall((:gp_posterior_free, libgpmi355), Int32, (Ptr{Cvoid},), getfield(c, :handle)), C)
-    return HipPosteriorGP(post.prior, (α=α, C=C, x=vcat(post.data.x, fx.x), δ=δ), Float64(lp[]))   # :54-55
+    return HipPosteriorGP(post.prior, (α=α, C=device_cholesky(h[], length(δ), T), x=vcat(post.data.x, fx.x), δ=δ), Float64(lp[]))   # :54-55
 end
 
-# ---- sampling (src/finite_gp_projection.jl:233-237): m .+ C.U' * randn(rng, n, N), product on the device ----------
+# ---- sampling (src/finite_gp_projection.jl:233-237, 271-277): m .+ C.U' * randn(rng, n, N), factor and product on the device ----
 function Random.rand(rng::Random.AbstractRNG, fx::FiniteGP{<:HipGP}, N::Int)
     a = marshal(fx)
     a === nothing && return rand(rng, stock(fx), N)
     T = a.T
-    p0 = posterior(fx, zeros(T, length(fx)))          # factor of cov(fx); α = C \ (0 − m) is discarded
+    p0 = posterior(FiniteGP(HipGP(GP(fx.f.gp.kernel), fx.f.ctx), fx.x, fx.Σy), zeros(T, length(fx)))   # factor of cov(fx)
     ξ = randn(rng, T, length(fx), N)
     out = similar(ξ)
     GC.@preserve ξ out check(ccall((:gp_posterior_factor_mul, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
         getfield(p0.data.C, :handle), ξ, N, out))
     return mean(fx) .+ out
 end
+Random.rand(rng::Random.AbstractRNG, fx::FiniteGP{<:HipGP}) = vec(rand(rng, fx, 1))
+Random.rand(fx::FiniteGP{<:HipGP}, N::Int) = rand(Random.default_rng(), fx, N)
+Random.rand(fx::FiniteGP{<:HipGP}) = rand(Random.default_rng(), fx)
+
+post_handle(f::HipPosteriorGP) = (getfield(f.data.C, :handle), getfield(f.data.C, :T), :gp_posterior_logpdf, :gp_posterior_rand)
+
+# logpdf(post(x*, Σy*), Y*) and rand(post(x*, Σy*)) — the FiniteGP-over-posterior path of the reference (mean_and_cov of the
+# posterior + Σy*, cholesky, logdet/_sqmahal or m + U'ξ) as ONE device call each; nothing is refitted
+function joint_logpdf(f, fx::FiniteGP, Y::AbstractVecOrMat{<:Real})
+    h, T, sym_lp, _ = post_handle(f)
+    size(Y, 1) == length(fx) || throw(DimensionMismatch("length(fx) = $(length(fx)) but Y has $(size(Y, 1)) rows"))
+    xbuf, cx, nbuf, cn, pm = joint_args(fx, f.prior.gp, T)
+    Yd = Matrix{T}(reshape(Y, size(Y, 1), :))
+    out = Vector{T}(undef, size(Yd, 2))
+    GC.@preserve xbuf nbuf pm Yd out begin
+        rc = sym_lp === :gp_posterior_logpdf ?
+            ccall((:gp_posterior_logpdf, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Ref{CNoise}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}),
+                h, cx, pm === nothing ? C_NULL : pointer(pm), cn, Yd, size(Yd, 1), size(Yd, 2), out) :
+            ccall((:gp_vfe_logpdf, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Ref{CNoise}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}),
+                h, cx, pm === nothing ? C_NULL : pointer(pm), cn, Yd, size(Yd, 1), size(Yd, 2), out)
+        check(rc)
+    end
+    return Y isa AbstractVector ? out[1] : out
+end
+function joint_rand!(rng::Random.AbstractRNG, f, fx::FiniteGP, out::AbstractVecOrMat{<:Real})
+    h, T, _, sym_r = post_handle(f)
+    size(out, 1) == length(fx) || throw(DimensionMismatch("length(fx) = $(length(fx)) but the output has $(size(out, 1)) rows"))
+    xbuf, cx, nbuf, cn, pm = joint_args(fx, f.prior.gp, T)
+    N = size(out, 2)
+    ξ = randn(rng, T, length(fx), N)
+    res = Matrix{T}(undef, length(fx), N)
+    GC.@preserve xbuf nbuf pm ξ res begin
+        rc = sym_r === :gp_posterior_rand ?
+            ccall((:gp_posterior_rand, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Ref{CNoise}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+                h, cx, pm === nothing ? C_NULL : pointer(pm), cn, ξ, N, res) :
+            ccall((:gp_vfe_rand, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Ref{CNoise}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+                h, cx, pm === nothing ? C_NULL : pointer(pm), cn, ξ, N, res)
+        check(rc)
+    end
+    out .= reshape(res, size(out))
+    return out
+end
 
 # ---- predictive methods (src/exact_gpr_posterior.jl:60-90) ----------------------------------------
 function predict(f::HipPosteriorGP, x::AbstractVector, what::Integer)
-    px = points(x)
-    px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior"))
-    xbuf, cx, T = px
+    T = getfield(f.data.C, :T)
+    px = points(x, T)
+    px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior (use a Vector, ColVecs or RowVecs)"))
+    xbuf, cx = px
     ns = length(x)
     pm = prior_mean(f.prior.gp, x, T)
     m = (what & 1) != 0 ? Vector{T}(undef, ns) : T[]
@@ -303,29 +432,51 @@ struct HipApproxPosteriorGP{Tapprox,Tprior<:HipGP} <: AbstractGP
     prior::Tprior
     handle::Base.RefValue{Ptr{Cvoid}}
     T::DataType
+    objective::Float64                 # ELBO / DTC evidence from the same streamed pass
+end
+post_handle(f::HipApproxPosteriorGP) = (f.handle[], f.T, :gp_vfe_logpdf, :gp_vfe_rand)
+function approx_posterior(approx, prior, h::Base.RefValue{Ptr{Cvoid}}, ::Type{T}, obj) where {T}
+    finalizer(hh -> ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), hh[]), h)
+    return HipApproxPosteriorGP(approx, prior, h, T, Float64(obj))
+end
+
+# FiniteGP API of the two posterior types on the device
+for PT in (:HipPosteriorGP, :HipApproxPosteriorGP)
+    @eval begin
+        Distributions.logpdf(fx::FiniteGP{<:$PT}, Y::AbstractVecOrMat{<:Real}) = joint_logpdf(fx.f, fx, Y)
+        Random.rand(rng::Random.AbstractRNG, fx::FiniteGP{<:$PT}, N::Int) =
+            joint_rand!(rng, fx.f, fx, Matrix{post_handle(fx.f)[2]}(undef, length(fx), N))
+        Random.rand(rng::Random.AbstractRNG, fx::FiniteGP{<:$PT}) = joint_rand!(rng, fx.f, fx, Vector{post_handle(fx.f)[2]}(undef, length(fx)))
+        Random.rand!(rng::Random.AbstractRNG, fx::FiniteGP{<:$PT}, y::AbstractVecOrMat{<:Real}) = joint_rand!(rng, fx.f, fx, y)   # :271-277
+    end
+end
+function Random.rand!(rng::Random.AbstractRNG, fx::FiniteGP{<:HipGP}, y::AbstractVecOrMat{<:Real})            # :271-277
+    y .= y isa AbstractVector ? rand(rng, fx) : rand(rng, fx, size(y, 2))
+    return y
 end
 
 function vfe_call(approx::Union{VFE,DTC}, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}, want_post::Bool)
     @assert approx.fz.f === fx.f                                                       # :59, :249, :283
     length(fx) == length(y) || throw(DimensionMismatch("length(fx) != length(y)"))    # :290-294
-    a = marshal(fx)
-    pz = points(approx.fz.x)
-    (a === nothing || pz === nothing) && return nothing
-    jit = approx.fz.Σy
-    jit isa Union{Fill,Diagonal{<:Any,<:Fill}} || return nothing
-    jitter = Float64(jit isa Fill ? FillArrays.getindex_value(jit) : FillArrays.getindex_value(jit.diag))
+    a = marshal(fx, eltype(y))
+    a === nothing && return nothing
     T = a.T
-    zbuf, cz, _ = pz
+    pz = points(approx.fz.x, T)
+    pz === nothing && return nothing
+    jit = approx.fz.Σy
+    jit isa Diagonal{<:Any,<:Fill} || return nothing
+    jitter = Float64(FillArrays.getindex_value(jit.diag))
+    zbuf, cz = pz
     yv = Vector{T}(y)
     obj = Ref{T}(zero(T))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     mptr = a.m === nothing ? C_NULL : pointer(a.m)
-    GC.@preserve a zbuf yv begin
+    GC.@preserve a zbuf yv h begin
         check(ccall((:gp_vfe_fit, libgpmi355), Int32,
             (Ptr{Cvoid}, Ref{CKernel}, Ref{CPoints}, Ref{CPoints}, Ref{CNoise}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
                 Ptr{Ptr{Cvoid}}, Ref{T}),
             fx.f.ctx.handle, a.ck, a.cx, cz, a.cn, jitter, mptr, yv, approx isa VFE ? 0 : 1,
-            want_post ? Base.unsafe_convert(Ptr{Ptr{Cvoid}}, h) : Ptr{Ptr{Cvoid}}(C_NULL), obj))
+            want_post ? h : Ptr{Ptr{Cvoid}}(C_NULL), obj))
     end
     return (h, Float64(obj[]), T)
 end
@@ -333,9 +484,7 @@ end
 function AbstractGPs.posterior(approx::Union{VFE,DTC}, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     r = vfe_call(approx, fx, y, true)
     r === nothing && return posterior(typeof(approx)(FiniteGP(fx.f.gp, approx.fz.x, approx.fz.Σy)), stock(fx), y)
-    p = HipApproxPosteriorGP(approx, fx.f, r[1], r[3])
-    finalizer(hh -> ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), hh[]), p.handle)
-    return p
+    return approx_posterior(approx, fx.f, r[1], r[3], r[2])
 end
 function AbstractGPs.approx_log_evidence(approx::Union{VFE,DTC}, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     r = vfe_call(approx, fx, y, false)
@@ -346,41 +495,67 @@ end
 AbstractGPs.elbo(vfe::VFE, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}) = approx_log_evidence(vfe, fx, y)  # :254
 
 function vfe_predict(f::HipApproxPosteriorGP, x::AbstractVector, what::Integer)
-    xbuf, cx, T = points(x)
+    T = f.T
+    px = points(x, T)
+    px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior (use a Vector, ColVecs or RowVecs)"))
+    xbuf, cx = px
     ns = length(x)
     pm = prior_mean(f.prior.gp, x, T)
     m = (what & 1) != 0 ? Vector{T}(undef, ns) : T[]
     v = (what & 2) != 0 ? Vector{T}(undef, ns) : T[]
-    GC.@preserve xbuf pm m v begin
+    c = (what & 4) != 0 ? Matrix{T}(undef, ns, ns) : Matrix{T}(undef, 0, 0)
+    GC.@preserve xbuf pm m v c begin
         check(ccall((:gp_vfe_predict, libgpmi355), Int32,
-            (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
-            f.handle[], cx, pm === nothing ? C_NULL : pointer(pm), what, m, v))
+            (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+            f.handle[], cx, pm === nothing ? C_NULL : pointer(pm), what, m, v, c))
     end
-    return m, v
+    return m, v, c
 end
 Statistics.mean(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 1)[1]          # :183-185
+Statistics.cov(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 4)[3]           # :187-190
 Statistics.var(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 2)[2]           # :192-195
-StatsBase.mean_and_var(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 3)      # :212-217
+function Statistics.cov(f::HipApproxPosteriorGP, x::AbstractVector, z::AbstractVector)         # :197-203
+    c = vfe_predict(f, vcat(x, z), 4)[3]
+    return c[1:length(x), (length(x) + 1):end]
+end
+function StatsBase.mean_and_cov(f::HipApproxPosteriorGP, x::AbstractVector)                    # :205-210
+    m, _, c = vfe_predict(f, x, 5)
+    return m, c
+end
+StatsBase.mean_and_var(f::HipApproxPosteriorGP, x::AbstractVector) = vfe_predict(f, x, 3)[1:2] # :212-217
 AbstractGPs.inducing_points(f::HipApproxPosteriorGP) = f.approx.fz.x                            # :219
 
 # update_posterior with new observations, same pseudo-points (src/sparse_approximations.jl:87-121)
 function AbstractGPs.update_posterior(f::HipApproxPosteriorGP, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     @assert f.prior === fx.f
-    xbuf, cx, T = points(fx.x)
-    nz = noise(fx.Σy, T)
-    nz === nothing && throw(ArgumentError("dense Σy is not accelerated"))
-    m2 = prior_mean(f.prior.gp, fx.x, T)
+    T = f.T
+    xbuf, cx, nbuf, cn, m2 = joint_args(fx, f.prior.gp, T)
     yv = Vector{T}(y)
     obj = Ref{T}(zero(T))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve xbuf nz m2 yv begin
+    GC.@preserve xbuf nbuf m2 yv begin
         check(ccall((:gp_vfe_update, libgpmi355), Int32,
             (Ptr{Cvoid}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{T}),
-            f.handle[], cx, nz[2], m2 === nothing ? C_NULL : pointer(m2), yv, h, obj))
+            f.handle[], cx, cn, m2 === nothing ? C_NULL : pointer(m2), yv, h, obj))
     end
-    p = HipApproxPosteriorGP(f.approx, f.prior, h, T)
-    finalizer(hh -> ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), hh[]), p.handle)
-    return p
+    return approx_posterior(f.approx, f.prior, h, T, obj[])
+end
+
+# update_posterior with new pseudo-points (src/sparse_approximations.jl:131-176): bordered K_zz factor + re-streamed new block
+# rows on the device; the approximation object is rebuilt with z = vcat(z_old, z_new) like _update_approx (:178-179)
+function AbstractGPs.update_posterior(f::HipApproxPosteriorGP, fz::FiniteGP{<:HipGP})
+    @assert f.prior === fz.f                                                                   # :132
+    T = f.T
+    pz = points(fz.x, T)
+    pz === nothing && throw(ArgumentError("unsupported container for the new pseudo-points"))
+    zbuf, cz = pz
+    obj = Ref{T}(zero(T))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve zbuf begin
+        check(ccall((:gp_vfe_append, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ref{Ptr{Cvoid}}, Ref{T}), f.handle[], cz, h, obj))
+    end
+    fz_new = f.approx.fz.f(vcat(f.approx.fz.x, fz.x), f.approx.fz.Σy)                         # :160-162
+    return approx_posterior(typeof(f.approx)(fz_new), f.prior, h, T, obj[])
 end
 
 end # module

@@ -77,6 +77,8 @@ if __name__ == "__main__":
             exact("C3", 32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5), {**base, **p}, reps=2)
     for k, v in base.items():
         agp.default_context(0).set_param(k, v)
+    if "C5only16" in which:
+        vfe({"vfe_chunk": 16384}, reps=1)
     if "C5" in which:
         for ch in (8192, 16384, 32768):
             vfe({"vfe_chunk": ch})
