@@ -196,7 +196,39 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             grid = dim3((unsigned)total, 1);
         }
         if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
-        if (kmajor)
+        // wide tile (256×128, 3-stage ring, one workgroup per CU): large launches only — "gemm_wide" 1 = launches of at least
+        // gemm_wide_min tiles, 2 = wherever the shape allows (tests)
+        bool wide = false;
+        if constexpr (std::is_same<T, CT>::value) {
+            const long bk = 128 / (long)sizeof(T);
+            const long tm2 = (M + 255) / 256;
+            const bool shape_ok = !kmajor && c->gemm_wide > 0 && c->gemm_dma && (M % 128) == 0 && (N % 64) == 0 && (K % bk) == 0 && K >= 2 * bk &&
+                                  (g.ktri != 2 || true) && (!single_lower || ((g.row0 - g.col0) % 128) == 0);
+            if (shape_ok) {
+                long ntile = tm2 * tn;
+                GridMap gw = g;
+                gw.compact = 0;
+                dim3 gridw((unsigned)tn, (unsigned)tm2);
+                if (single_lower) {  // lower trapezoid in 256×128 tiles: row tile i has min(tn, dt + 2i + 2) column tiles
+                    long tri = std::min(tm2, std::max(0L, (tn - dt - 2 + 1) / 2));
+                    ntile = tri * tri + tri * (dt + 1) + (tm2 - tri) * tn;
+                    gw.compact = 4;
+                    gridw = dim3((unsigned)ntile, 1);
+                }
+                if (g.nbatch > 1) gridw.z = (unsigned)g.nbatch;
+                if (c->gemm_wide >= 2 || ntile * std::max(1, g.nbatch) >= c->gemm_wide_min) {
+                    if (!c->gemm_wide_set) {
+                        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
+                        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
+                        c->gemm_wide_set = true;
+                    }
+                    hipLaunchKernelGGL((gemm_nt_wide_kernel<T>), gridw, dim3(256), 147456, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, gw);
+                    wide = true;
+                }
+            }
+        }
+        if (wide) {
+        } else if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
         else if ((c->gemm_streamk || c->sk_scope > 0) && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
@@ -1346,6 +1378,8 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
+    else if (!strcmp(name, "gemm_wide")) c->gemm_wide = (int)v;
+    else if (!strcmp(name, "gemm_wide_min")) c->gemm_wide_min = std::max<int64_t>(1, v);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");

@@ -696,7 +696,8 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
     // transport: RCCL between distinct devices unless told otherwise (GPMI_COMM=rccl|p2p); virtual ranks can only copy
     const char* want = getenv("GPMI_COMM");
     m->comm = 2;
-    if (rc == 0 && !dup && ndev > 1 && !(want && !strcmp(want, "p2p"))) {
+    const bool force_rccl = want && !strcmp(want, "rccl");  // also with ONE device: exercises dlopen + ncclCommInitAll (API check)
+    if (rc == 0 && !dup && (ndev > 1 || force_rccl) && !(want && !strcmp(want, "p2p"))) {
         std::lock_guard<std::mutex> l(g_rccl_mu);
         if (g_rccl.load()) {
             std::vector<ncclComm_t_> comms((size_t)ndev, nullptr);

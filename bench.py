@@ -178,12 +178,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536)
-    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--n", "--npoints", dest="n", type=int, default=65536, help="(--npoints under torch.distributed.run: its parser claims --n)")
+    ap.add_argument("--d", "--dim", dest="d", type=int, default=3)
     ap.add_argument("--nb", type=int, default=0, help="outer panel width override (single GPU) / distribution block (multi GPU)")
     ap.add_argument("--grid", default="", help="process grid PxQ of the multi-device run (default: chosen by the library)")
     ap.add_argument("--depth", type=int, default=0, help="look-ahead depth of the multi-device schedule")
-    ap.add_argument("--virtual", type=int, default=0, help="V virtual ranks sharing GPU 0 (schedule test / 1-rank overhead measurement)")
+    ap.add_argument("--vranks", dest="virtual", type=int, default=0, help="V virtual ranks sharing GPU 0 (schedule test / 1-rank overhead measurement)")
     ap.add_argument("--selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity properties")

@@ -20,8 +20,11 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--lower", type=int, default=0)
     ap.add_argument("--lda", type=int, default=0, help="operand leading dimension (0: k + 32)")
+    ap.add_argument("--params", default="", help="ctx parameters name=value,...")
     args = ap.parse_args()
     ctx = agp.Context(0)
+    for kv in [kv for kv in args.params.split(",") if kv]:
+        ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
     lib, h = ctx.lib, ctx.handle
     c = C.c_double()
     check(lib.gp_bench_mfma_f64(h, 20000, C.byref(c)))
@@ -42,7 +45,7 @@ def main():
         check(lib.gpd_sync(h))
         dt = (time.perf_counter() - t0) / args.reps
         fl = 2.0 * m * n * k * (0.5 if args.lower else 1.0)
-        print(json.dumps({"m": m, "n": n, "k": k, "lower": args.lower, "lda": lda, "ms": dt * 1e3, "tflops": fl / dt / 1e12}), flush=True)
+        print(json.dumps({"m": m, "n": n, "k": k, "lower": args.lower, "params": args.params, "ms": round(dt * 1e3, 4), "tflops": round(fl / dt / 1e12, 2)}), flush=True)
 
 
 if __name__ == "__main__":

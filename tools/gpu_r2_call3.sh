@@ -3,8 +3,8 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q --no-header -rA --tb=short -p no:cacheprovider --timeout 900 > gpurun_out/pytest_gpu.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed|FAILED|ERROR" gpurun_out/pytest_gpu.log | tail -15
-timeout 120 python bench.py --selftest --virtual 4 --grid 2x2 2>&1 | tail -2
-for A in "" "--virtual 1" "--virtual 1 --nb 2048" "--virtual 2" "--virtual 4 --grid 2x2" "--virtual 4" "--virtual 8"; do
+timeout 120 python bench.py --selftest --vranks 4 --grid 2x2 2>&1 | tail -2
+for A in "" "--vranks 1" "--vranks 1 --nb 2048" "--vranks 2" "--vranks 4 --grid 2x2" "--vranks 4" "--vranks 8"; do
   echo "== bench $A"
   timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $A 2>&1 | tail -1 | python -c "
 import sys,json
