@@ -55,7 +55,7 @@ PROTOTYPES = {
     "gp_posterior_fit": (i32, [vp, PK, PP, PN, vp, vp, C.POINTER(vp), vp, vp]),
     "gp_posterior_predict": (i32, [vp, PP, vp, i32, vp, vp, vp]),
     "gp_posterior_get_factor": (i32, [vp, vp]),
-    "gp_logpdf_grad": (i32, [vp, PK, PP, PN, vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl), vp, vp]),
+    "gp_logpdf_grad": (i32, [vp, PK, PP, PN, vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl), vp, vp, vp]),
     "gp_posterior_update": (i32, [vp, PP, PN, vp, C.POINTER(vp), vp, vp]),
     "gp_posterior_factor_mul": (i32, [vp, vp, i32, vp]),
     "gp_posterior_n": (i64, [vp]),
@@ -84,6 +84,7 @@ PROTOTYPES = {
     "gpd_gemm_time": (i32, [vp, C.POINTER(dbl), C.POINTER(i64)]),
     "gp_probe_mfma_f64": (i32, [vp, vp, vp, vp]),
     "gp_bench_mfma_f64": (i32, [vp, i32, C.POINTER(dbl)]),
+    "gp_bench_mfma_f32": (i32, [vp, i32, i32, C.POINTER(dbl)]),
 }
 
 

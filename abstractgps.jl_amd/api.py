@@ -398,11 +398,11 @@ def logpdf(fx: FiniteGP, y):
     return out[0] if y.ndim == 1 else out
 
 
-def logpdf_and_grad(fx: FiniteGP, y) -> tuple:
+def logpdf_and_grad(fx: FiniteGP, y, wrt_x: bool = False) -> tuple:
     """Value and gradient of logpdf(fx, y) for the rrule of the accelerated path (the reference differentiates the same
     expression by AD — test/finite_gp_projection.jl:152-178).  Returns (logpdf, grads) with grads =
     {"variance": ∂/∂σ_k², "scale": ∂/∂s (ScaleTransform) or ∂/∂v (ARDTransform) or None, "noise": ∂/∂σ² (scalar Σy) or the
-    vector ∂/∂Σy_ii, "y": −α, "mean": +α}."""
+    vector ∂/∂Σy_ii, "y": −α, "mean": +α} and, with wrt_x, "x": ∂/∂x in the shape of the input container's array."""
     y = _check_y(fx, y)
     if y.ndim != 1:
         raise TypeError("logpdf_and_grad expects a vector of observations")
@@ -423,14 +423,21 @@ def logpdf_and_grad(fx: FiniteGP, y) -> tuple:
     dscale = (C.c_double * max(kk.nscale, 1))()
     dnoise = np.empty(1 if nz.kind == 0 else px.n, dtype=dt)
     dy = np.empty(px.n, dtype=dt)
+    # ∂/∂x comes back in the ABI layout of the inputs: (n,) vector; ColVecs (N, D) C-order = D×N column-major; RowVecs (D, N)
+    dxb = None
+    if wrt_x:
+        dxb = np.empty((px.n,) if px.layout == 0 else ((px.n, px.d) if px.layout == 1 else (px.d, px.n)), dtype=dt)
     check(ctx.lib.gp_logpdf_grad(ctx.handle, C.byref(kk), C.byref(px), C.byref(nz), m.ptr(mean), yv.ctypes.data,
-                                 lp.ctypes.data, C.byref(dvar), dscale, dnoise.ctypes.data, dy.ctypes.data))
+                                 lp.ctypes.data, C.byref(dvar), dscale, dnoise.ctypes.data, dy.ctypes.data, m.ptr(dxb)))
     sc = None
     if kk.nscale == 1:
         sc = float(dscale[0])
     elif kk.nscale > 1:
         sc = np.array([dscale[i] for i in range(kk.nscale)])
-    return lp[0], {"variance": dvar.value, "scale": sc, "noise": dnoise[0] if nz.kind == 0 else dnoise, "y": dy, "mean": -dy}
+    g = {"variance": dvar.value, "scale": sc, "noise": dnoise[0] if nz.kind == 0 else dnoise, "y": dy, "mean": -dy}
+    if wrt_x:
+        g["x"] = dxb if px.layout == 0 else np.ascontiguousarray(dxb.T)  # ColVecs -> (D, N) like x.X; RowVecs -> (N, D)
+    return lp[0], g
 
 
 def loglikelihood(fx: FiniteGP, Y):  # src/finite_gp_projection.jl:304

@@ -245,6 +245,15 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             if (R == 0) G2 = 0;
             hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g, ntiles, (int)G2);
+        } else if ((c->gemm_ring3 == 2 || (c->gemm_ring3 == 1 && sizeof(T) == 4)) && (c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) &&
+                   std::is_same<T, CT>::value) {
+            // three-stage operand ring, one workgroup per CU (96 KiB of dynamic LDS)
+            if (!c->gemm_ring3_set) {
+                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma3_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+                c->gemm_ring3_set = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_dma3_kernel<T>), grid, dim3(256), 98304, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, g);
         } else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
             // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
             // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
@@ -901,7 +910,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
 // logpdf value + gradient (see include/gpmi355.h gp_logpdf_grad)
 template <typename T>
 static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean,
-                         const void* y, void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy) {
+                         const void* y, void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy, void* dx) {
     const long n = x->n;
     const int d = x->d;
     if (d > 16) return set_arg_err(3, "gradients support D <= 16");
@@ -913,7 +922,9 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     SkScope sk(c);
     const long np = post.np, ld = post.ld;
     hipStream_t s = c->sm;
-    void *W_v = 0, *Ci_v = 0, *g_v = 0, *dn_v = 0, *sc_v = 0;
+    void *W_v = 0, *Ci_v = 0, *g_v = 0, *dn_v = 0, *sc_v = 0, *gx_v = 0;
+    const size_t gx_b = sizeof(double) * (size_t)d * np;
+    std::vector<double> gx_h(dx ? (size_t)d * np : 0);
     const size_t M_b = sizeof(T) * (size_t)(np + 128) * ld, g_b = sizeof(double) * 32, dn_b = sizeof(T) * (size_t)np;
     const size_t sc_b = sizeof(double) * 16;
     DevBufs bufs(c);
@@ -930,6 +941,7 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         RC(bufs.get(g_b, &g_v));
         RC(bufs.get(dn_b, &dn_v));
         RC(bufs.get(sc_b, &sc_v));
+        if (dx) RC(bufs.get(gx_b, &gx_v));
         T* W = (T*)W_v;
         T* Ci = (T*)Ci_v;
         HIPCHK(hipMemsetAsync(g_v, 0, g_b, s));
@@ -958,6 +970,13 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         hipLaunchKernelGGL(noise_grad_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)Ci, ld,
                            (const T*)post.alpha, n, (T*)dn_v, (double*)g_v + 24);
         HIPCHK(hipGetLastError());
+        if (dx) {  // ∂/∂x: full-square pass (the mirrored C⁻¹ entry serves the tiles above the diagonal)
+            HIPCHK(hipMemsetAsync(gx_v, 0, gx_b, s));
+            hipLaunchKernelGGL((kgradx_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
+                               (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)gx_v, np);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(gx_h.data(), gx_v, gx_b, hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(hipMemcpyAsync(g_h, g_v, g_b, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(dn_h.data(), dn_v, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -978,6 +997,16 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     }
     if (dy)
         for (long i = 0; i < n; ++i) ((T*)dy)[i] = -alpha_h[i];
+    if (dx) {  // same container layout as the inputs (src/finite_gp_projection.jl:32-37)
+        T* o = (T*)dx;
+        for (int dd = 0; dd < d; ++dd)
+            for (long i = 0; i < n; ++i) {
+                const T v = (T)gx_h[(size_t)dd * np + i];
+                if (x->layout == 0) o[i] = v;
+                else if (x->layout == 1) o[(long)dd + i * d] = v;
+                else o[i + (long)dd * n] = v;
+            }
+    }
     return 0;
 }
 
@@ -1378,6 +1407,9 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
+    else if (!strcmp(name, "gemm_ring3")) c->gemm_ring3 = (int)v;
+    else if (!strcmp(name, "vfe_ks")) c->vfe_ks = std::max<int64_t>(512, round_up(v, 512));
+    else if (!strcmp(name, "vfe_sk")) c->vfe_sk = v != 0;
     else if (!strcmp(name, "gemm_wide")) c->gemm_wide = (int)v;
     else if (!strcmp(name, "gemm_wide_min")) c->gemm_wide_min = std::max<int64_t>(1, v);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
@@ -1538,14 +1570,14 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
 }
 
 int32_t gp_logpdf_grad(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean, const void* y,
-                       void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy) {
+                       void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy, void* dx) {
     RC(check_fit_args(c, k, x, noise));
     if (!y) return set_arg_err(6, "y is NULL");
     if (!logpdf_out) return set_arg_err(7, "logpdf_out is NULL");
     std::lock_guard<std::mutex> l(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    return k->dtype == 0 ? grad_impl<double>(c, k, x, noise, mean, y, logpdf_out, dvar, dscale, dnoise, dy)
-                         : grad_impl<float>(c, k, x, noise, mean, y, logpdf_out, dvar, dscale, dnoise, dy);
+    return k->dtype == 0 ? grad_impl<double>(c, k, x, noise, mean, y, logpdf_out, dvar, dscale, dnoise, dy, dx)
+                         : grad_impl<float>(c, k, x, noise, mean, y, logpdf_out, dvar, dscale, dnoise, dy, dx);
 }
 
 int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post** out,
@@ -1930,6 +1962,40 @@ int32_t gp_bench_mfma_f64(gp_ctx* c, int32_t iters, double* tflops_out) {
     HIPCHK(hipEventElapsedTime(&ms, a, b));
     const double flops = (double)blocks * 16.0 * (double)iters * 4.0 * 2.0 * 16 * 16 * 4;
     *tflops_out = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIPCHK(hipFree(buf));
+    return 0;
+}
+
+// measured TFLOP/s of back-to-back fp32 MFMAs: variant 0 = v_mfma_f32_16x16x4_f32 (what the GEMM kernels issue), 1 = 32x32x2
+int32_t gp_bench_mfma_f32(gp_ctx* c, int32_t variant, int32_t iters, double* tflops_out) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    float* buf;
+    HIPCHK(hipMalloc((void**)&buf, 64));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount;
+    const size_t smem = 96 * 1024;
+    auto run = [&](auto kern) -> int32_t {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), smem, c->sm, buf, 64);
+        HIPCHK(hipEventRecord(a, c->sm));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), smem, c->sm, buf, iters);
+        HIPCHK(hipEventRecord(b, c->sm));
+        HIPCHK(hipStreamSynchronize(c->sm));
+        return 0;
+    };
+    RC(variant == 0 ? run(mfma_rate_f32_kernel<0>) : run(mfma_rate_f32_kernel<1>));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    const double per = variant == 0 ? 2.0 * 16 * 16 * 4 : 2.0 * 32 * 32 * 2;
+    *tflops_out = (double)blocks * 16.0 * (double)iters * 4.0 * per / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     HIPCHK(hipFree(buf));

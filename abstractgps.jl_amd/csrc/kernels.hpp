@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
 
     for (int kt = kt0; kt < nk; ++kt) {
         const int cur = (kt - kt0) & 1;
+#if GPMI_ABL & 16  // ablation (fp32 only): no operand DMA inside the loop
+        if (sizeof(T) != 4)
+#endif
         dma(cur ^ 1, (kt + 1 < nk) ? kt + 1 : kt);  // the last step re-fetches its own tile into the idle buffer
         chunk_t a[2][4], b[2][4];
 #pragma unroll
@@ -459,7 +462,175 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
         __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC + 8, 0);
 #endif
         __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this step in front of the vmcnt(0) + barrier
+#if GPMI_ABL & 32  // ablation (fp32 only): no wait + barrier at the end of the step
+        if (sizeof(T) != 4)
+#endif
         dma_wait_barrier();
+    }
+
+#if GPMI_ABL & 8  // ablation: no epilogue stores for fp32 (timing experiment only)
+    if (sizeof(T) == 4) {
+        T sink = T(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (sink == T(12345.678)) Cw[0] = sink;
+        return;
+    }
+#endif
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = -acc[mt][nt][r];
+    }
+}
+
+// gemm_nt_dma3: gemm_nt_dma with a THREE-stage ring (96 KiB of dynamic LDS, hence one workgroup per CU): the operand DMA of k-step
+// kt+2 is in flight while kt computes, and the only wait in the loop is vmcnt(8) — everything but the youngest stage's eight
+// DMA instructions of this wave has landed.  Used for the fp32 VFE GEMMs ("gemm_ring3").
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma3_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
+                                                               int N, int K, GridMap g) {
+    using CT = T;
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    using acc_t = typename TR::acc_t;
+    constexpr int VEC = TR::VEC;
+    constexpr int BK = 8 * VEC;
+
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (g.compact == 1) compact_tile(g, (int)blockIdx.x, bi, bj);
+    else if (g.compact >= 2) {
+        if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
+    } else if (g.ktri == 1) {
+        bi = (int)gridDim.y - 1 - bi;  // triangular k range: the long row tiles are dispatched first
+    }
+    if (g.nbatch > 1) {
+        C += (long)blockIdx.z * g.cstride;
+        A += (long)blockIdx.z * K;
+        B += (long)blockIdx.z * K;
+    }
+    const int m0 = bi * 128, n0 = bj * 128;
+    long gr0 = 0, gc0 = 0;
+    if (g.lower) {
+        gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
+        gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
+        if (gc0 > gr0 + 127) return;  // whole tile above the diagonal (block-uniform)
+    }
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring3_smem[];  // 3 stages × (A 16 KiB + B 16 KiB)
+    chunk_t (*As)[128 * 8] = reinterpret_cast<chunk_t (*)[128 * 8]>(ring3_smem);
+    chunk_t (*Bs)[128 * 8] = reinterpret_cast<chunk_t (*)[128 * 8]>(ring3_smem + 3 * 16384);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
+    if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
+
+    // DMA map: instruction i of wave w covers rows 8·(4i+w) .. +8; lane -> row 8·(4i+w) + (lane>>3), slot lane&7
+    const int drow = lane >> 3;
+    const T* Ag[4];
+    const T* Bg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * (4 * i + w) + drow;
+        const int cch = (lane & 7) ^ ((r >> 1) & 7);
+        Ag[i] = A + (long)(m0 + r) * lda + cch * VEC;
+        Bg[i] = B + (long)(n0 + r) * ldb + cch * VEC;
+    }
+    // The DMA is issued from inline asm: hipcc (ROCm 7.2) otherwise drains vmcnt(0) in front of the next ds_read of the
+    // OTHER buffer (it cannot tell the two apart), which serialises the prefetch.  The only consumer-side wait is the
+    // explicit vmcnt(0) in front of the step's barrier below.
+    const unsigned ldsA = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&As[0][0];
+    const unsigned ldsB = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&Bs[0][0];
+    auto dma1 = [&](const T* src, unsigned dst) {
+        unsigned keep;
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(d)
+                     : "memory");
+    };
+    auto dma = [&](int buf, long kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+            dma1(Bg[i] + kt * BK, ldsB + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+        }
+    };
+    auto dma_wait_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    const int li = lane & 15, lg = lane >> 4;
+    acc_t acc[4][4];
+    CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
+    const CT* const Cr = active ? Cw : C + li;
+    const int kt0 = (g.ktri == 2) ? m0 / BK : 0;
+    int nk = K / BK;
+    if (g.ktri == 1) nk = min(nk, (g.ktri_off + m0 + 128) / BK);
+    dma(0, kt0);
+    dma(1, (kt0 + 1 < nk) ? kt0 + 1 : kt0);
+    if (g.beta0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = T(0);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
+    }
+
+    // fragment slots: row wr·64 + t·16 + li, chunk 4h+lg -> slot (row·8) + ((4h+lg) ^ swz(li))
+    const int sw = (li >> 1) & 7;
+    const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
+    dma_wait_barrier();
+
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) % 3;
+        int nx2 = cur + 2;
+        if (nx2 >= 3) nx2 -= 3;
+        dma(nx2, (kt + 2 < nk) ? kt + 2 : nk - 1);  // the tail re-fetches the last tile into an idle stage (uniform counts)
+        chunk_t a[2][4], b[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sl = (4 * h + lg) ^ sw;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[h][t] = As[cur][fa + t * 128 + sl];
+                b[h][t] = Bs[cur][fb + t * 128 + sl];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[h][mt][v], b[h][nt][v], acc[mt][nt]);
+#if GPMI_GEMM_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC - 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC + 8, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this step in front of the vmcnt(0) + barrier
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 
     if (active) {
@@ -1065,6 +1236,66 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, 
         double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         if (tid >= 1) v /= scale[tid - 1];  // the 1/s (1/v_p) factor of ∂r²
         atomicAdd(g + tid, v);
+    }
+}
+// kgradx: ∂logpdf/∂x_ip = 2 s_p σ² Σ_j (α_i α_j − C⁻¹_ij) dκ/dr²(r²_ij) (u_ip − u_jp)   (u = s∘x; both orders of the symmetric pair
+//   folded in) — the input gradient a deep-kernel model back-propagates (examples/2-deep-kernel-learning/script.jl).  One
+//   128×128 tile of the FULL square per workgroup (C⁻¹ is stored lower: the mirrored entry is read for tiles above the diagonal);
+//   row sums by wave shuffles, one atomicAdd per (row, p).  gx: double [d][ldg] (dimension-major like x).
+template <typename T, int NSMAX>
+__global__ __launch_bounds__(256) void kgradx_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ x, long ldx, int d,
+                                                      int kind, T variance, int nscale, const double* __restrict__ scale,
+                                                      const T* __restrict__ alpha, long n, double* __restrict__ gx, long ldg) {
+    constexpr int DC = 16;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    __shared__ T xi[DC][128];
+    __shared__ T xj[DC][128];
+    __shared__ T aj[128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < d * 128; e += 256) {  // d <= DC (checked by the host)
+        const int dd = e >> 7, i = e & 127;
+        xi[dd][i] = x[(long)dd * ldx + m0 + i];
+        xj[dd][i] = x[(long)dd * ldx + n0 + i];
+    }
+    if (tid < 128) aj[tid] = (n0 + tid < n) ? alpha[n0 + tid] : T(0);
+    __syncthreads();
+    for (int rr = 0; rr < 32; ++rr) {
+        const int row = w + 4 * rr;
+        const long gi = m0 + row;
+        if (gi >= n) continue;  // wave-uniform
+        const T ai = alpha[gi];
+        double acc[NSMAX];
+#pragma unroll
+        for (int p = 0; p < NSMAX; ++p) acc[p] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int col = 2 * lane + cc;
+            const long gj = n0 + col;
+            if (gj >= n || gj == gi) continue;
+            T d2 = 0;
+            for (int dd = 0; dd < d; ++dd) {
+                const T t = xi[dd][row] - xj[dd][col];
+                d2 = fma(t, t, d2);
+            }
+            T kap, dk;
+            kappa_and_dr2<T>(kind, d2, kap, dk);
+            const T ci = gi >= gj ? Cinv[gi * ld + gj] : Cinv[gj * ld + gi];
+            const double wgt = ((double)ai * (double)aj[col] - (double)ci) * (double)dk;
+#pragma unroll
+            for (int p = 0; p < NSMAX; ++p)
+                if (p < d) acc[p] += wgt * (double)(xi[p][row] - xj[p][col]);
+        }
+#pragma unroll
+        for (int p = 0; p < NSMAX; ++p) {
+            if (p >= d) break;
+            double v = acc[p];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) {
+                const double sp = nscale == 0 ? 1.0 : (nscale == 1 ? scale[0] : scale[p]);
+                atomicAdd(gx + (long)p * ldg + gi, 2.0 * sp * (double)variance * v);
+            }
+        }
     }
 }
 // out[i] = ½ (α_i² − Cinv_ii)   (∂logpdf/∂Σy_ii);  sum[0] += Σ_i out[i]   (one block of 256 threads per 256 rows)
@@ -1713,16 +1944,23 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
             if (FWD) {
                 for (int i = s0 + 64 + tid; i < nbv; i += 1024) {
                     const T* lrow = L + (b0 + i) * ldl + b0 + s0;
-                    T acc = 0;
-                    for (int c = 0; c < 64; ++c) acc = fma(lrow[c], rv[s0 + c], acc);
-                    rv[i] -= acc;
+                    T acc0 = 0, acc1 = 0;
+#pragma unroll
+                    for (int c = 0; c < 64; c += 2) {  // all 64 loads of the row segment in flight at once
+                        acc0 = fma(lrow[c], rv[s0 + c], acc0);
+                        acc1 = fma(lrow[c + 1], rv[s0 + c + 1], acc1);
+                    }
+                    rv[i] -= acc0 + acc1;
                 }
             } else {
                 for (int j = tid; j < s0; j += 1024) {
-                    T acc = 0;
-#pragma unroll 8
-                    for (int c = 0; c < 64; ++c) acc = fma(L[(b0 + s0 + c) * ldl + b0 + j], rv[s0 + c], acc);
-                    rv[j] -= acc;
+                    T acc0 = 0, acc1 = 0;
+#pragma unroll
+                    for (int c = 0; c < 64; c += 2) {  // 64 independent (coalesced) loads in flight: one memory round trip per step
+                        acc0 = fma(L[(b0 + s0 + c) * ldl + b0 + j], rv[s0 + c], acc0);
+                        acc1 = fma(L[(b0 + s0 + c + 1) * ldl + b0 + j], rv[s0 + c + 1], acc1);
+                    }
+                    rv[j] -= acc0 + acc1;
                 }
             }
             __syncthreads();
@@ -2029,6 +2267,36 @@ __global__ __launch_bounds__(1024) void mfma_rate_f64_kernel(double* out, int it
     if (s == 12345.678) {
         out[0] = s;  // keep live
         rate_smem[threadIdx.x] = 1;
+    }
+}
+
+// fp32 counterparts of mfma_rate_f64_kernel: back-to-back v_mfma_f32_16x16x4_f32 (VAR 0) or v_mfma_f32_32x32x2_f32 (VAR 1)
+typedef float f16_t __attribute__((ext_vector_type(16)));
+template <int VAR> __global__ __launch_bounds__(1024) void mfma_rate_f32_kernel(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rate_smem32[];
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    float s = 0;
+    if constexpr (VAR == 0) {
+        f4_t acc[4];
+        for (int i = 0; i < 4; ++i) acc[i] = (f4_t)((float)i);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        f16_t acc[4];
+        for (int i = 0; i < 4; ++i) acc[i] = (f16_t)((float)i);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 16; ++j) s += acc[i][j];
+    }
+    if (s == 12345.678f) {
+        out[0] = s;
+        rate_smem32[threadIdx.x] = 1;
     }
 }
 

@@ -85,8 +85,16 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     const long mp = round_up(m, 128);
     const int d = prev ? prev->d : x->d;
     const long CH = c->vfe_chunk;               // data points per streamed chunk
-    constexpr long KS = 2048;                   // fp32: data points per fp32 partial product
+    const long KS = std::min(c->vfe_ks, CH);    // fp32: data points per fp32 partial product
     const int NBAT = (int)(CH / KS);
+    if (CH % KS) return set_arg_err(1, "vfe_chunk must be a multiple of vfe_ks");
+    if (c->vfe_sk) ++c->sk_scope;
+    struct SkOff {
+        gp_ctx* c;
+        ~SkOff() {
+            if (c->vfe_sk) --c->sk_scope;
+        }
+    } sk_off{c};
     const long n = x ? x->n : 0, npad = round_up(std::max(n, 1L), CH);
     const long ld = mp + c->ldpad;              // M×M matrices and the CH×M chunk
     const T* y = (const T*)yv;

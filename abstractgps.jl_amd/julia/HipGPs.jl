@@ -200,7 +200,7 @@ function Distributions.logpdf(fx::FiniteGP{<:HipGP}, Y::AbstractVecOrMat{<:Real}
 end
 
 # ---- value + gradient: one factorisation, C⁻¹ by blocked TRSM + MFMA SYRK, one fused ½Σ(αᵢαⱼ − C⁻¹ᵢⱼ)∂Cᵢⱼ pass ----------
-function logpdf_and_grad(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
+function logpdf_and_grad(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}; wrt_x::Bool=true)
     a = marshal(fx, eltype(y))
     a === nothing && throw(ArgumentError("kernel / noise form is not accelerated"))
     T = a.T
@@ -209,14 +209,16 @@ function logpdf_and_grad(fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     dscale = zeros(Float64, max(length(a.scales), 1))
     dnoise = Vector{T}(undef, a.cn.kind == 0 ? 1 : length(yv))
     dy = Vector{T}(undef, length(yv))
+    dx = wrt_x ? similar(a.xbuf) : T[]                  # same container layout as the inputs (Vector / D×N / N×D)
     mptr = a.m === nothing ? C_NULL : pointer(a.m)
-    GC.@preserve a yv dscale dnoise dy begin
+    GC.@preserve a yv dscale dnoise dy dx begin
         check(ccall((:gp_logpdf_grad, libgpmi355), Int32,
             (Ptr{Cvoid}, Ref{CKernel}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{T}, Ref{Float64}, Ptr{Float64},
-                Ptr{Cvoid}, Ptr{Cvoid}),
-            fx.f.ctx.handle, a.ck, a.cx, a.cn, mptr, yv, lp, dvar, dscale, dnoise, dy))
+                Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+            fx.f.ctx.handle, a.ck, a.cx, a.cn, mptr, yv, lp, dvar, dscale, dnoise, dy, wrt_x ? pointer(dx) : C_NULL))
     end
-    return lp[], (variance=dvar[], scale=dscale[1:length(a.scales)], noise=a.cn.kind == 0 ? dnoise[1] : dnoise, y=dy, mean=-dy)
+    return lp[], (variance=dvar[], scale=dscale[1:length(a.scales)], noise=a.cn.kind == 0 ? dnoise[1] : dnoise, y=dy, mean=-dy,
+        x=wrt_x ? dx : nothing)
 end
 
 # ---- reverse-mode rule: Zygote / any ChainRules-based AD differentiates THROUGH the ccall -----------------------------------
@@ -225,7 +227,8 @@ end
 # from gp_logpdf_grad.  Tangents are structural, mirroring how `descriptor` walks the kernel:
 #   ScaledKernel.σ²  (1-vector)  <- ∂/∂variance · (total variance / σ²)      TransformedKernel.transform.s / .v  <- ∂/∂scale
 #   ConstMean.c <- Σ_i α_i        FiniteGP.Σy (Diagonal{Fill} value / Diagonal diag) <- ∂/∂σ² / ½(α_i² − C⁻¹_ii)        y <- −α
-# Inputs x (deep-kernel style models) and CustomMean parameters are not differentiated here (@not_implemented).
+#   x (Vector / ColVecs.X / RowVecs.X) <- ∂/∂x, the input gradient a deep-kernel model back-propagates into its feature map
+# CustomMean parameters are not differentiated here (@not_implemented); the prior mean is taken as constant in x.
 kernel_tangent(k, dvar, variance, dscale) = NoTangent()
 function kernel_tangent(k::ScaledKernel, dvar, variance, dscale)
     σ² = only(k.σ²)
@@ -242,6 +245,9 @@ end
 mean_tangent(::ZeroMean, dm) = NoTangent()
 mean_tangent(m::ConstMean, dm) = Tangent{typeof(m)}(; c=sum(dm))
 mean_tangent(m, dm) = ChainRulesCore.@not_implemented("HipGPs: gradients w.r.t. CustomMean parameters go through the stock path")
+input_tangent(x::AbstractVector{<:Real}, dx, Δ) = Δ .* dx
+input_tangent(x::ColVecs, dx, Δ) = Tangent{typeof(x)}(; X=Δ .* dx)
+input_tangent(x::RowVecs, dx, Δ) = Tangent{typeof(x)}(; X=Δ .* dx)
 noise_tangent(Σ::Diagonal{<:Any,<:Fill}, dn) = Tangent{typeof(Σ)}(; diag=Tangent{typeof(Σ.diag)}(; value=dn))
 noise_tangent(Σ::Diagonal, dn) = Tangent{typeof(Σ)}(; diag=dn)
 
@@ -262,8 +268,7 @@ function ChainRulesCore.rrule(config::RuleConfig{>:HasReverseMode}, ::typeof(Dis
         dk = kernel_tangent(gp.kernel, Δr * g.variance, desc[2], Δr .* g.scale)
         dgp = Tangent{typeof(gp)}(; mean=mean_tangent(gp.mean, Δr .* g.mean), kernel=dk)
         df = Tangent{typeof(fx.f)}(; gp=dgp, ctx=NoTangent())
-        dfx = Tangent{typeof(fx)}(; f=df, x=ChainRulesCore.@not_implemented("HipGPs: no gradient w.r.t. the inputs x"),
-            Σy=noise_tangent(fx.Σy, Δr .* g.noise))
+        dfx = Tangent{typeof(fx)}(; f=df, x=input_tangent(fx.x, g.x, Δr), Σy=noise_tangent(fx.Σy, Δr .* g.noise))
         return NoTangent(), dfx, Δr .* g.y
     end
     return lp, logpdf_hip_pullback

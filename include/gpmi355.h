@@ -173,10 +173,12 @@ int32_t gp_posterior_rand(gp_post* post, const gp_points* xs, const void* prior_
  *   dvariance_out  double[1]        ∂/∂(kernel variance)
  *   dscale_out     double[nscale]   ∂/∂scale (ScaleTransform s, or ARDTransform v_p; D <= 16)
  *   dnoise_out     noise.kind 0: 1 entry ∂/∂σ² = ½(αᵀα − tr C⁻¹);  kind 1: n entries ½(α_i² − C⁻¹_ii)
- *   dy_out         n entries ∂/∂y = −α   (∂/∂m = +α for a mean vector m) */
+ *   dy_out         n entries ∂/∂y = −α   (∂/∂m = +α for a mean vector m)
+ *   dx_out         n×d entries ∂/∂x in the container layout of x (what a deep-kernel model back-propagates into its feature
+ *                  map, examples/2-deep-kernel-learning/script.jl); the prior mean is taken as constant in x */
 int32_t gp_logpdf_grad(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null,
                        const void* y, void* logpdf_out, double* dvariance_out, double* dscale_out, void* dnoise_out,
-                       void* dy_out);
+                       void* dy_out, void* dx_out);
 
 /* Sequential conditioning, posterior(fx::FiniteGP{<:PosteriorGP}, y) (src/exact_gpr_posterior.jl:46-56): the resident
  * factor of `old` is extended by the bordered-Cholesky step update_chol (src/util/common_covmat_ops.jl:38-42):
@@ -283,6 +285,8 @@ int32_t gpd_gemm_time(gp_ctx* ctx, double* ms_out, int64_t* launches_out);
 int32_t gp_probe_mfma_f64(gp_ctx* ctx, const double* a_host, const double* b_host, double* d_host);
 /* measured TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on all CUs (the roofline's measured ceiling). */
 int32_t gp_bench_mfma_f64(gp_ctx* ctx, int32_t iters, double* tflops_out);
+/* the same for fp32: variant 0 = v_mfma_f32_16x16x4_f32, 1 = v_mfma_f32_32x32x2_f32 (the C5 roofline's measured ceiling). */
+int32_t gp_bench_mfma_f32(gp_ctx* ctx, int32_t variant, int32_t iters, double* tflops_out);
 
 #ifdef __cplusplus
 }

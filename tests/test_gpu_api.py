@@ -189,6 +189,41 @@ def test_vfe_append_pseudo_points(agp, dtype, m1, m2):
     np.testing.assert_allclose(p1.mean(agp.RowVecs(xs.astype(dtype))), o1.mean(xs), atol=tol)
 
 
+@pytest.mark.parametrize("kind,okind", [(0, o.SE), (1, o.MATERN12), (2, o.MATERN32), (3, o.MATERN52)])
+def test_logpdf_grad_wrt_inputs(agp, kind, okind):
+    """∂logpdf/∂x (gp_logpdf_grad dx_out) for every input container against the oracle's dense-calculus gradient (finite-
+    difference checked in tests/test_oracle.py) — what a deep-kernel model back-propagates into its feature map."""
+    rng = np.random.default_rng(70 + kind)
+    n, d = 333, 3
+    X = rng.standard_normal((n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    for scale, sig in [(None, 0.05), (0.8, 0.05), (np.array([0.5, 1.1, 0.9]), rng.uniform(0.03, 0.1, n))]:
+        kern = 1.4 * agp.Kernel(kind)
+        if scale is not None:
+            kern = kern @ (agp.ScaleTransform(scale) if np.ndim(scale) == 0 else agp.ARDTransform(scale))
+        f = agp.GP(0.2, kern)
+        go = o.logpdf_grad(o.FiniteGP(o.GP(o.Kernel(okind, 1.4, scale), 0.2), X, sig), y)
+        tol = 1e-8 * max(1.0, np.abs(go["x"]).max())
+        lp, g = agp.logpdf_and_grad(f(agp.RowVecs(X), sig), y, wrt_x=True)
+        assert g["x"].shape == (n, d)
+        np.testing.assert_allclose(g["x"], go["x"], rtol=1e-7, atol=tol)
+        np.testing.assert_allclose(g["scale"] if scale is not None else 0.0, go["scale"] if scale is not None else 0.0, rtol=1e-7)
+        _, gc = agp.logpdf_and_grad(f(agp.ColVecs(X.T.copy()), sig), y, wrt_x=True)
+        assert gc["x"].shape == (d, n)
+        np.testing.assert_allclose(gc["x"].T, go["x"], rtol=1e-7, atol=tol)
+    # Vector{T} inputs (D = 1) and Float32
+    x1 = rng.standard_normal(200)
+    y1 = np.sin(2 * x1) + 0.1 * rng.standard_normal(200)
+    f1 = agp.GP(agp.Kernel(kind) @ agp.ScaleTransform(1.3))
+    g1o = o.logpdf_grad(o.FiniteGP(o.GP(o.Kernel(okind, 1.0, 1.3)), x1, 0.1), y1)
+    _, g1 = agp.logpdf_and_grad(f1(x1, 0.1), y1, wrt_x=True)
+    assert g1["x"].shape == (200,)
+    np.testing.assert_allclose(g1["x"], g1o["x"], rtol=1e-7, atol=1e-8 * max(1.0, np.abs(g1o["x"]).max()))
+    _, g32 = agp.logpdf_and_grad(f1(x1.astype(np.float32), np.float32(0.1)), y1.astype(np.float32), wrt_x=True)
+    assert g32["x"].dtype == np.float32
+    np.testing.assert_allclose(g32["x"], g1o["x"], rtol=2e-2, atol=2e-2 * max(1.0, np.abs(g1o["x"]).max()))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Conformance suites of the reference (src/util/TestUtils.jl), mirrored on the Python API.  `marginals` returns (mean, std)
 # arrays instead of Normal objects; "isa AbstractVector{<:Real}" becomes a 1-D floating ndarray of the input eltype.

@@ -181,3 +181,9 @@ def test_logpdf_grad_matches_finite_differences():
             e0 = np.zeros(n)
             e0[5] = h
             assert g["y"][5] == pytest.approx((lp(yy=y + e0) - lp(yy=y - e0)) / (2 * h), rel=1e-6, abs=1e-6)
+            for i, p in [(0, 0), (7, 2), (n - 1, 1)]:  # ∂/∂x (deep-kernel style input gradients)
+                E = np.zeros_like(X)
+                E[i, p] = h
+                fd = (float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(**base), 0.2), X + E, sig), y))
+                      - float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(**base), 0.2), X - E, sig), y))) / (2 * h)
+                assert g["x"][i, p] == pytest.approx(fd, rel=1e-6, abs=1e-6)

@@ -53,12 +53,16 @@ def vfe(params, n=262144, m=4096, d=3, reps=2):
     best = None
     for _ in range(reps + 1):
         t0 = time.perf_counter()
-        post = agp.posterior(approx, fx, y)
+        try:
+            post = agp.posterior(approx, fx, y)
+            obj = float(post.objective)
+            del post
+        except agp.PosDefException:  # ablation builds compute garbage: the time is still the time
+            obj = float("nan")
         dt = time.perf_counter() - t0
         tm = ctx.timings()
         if _ > 0 and (best is None or dt < best[0]):
-            best = (dt, tm, float(post.objective))
-        del post
+            best = (dt, tm, obj)
     dt, tm, obj = best
     flops = 2.0 * n * m * m + 2.0 * m**3 / 3
     print(json.dumps({"config": "C5", "params": params, "fit_ms": round(dt * 1e3, 3), "fit_tflops_fp32": round(flops / dt / 1e12, 2),
