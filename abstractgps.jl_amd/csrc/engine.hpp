@@ -90,6 +90,7 @@ struct gp_ctx {
     int gemm_ring3 = 0;    // three-stage operand ring (gemm_nt_dma3_kernel): 0 off, 1 fp32 launches, 2 all
     bool gemm_ring3_set = false;
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
+    int vfe_overlap = 1;   // VFE: kmat / ystats / partial-sum adds on the second stream beside the chunk GEMMs (double buffers)
     int vfe_sk = 0;        // VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))
     int gemm_wide = 0;     // 256×128-tile, 3-stage, one-workgroup-per-CU GEMM (gemm_nt_wide_kernel): 0 off, 1 large launches, 2 wherever legal
     long gemm_wide_min = 256;  // gemm_wide = 1: launches of at least this many 256×128 tiles
@@ -103,7 +104,7 @@ struct gp_ctx {
     std::unordered_map<void*, size_t> blk;     // true size of every block handed out by ctx_alloc
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)96 << 30;        // bytes kept in the cache at most ("pool_cap_mb"; gp_ctx_trim drops it all)
-    long vfe_chunk = 8192;                     // data points per streamed VFE chunk (multiple of 2048)
+    long vfe_chunk = 16384;                    // data points per streamed VFE chunk (multiple of vfe_ks; 16 384 measured best at C5)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct GemmRec {

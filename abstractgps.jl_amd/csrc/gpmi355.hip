@@ -1410,6 +1410,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "gemm_ring3")) c->gemm_ring3 = (int)v;
     else if (!strcmp(name, "vfe_ks")) c->vfe_ks = std::max<int64_t>(512, round_up(v, 512));
     else if (!strcmp(name, "vfe_sk")) c->vfe_sk = v != 0;
+    else if (!strcmp(name, "vfe_overlap")) c->vfe_overlap = v != 0;
     else if (!strcmp(name, "gemm_wide")) c->gemm_wide = (int)v;
     else if (!strcmp(name, "gemm_wide_min")) c->gemm_wide_min = std::max<int64_t>(1, v);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));

@@ -143,7 +143,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     const size_t Y_b = sizeof(T) * (size_t)(mp + 128) * ldy, Li_b = sizeof(T) * (size_t)(mp + 128) * ld;
     const size_t vT_b = sizeof(double) * (size_t)mp, vD_b = sizeof(double) * (size_t)mp * 4, jit_b = sizeof(double) * (size_t)mp;
     void *zsT_v = 0, *zsD_v = 0, *D_v = 0, *X_v = 0, *Lz_v = 0, *Ld_v = 0, *cT_v = 0, *rss_v = 0, *vec_v = 0, *jit_v = 0, *Y_v = 0,
-         *Li_v = 0, *I_v = 0, *S_v = 0, *zn_v = 0, *znD_v = 0;
+         *Li_v = 0, *I_v = 0, *S_v = 0, *zn_v = 0, *znD_v = 0, *X2_v = 0, *Y2_v = 0, *S2_v = 0;
     DevBufs bufs(c);
     std::shared_ptr<ObsSeg> seg;
     if (x) {
@@ -165,6 +165,11 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(bufs.get(Li_b, &Li_v));
     if (mode != VFE_UPDATE) RC(bufs.get(L_b, &I_v));
     if (!is_f64) RC(bufs.get((size_t)NBAT * Li_b, &S_v));
+    if (c->vfe_overlap) {  // second set of chunk buffers for the overlapped helpers
+        RC(bufs.get(X_b, &X2_v));
+        RC(bufs.get(Y_b, &Y2_v));
+        if (!is_f64) RC(bufs.get((size_t)NBAT * Li_b, &S2_v));
+    }
     RC(bufs.get(vT_b, &cT_v));
     RC(bufs.get(vT_b, &rss_v));
     RC(bufs.get(vD_b, &vec_v));
@@ -188,42 +193,98 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     // accumulators continue), the block rows from the first new pseudo-point's 128-tile on for an append
     const long row_lo = (mode == VFE_APPEND) ? (m_old / 128) * 128 : 0;
 
-    // one chunk loop over a batch of observations: rows >= row_lo of D_acc, c_acc, rowss
-    auto stream_seg = [&](const ObsSeg& sg) -> int32_t {
+    // One chunk loop over a batch of observations: rows >= row_lo of D_acc, c_acc, rowss.  The two MFMA GEMMs of a chunk run
+    // back to back on the main stream; the bandwidth-bound helpers run on the ctx's second stream beside them, on double
+    // buffers: kmat of chunk c+1 and the partial-sum adds of chunk c overlap the GEMMs of their neighbours ("vfe_overlap").
+    hipStream_t sa = c->vfe_overlap ? c->sp : s;
+    const bool ovl = sa != s;
+    void* Xb[2] = {X_v, X2_v};
+    void* Yb[2] = {Y_v, Y2_v};
+    void* Sb[2] = {S_v, S2_v};
+    hipEvent_t evK[2] = {nullptr, nullptr}, evYs[2] = {nullptr, nullptr}, evAdd[2] = {nullptr, nullptr};
+    long cidx = 0;
+    auto kmat_chunk = [&](const ObsSeg& sg, long c0, int bb) -> int32_t {
+        GridMap g = plain_map(0, c0, 0);
+        dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
+        hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, sa, (T*)Xb[bb], ld, (const T*)sg.xs, sg.npad, (const T*)zsT_v, mp, d,
+                           k->kind, (T)k->variance, (const T*)nullptr, sg.n, m, 0, g, (const T*)nullptr, (const T*)sg.rs);
+        HIPCHK(hipGetLastError());
+        if (ovl) {
+            RC(ctx_event(c, &evK[bb], false));
+            HIPCHK(hipEventRecord(evK[bb], sa));
+        }
+        return 0;
+    };
+    auto stream_seg = [&](const ObsSeg& sg, const ObsSeg* next_sg) -> int32_t {
         for (long c0 = 0; c0 < sg.npad; c0 += CH) {
             if (c0 >= sg.n) break;  // nothing but padding in the remaining chunks
-            GridMap g = plain_map(0, c0, 0);
-            dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
-            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, (T*)X_v, ld, (const T*)sg.xs, sg.npad, (const T*)zsT_v, mp, d,
-                               k->kind, (T)k->variance, (const T*)nullptr, sg.n, m, 0, g, (const T*)nullptr, (const T*)sg.rs);
-            HIPCHK(hipGetLastError());
+            const int bb = ovl ? (int)(cidx & 1) : 0;
+            if (!ovl || cidx == 0) RC(kmat_chunk(sg, c0, bb));  // (overlapped mode: later chunks were prefetched below)
+            if (ovl) {
+                HIPCHK(hipStreamWaitEvent(s, evK[bb], 0));
+                if (evYs[bb]) HIPCHK(hipStreamWaitEvent(s, evYs[bb], 0));  // chunk cidx−2 is done with Y[bb]
+            }
             {
                 GridMap gy = plain_map(0, 0, 0);
                 gy.beta0 = 1;
                 gy.ktri = 1;
-                RC(launch_gemm<T>(c, s, (T*)Y_v, ldy, (const T*)Li_v, ld, (const T*)X_v, ld, mp, CH, mp, gy));   // Y = −B_c
+                RC(launch_gemm<T>(c, s, (T*)Yb[bb], ldy, (const T*)Li_v, ld, (const T*)Xb[bb], ld, mp, CH, mp, gy));   // Y = −B_c
             }
-            hipLaunchKernelGGL(ystats_kernel<T>, dim3((unsigned)(mp - row_lo)), dim3(256), 0, s, (const T*)Y_v, ldy, CH,
+            if (ovl) {
+                hipEvent_t e;
+                RC(ctx_event(c, &e, false));
+                HIPCHK(hipEventRecord(e, s));
+                HIPCHK(hipStreamWaitEvent(sa, e, 0));
+            }
+            hipLaunchKernelGGL(ystats_kernel<T>, dim3((unsigned)(mp - row_lo)), dim3(256), 0, sa, (const T*)Yb[bb], ldy, CH,
                                (const T*)sg.b + c0, row_lo, (double*)cT_v, (double*)rss_v);   // c += B_c b_c ; ‖B‖² rows (fp64)
             HIPCHK(hipGetLastError());
-            const T* Yr = (const T*)Y_v + row_lo * ldy;
+            if (ovl) {
+                RC(ctx_event(c, &evYs[bb], false));
+                HIPCHK(hipEventRecord(evYs[bb], sa));
+                // prefetch the next chunk's S·K(x_c, z) into the other X buffer (its last reader, the previous Y GEMM, is done)
+                const long c1 = c0 + CH;
+                if (c1 < sg.npad && c1 < sg.n) RC(kmat_chunk(sg, c1, bb ^ 1));
+                else if (next_sg) RC(kmat_chunk(*next_sg, 0, bb ^ 1));
+            }
+            const T* Yr = (const T*)Yb[bb] + row_lo * ldy;
             if constexpr (is_f64) {
-                RC((launch_gemm<T, double>(c, s, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Y_v, ldy, mp - row_lo, mp, CH,
+                RC((launch_gemm<T, double>(c, s, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, CH,
                                            plain_map(1, row_lo, 0))));
             } else {
-                // fp32: the chunk's SYRK runs on the LDS-DMA kernel into fp32 scratch — NBAT partial products over K = 2 048 data
-                // points each in ONE launch (blockIdx.z) — which one pass then adds into the fp64 accumulator: fp64 sums across
+                // fp32: the chunk's SYRK runs on the LDS-DMA kernel into fp32 scratch — NBAT partial products over KS data points
+                // each in ONE launch (blockIdx.z) — which one pass then adds into the fp64 accumulator: fp64 sums across
                 // partials and chunks, fp32 MFMA within a partial
                 GridMap gs = plain_map(1, row_lo, 0);
                 gs.beta0 = 1;
                 gs.nbatch = NBAT;
                 gs.cstride = (long)(mp + 128) * ld;
-                RC(launch_gemm<T>(c, s, (T*)S_v + row_lo * ld, ld, Yr, ldy, (const T*)Y_v, ldy, mp - row_lo, mp, KS, gs));
+                if (ovl && evAdd[bb]) HIPCHK(hipStreamWaitEvent(s, evAdd[bb], 0));  // chunk cidx−2's partials have been added
+                RC(launch_gemm<T>(c, s, (T*)Sb[bb] + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, KS, gs));
+                if (ovl) {
+                    hipEvent_t e;
+                    RC(ctx_event(c, &e, false));
+                    HIPCHK(hipEventRecord(e, s));
+                    HIPCHK(hipStreamWaitEvent(sa, e, 0));
+                }
                 hipLaunchKernelGGL(add_lower_batched_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(mp - row_lo)), dim3(256),
-                                   0, s, (const T*)S_v, gs.cstride, NBAT, ld, (double*)D_v, ld, mp, row_lo);
+                                   0, sa, (const T*)Sb[bb], gs.cstride, NBAT, ld, (double*)D_v, ld, mp, row_lo);
                 HIPCHK(hipGetLastError());
+                if (ovl) {
+                    RC(ctx_event(c, &evAdd[bb], false));
+                    HIPCHK(hipEventRecord(evAdd[bb], sa));
+                }
             }
+            ++cidx;
         }
+        return 0;
+    };
+    auto stream_join = [&]() -> int32_t {  // everything the helpers accumulated is visible to the main stream
+        if (!ovl) return 0;
+        hipEvent_t e;
+        RC(ctx_event(c, &e, false));
+        HIPCHK(hipEventRecord(e, sa));
+        HIPCHK(hipStreamWaitEvent(s, e, 0));
         return 0;
     };
 
@@ -325,11 +386,19 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         }
         HIPCHK(hipEventRecord(c->ev_phase[1], s));
         // ---- streamed pass over the data points                                                   :64-71
-        if (mode == VFE_APPEND) {
-            for (auto& sg : prev->segs) RC(stream_seg(*sg));
-        } else {
-            RC(stream_seg(*seg));
+        if (ovl) {  // the helper stream starts after the M×M prelude and the uploads
+            hipEvent_t e;
+            RC(ctx_event(c, &e, false));
+            HIPCHK(hipEventRecord(e, s));
+            HIPCHK(hipStreamWaitEvent(sa, e, 0));
         }
+        if (mode == VFE_APPEND) {
+            for (size_t si = 0; si < prev->segs.size(); ++si)
+                RC(stream_seg(*prev->segs[si], si + 1 < prev->segs.size() ? prev->segs[si + 1].get() : nullptr));
+        } else {
+            RC(stream_seg(*seg, nullptr));
+        }
+        RC(stream_join());
         hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s,
                            (const double*)cT_v, vec, mp, 1.0);                                                              // c = B b_y
         HIPCHK(hipGetLastError());

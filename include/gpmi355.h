@@ -119,7 +119,11 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one
  *                    large launch, 4-7 % slower over a whole factorisation; fp32: 5 % faster)   default 0 (fp64) / 20480 (fp32)
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32
- *   "vfe_chunk"      data points per streamed VFE chunk (multiple of 2048)                default 8192
+ *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
+ *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
+ *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
+ *   "gemm_ring3"     three-stage operand ring GEMM (1 fp32 launches, 2 all; measured slower)   default 0
+ *   "gemm_wide"      256×128-tile one-wave-per-SIMD GEMM (1 large launches, 2 all; measured slower)   default 0
  *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Return every cached (free) device block of the ctx to the HIP allocator — e.g. after freeing an N = 65 536 posterior
