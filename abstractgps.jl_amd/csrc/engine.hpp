@@ -75,8 +75,10 @@ struct gp_ctx {
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
     int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
     int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
-    int gemm_streamk = 0;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel): measured
-                           // no gain at N = 16 384 and −3 % at N = 65 536 against hardware workgroup dispatch, kept as an option
+    long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)
+    long leaf_group = 128; // columns factored left-looking by consecutive leaves (64 = every leaf followed by its own GEMM)
+    int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at
+                           // most sk_max_tiles tiles: the few-tile in-panel GEMMs are cut along k over all CUs (−2…5 % at N <= 32 768)
     int num_cus = 256;
     long sk_max_tiles = 4096;  // stream-K only for launches of at most this many tiles (8 rounds): the persistent kernel is
                            // ~5 % slower than hardware dispatch on large launches, where the tail does not matter anyway

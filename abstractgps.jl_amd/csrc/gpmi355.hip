@@ -313,23 +313,34 @@ static long split_half(long n) {  // largest multiple of 64 that is <= n/2 (>= 6
     return h < 64 ? 64 : h;
 }
 
+// one fused 64-column leaf (panel64_kernel): tile Cholesky (replicated per workgroup) + X L⁻ᵀ of all rows below, after the
+// in-leaf update by the kpre column tiles to its left
+template <typename T>
+static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long mtot, int* info_dev, long gcol0, long n_valid,
+                           double* logdet_dev, int kpre) {
+    const long mrows = mtot - j0 - 64;
+    const unsigned nblk = (unsigned)std::max(1L, (mrows + 127) / 128);
+    if (!c->ticket_dev) {
+        HIPCHK(hipMalloc((void**)&c->ticket_dev, sizeof(int) * 64));
+        // null-stream memsets are not ordered against the (non-blocking) ctx streams: zero it and wait
+        HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    hipLaunchKernelGGL(panel64_kernel<T>, dim3(nblk), dim3(256), 0, s, A + j0 * lda + j0, lda, (int)mrows, info_dev,
+                       (int)(gcol0 + j0), (int)n_valid, logdet_dev, c->ticket_dev + (s == c->sp ? 32 : 0), kpre);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // Factor columns [j0, j0+n) of the row-major matrix A (n multiple of 64) including all rows below
 // (rows [j0, mtot)).  Recursive: left half, MFMA update of the right half, right half.
 template <typename T>
 static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long n, long mtot, int* info_dev,
                          long gcol0, long n_valid, double* logdet_dev) {
-    if (n <= 64 && c->panel_fused) {  // one launch: tile Cholesky (replicated per workgroup) + X L⁻ᵀ of all rows below
-        const long mrows = mtot - j0 - 64;
-        const unsigned nblk = (unsigned)std::max(1L, (mrows + 127) / 128);
-        if (!c->ticket_dev) {
-            HIPCHK(hipMalloc((void**)&c->ticket_dev, sizeof(int) * 64));
-            // null-stream memsets are not ordered against the (non-blocking) ctx streams: zero it and wait
-            HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
-            HIPCHK(hipDeviceSynchronize());
-        }
-        hipLaunchKernelGGL(panel64_kernel<T>, dim3(nblk), dim3(256), 0, s, A + j0 * lda + j0, lda, (int)mrows, info_dev,
-                           (int)(gcol0 + j0), (int)n_valid, logdet_dev, c->ticket_dev + (s == c->sp ? 32 : 0));
-        HIPCHK(hipGetLastError());
+    if (n <= 64 && c->panel_fused) return launch_leaf<T>(c, s, A, lda, j0, mtot, info_dev, gcol0, n_valid, logdet_dev, 0);
+    if (c->panel_fused && n <= c->leaf_group) {  // left-looking group: leaf t first applies the t tiles to its left itself
+        for (long t = 0; t < n / 64; ++t)
+            RC(launch_leaf<T>(c, s, A, lda, j0 + 64 * t, mtot, info_dev, gcol0, n_valid, logdet_dev, (int)t));
         return 0;
     }
     if (n <= 64) {
@@ -544,7 +555,7 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
 // Vector solves with the resident factor: R rows hold nrhs right-hand sides of length np.
 template <typename T>
 static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* R, long ldr, int nrhs, bool fwd) {
-    const int NBV = 1024;
+    const int NBV = (int)c->trsv_nb;
     const size_t smem = sizeof(T) * (NBV + 64 * 65 + 16 * 64);
     const long nblk = (np + NBV - 1) / NBV;
     T* W = nullptr;
@@ -1404,6 +1415,8 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     }
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
+    else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
+    else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);

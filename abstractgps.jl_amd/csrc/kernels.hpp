@@ -1443,10 +1443,15 @@ __global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long ld
 //   other operation is a 16×16×16 product P·Qᵀ on the fp64/fp32 MFMA with both operands read row-wise from LDS:
 //     block TRSM   B_ij ← B_ij · Inv_jᵀ          (tile rows below the block and the workgroup's X rows)
 //     block update B_ik ← B_ik − B_ij · B_kjᵀ     (k > j)
+//   Left-looking entry (kpre > 0): the kpre 64-column tiles immediately LEFT of this leaf (same rows, already final) are
+//   applied first —  [D; X] ← [D; X] − [L_k; X_k] · L_kᵀ,  k = 0..kpre−1  — as 16×16×16 MFMA products accumulated in
+//   registers, operands staged through the same two LDS buffers.  That replaces the K = 64 / 128 trailing GEMMs between
+//   the leaves of a 256-column group (three launches of a latency-bound kernel per group) by ≈3 µs of in-leaf work each.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int XR = 128>  // XR: rows of X per workgroup (128; 64 keeps the LDS footprint at 75 KB)
 __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
-                                                       int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket) {
+                                                       int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket,
+                                                       int kpre) {
     using TR = Tr<T>;
     using chunk_t = typename TR::chunk_t;
     using acc_t = typename TR::acc_t;
@@ -1470,6 +1475,79 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     int xrows = mrows - (int)blockIdx.x * XR;
     xrows = xrows < 0 ? 0 : (xrows > XR ? XR : xrows);
     T* const Xg = A + (long)(64 + (long)blockIdx.x * XR) * lda;
+
+    // ---- left-looking pre-update: wave w owns column block w of every 16-row tile (X: XR/16 tiles, D: 4 tiles)
+    constexpr int NXT = XR / 16;
+    acc_t dxp[NXT], ddp[4];
+    if (kpre > 0) {
+        constexpr int CPR = 64 / VEC;
+        constexpr int ND = 64 * CPR / 256, NX = XR * CPR / 256;
+#pragma unroll
+        for (int i = 0; i < NXT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxp[i][r] = T(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ddp[i][r] = T(0);
+        const int nxtp = (xrows + 15) >> 4;
+        for (int k = 0; k < kpre; ++k) {
+            const long coff = -64L * (kpre - k);
+            chunk_t dv[ND], xv[NX];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+                dv[i] = *reinterpret_cast<const chunk_t*>(A + (long)row * lda + coff + cc * VEC);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) xv[i][q] = T(0);
+                if (row < xrows) xv[i] = *reinterpret_cast<const chunk_t*>(Xg + (long)row * lda + coff + cc * VEC);
+            }
+            if (k > 0) __syncthreads();  // the previous tile's fragments have been read
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) Ds[row * LD + cc * VEC + q] = dv[i][q];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int e = tid + 256 * i, row = e / CPR, cc = e % CPR;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) Xs[row * LD + cc * VEC + q] = xv[i][q];
+            }
+            __syncthreads();
+            T qf[16];  // Q fragments of block row w of L_k: shared by every product of this wave
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) qf[4 * kb + m] = Ds[(16 * w + li) * LD + 16 * kb + 4 * m + lg];
+#pragma unroll
+            for (int i = 0; i < NXT; ++i) {
+                if (i < nxtp) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            dxp[i] = TR::mfma(-Xs[(16 * i + li) * LD + 16 * kb + 4 * m + lg], qf[4 * kb + m], dxp[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i >= w) {  // lower block triangle of D only
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            ddp[i] = TR::mfma(-Ds[(16 * i + li) * LD + 16 * kb + 4 * m + lg], qf[4 * kb + m], ddp[i]);
+                }
+            }
+        }
+        __syncthreads();  // LDS buffers are free again
+    }
 
     {  // all global loads of the tile and of the X slab are issued before the first LDS store (one memory round trip)
         constexpr int CPR = 64 / VEC;              // 16-B chunks per 64-column row
@@ -1503,6 +1581,19 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     __syncthreads();  // every load of the input tile by this workgroup has completed (values are in LDS)
     PSTAMP();
     if (tid == 0) writer_s = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    if (kpre > 0) {  // fold the pre-update in (each 16×16 block is owned by exactly one wave)
+#pragma unroll
+        for (int i = 0; i < NXT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(16 * i + TR::crow(lane, r)) * LD + 16 * w + li] += dxp[i][r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i >= w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ds[(16 * i + TR::crow(lane, r)) * LD + 16 * w + li] += ddp[i][r];
+            }
+        __syncthreads();
+    }
 
     int bad = 0;
     T mydiag[4] = {T(1), T(1), T(1), T(1)};  // L_cc of column 16j + li (lanes < 16 of wave 0); log() is taken once, by the writer
@@ -1916,12 +2007,26 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
     for (int s = 0; s < nrhs; ++s) {
         T* r = R + (long)s * ldr + b0;
         for (int i = tid; i < nbv; i += 1024) rv[i] = r[i];
+        T wreg[4];  // this thread's share of the NEXT step's W tile: its load is in flight during the current step
+        {
+            const T* W0 = W + ((b0 >> 6) + (FWD ? 0 : ns - 1)) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wreg[i] = W0[tid + 1024 * i];
+        }
         __syncthreads();
         for (int ss = 0; ss < ns; ++ss) {
             const int sb = FWD ? ss : (ns - 1 - ss);
             const int s0 = sb * 64;
-            const T* Wt = W + ((b0 >> 6) + sb) * 4096;
-            for (int e = tid; e < 64 * 64; e += 1024) Ws[(e >> 6) * 65 + (e & 63)] = Wt[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + 1024 * i;
+                Ws[(e >> 6) * 65 + (e & 63)] = wreg[i];
+            }
+            if (ss + 1 < ns) {
+                const T* Wn = W + ((b0 >> 6) + (FWD ? sb + 1 : sb - 1)) * 4096;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wreg[i] = Wn[tid + 1024 * i];
+            }
             __syncthreads();
             {
                 T acc = 0;

@@ -681,7 +681,10 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
         rk.r = r; rk.p = r / Q; rk.q = r % Q; rk.device = devices[r];
         rc = gp_ctx_create(&rk.c, devices[r], nullptr);
         if (rc != 0) break;
-        if (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&rk.sc, hipStreamNonBlocking) != hipSuccess) {
+        // comm stream: highest priority, so that a copy / RCCL kernel takes the next free CU slot ahead of the queued GEMM workgroups
+        int plo = 0, phi = 0;
+        if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess ||
+            hipStreamCreateWithPriority(&rk.sc, hipStreamNonBlocking, phi) != hipSuccess) {
             rc = set_err_text(-1997, "could not create the comm stream of a rank");
             break;
         }

@@ -115,7 +115,9 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "trsm_leaf_mfma" MFMA TRSM leaf (1) or VALU leaf (0)                                  default 1
  *   "trsm_mfma"      all-MFMA blocked TRSM through I − inv(L_jj) tiles                    default 0
  *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
- *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail (gemm_nt_sk_kernel)           default 0
+ *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail on launches of <= sk_max_tiles tiles   default 1
+ *   "leaf_group"     columns factored left-looking by consecutive fused leaves (64/128/256/512)   default 128
+ *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one
  *                    large launch, 4-7 % slower over a whole factorisation; fp32: 5 % faster)   default 0 (fp64) / 20480 (fp32)
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     auto chain = [&]() {
         for (int i = 0; i < NL; ++i)  // the same (already positive definite) tile again and again: timing only
             hipLaunchKernelGGL((panel64_kernel<double, XR>), dim3((unsigned)(M / XR)), dim3(256), 0, s2, P, ldp, (int)M, info, 0, 64, logdet,
-                               ticket);
+                               ticket, 0);
     };
     float ms;
     for (int rep = 0; rep < 2; ++rep) {

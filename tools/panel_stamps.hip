@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
         hipMemcpy(P, p.data(), sizeof(double) * p.size(), hipMemcpyHostToDevice);
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL((panel64_kernel<double, 128>), dim3((unsigned)((M + 127) / 128 > 0 ? (M + 127) / 128 : 1)), dim3(256), 0, 0, P, ldp,
-                           (int)M, info, 0, 64, logdet, ticket);
+                           (int)M, info, 0, 64, logdet, ticket, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
