@@ -51,6 +51,10 @@ def se_rows(xi: np.ndarray, x: np.ndarray) -> np.ndarray:
     return np.exp(-0.5 * d2)
 
 
+def gram_threads_default() -> int:
+    return min(32, os.cpu_count() or 1)
+
+
 def cpu_baseline(n_full: int, d: int):
     """Oracle (NumPy/SciPy -> OpenBLAS LAPACK, the routines Julia's cholesky reaches) timed on this box's host cores on a
     bounded sample of the same workload: the in-place fused pair (one Fortran-ordered N×N, dpotrf('U') in place — SURVEY.md
@@ -67,10 +71,11 @@ def cpu_baseline(n_full: int, d: int):
 
         pools = [{k: p.get(k) for k in ("user_api", "internal_api", "version", "num_threads", "threading_layer")}
                  for p in threadpool_info()]
-        cores = max([p.get("num_threads") or 1 for p in pools] + [1])
+        blas = [p.get("num_threads") or 1 for p in pools if p.get("user_api") == "blas"]  # dpotrf / dtrsv run on the BLAS pool
+        cores = max(blas + [gram_threads_default()]) if blas else max([p.get("num_threads") or 1 for p in pools] + [1])
     except Exception:
         pass
-    gram_threads = min(32, os.cpu_count() or 1)
+    gram_threads = gram_threads_default()
     x, y = synth_inputs(n_full, d, 4)
     f = o.GP(o.Kernel(o.SE))
     sizes = [nn for nn in (8192, 16384, 32768) if nn <= n_full]
@@ -303,7 +308,8 @@ def main():
                         "frac": pair_tf / peak, **(pmc_traffic(n) if not multi else {"traffic": None}),
                         "definition": "achieved = (N^3/3 + 3N^2) / wall time of one pair (SURVEY.md 8(d)), peak = 78.6 TF/s x n_gpus; "
                                       "kernel_* = the dominant kernel alone" + (" (rank 0's launches)" if multi else ""),
-                        "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands)",
+                        "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands; launches of <= 4096 tiles run its "
+                                  "persistent stream-K variant gemm_nt_sk_kernel — kernel_* and the per-launch averages cover both)",
                         "kernel_achieved": kernel_tflops, "kernel_frac": kernel_tflops / FP64_MFMA_PEAK_TFLOPS,
                         "kernel_timing": "separate untimed pass with time_kernels=1 (HIP events around each launch on its stream)",
                         "algorithmic_bytes_per_launch_avg": gemm_bytes / max(gemm_launches, 1),
