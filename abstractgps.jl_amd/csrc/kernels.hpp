@@ -1609,9 +1609,8 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
         }
         return d;
     };
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (w == 0) {  // 16×16 diagonal block: L16 and inv(L16)
+    // wave 0 only: factor the 16×16 diagonal block j (L16 into Ds, inv(L16) into Inv[j])
+    auto factor16 = [&](int j) {
 #if GPMI_POTF2_LDS
             // lane = row (factor) and lane = column (inverse); the finished column c is published in LDS (Lc[c][·]) and
             // every multiplier L[t][c] / L[c][k] is an LDS broadcast read — ~10 instructions per column instead of
@@ -1681,57 +1680,65 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
                 }
             }
 #endif
-        }
-        __syncthreads();
-        PSTAMP();
-        // block TRSM: tasks 0..2-j: tile blocks (j+1+q, j); then the X row tiles
-        {
-            const int ntile = 3 - j;
-            for (int q = w; q < ntile + nxt; q += 4) {
-                T* P = (q < ntile) ? &Ds[(16 * (j + 1 + q)) * LD + 16 * j] : &Xs[(16 * (q - ntile)) * LD + 16 * j];
-                acc_t d;
+    };
+    // one 16×16 task each: block TRSM  P ← P · Inv_jᵀ   and block update  C ← C − P · Qᵀ
+    auto trsm_blk = [&](T* P, int j) {
+        acc_t d;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = T(0);
-                d = mma16(d, P, LD, &Inv[j][0], LI, false);
+        for (int r = 0; r < 4; ++r) d[r] = T(0);
+        d = mma16(d, P, LD, &Inv[j][0], LI, false);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) P[TR::crow(lane, r) * LD + li] = d[r];
-            }
-        }
-        __syncthreads();
-        PSTAMP();
-        // block updates: tile pairs (i, k), j < k <= i <= 3, then (X row tile, k), k = j+1..3
+        for (int r = 0; r < 4; ++r) P[TR::crow(lane, r) * LD + li] = d[r];
+    };
+    auto upd_blk = [&](T* Cb, const T* P, const T* Q) {
+        acc_t d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = Cb[TR::crow(lane, r) * LD + li];
+        d = mma16(d, P, LD, Q, LD, true);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cb[TR::crow(lane, r) * LD + li] = d[r];
+    };
+    // Schedule per 16-column block j (three barriers, as before), with the X-row products of block j running in the shadow of
+    // the factorisation of block j+1 — the 16×16 factorisation is a serial chain on ONE wave (≈2.7 µs) and used to idle the
+    // other three:
+    //   1. tile TRSM      D(k, j) ← D(k, j) Inv_jᵀ,  k > j              (≤ 3 tasks, one per wave)
+    //   2. tile updates   D(i, k) −= D(i, j) D(k, j)ᵀ,  j < k ≤ i        (≤ 6 tasks)
+    //   3. wave 0: factor block j+1   ∥   waves 1–3: for each of their X row tiles  X(·, j) ← X(·, j) Inv_jᵀ  and then
+    //      X(·, k) −= X(·, j) D(k, j)ᵀ, k > j  (row-tile local: no barrier between the two)
+    if (w == 0) factor16(0);
+    __syncthreads();
+    PSTAMP();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
         if (j < 3) {
-            const int nk = 3 - j;
-            const int npair = nk * (nk + 1) / 2;
-            for (int q = w; q < npair + nxt * nk; q += 4) {
-                T* Cb;
-                const T* P;
-                const T* Q;
-                if (q < npair) {
-                    int i = 0, rem = q;  // enumerate (i, k): i = j+1..3, k = j+1..i
-                    while (rem > i) {
-                        rem -= i + 1;
-                        ++i;
-                    }
-                    const int bi = j + 1 + i, bk = j + 1 + rem;
-                    Cb = &Ds[(16 * bi) * LD + 16 * bk];
-                    P = &Ds[(16 * bi) * LD + 16 * j];
-                    Q = &Ds[(16 * bk) * LD + 16 * j];
-                } else {
-                    const int qq = q - npair, rt = qq / nk, bk = j + 1 + qq % nk;
-                    Cb = &Xs[(16 * rt) * LD + 16 * bk];
-                    P = &Xs[(16 * rt) * LD + 16 * j];
-                    Q = &Ds[(16 * bk) * LD + 16 * j];
+            if (w < 3 - j) trsm_blk(&Ds[(16 * (j + 1 + w)) * LD + 16 * j], j);
+            __syncthreads();
+            const int nk = 3 - j, npair = nk * (nk + 1) / 2;
+            for (int q = w; q < npair; q += 4) {
+                int i = 0, rem = q;  // enumerate (i, k): i = j+1..3, k = j+1..i
+                while (rem > i) {
+                    rem -= i + 1;
+                    ++i;
                 }
-                acc_t d;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = Cb[TR::crow(lane, r) * LD + li];
-                d = mma16(d, P, LD, Q, LD, true);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Cb[TR::crow(lane, r) * LD + li] = d[r];
+                const int bi = j + 1 + i, bk = j + 1 + rem;
+                upd_blk(&Ds[(16 * bi) * LD + 16 * bk], &Ds[(16 * bi) * LD + 16 * j], &Ds[(16 * bk) * LD + 16 * j]);
             }
             __syncthreads();
+            PSTAMP();
         }
+        if (j < 3 && w == 0) {
+            factor16(j + 1);
+        } else {
+            const int nw = (j < 3) ? 3 : 4, w0 = (j < 3) ? w - 1 : w;
+            for (int rt = w0; rt < nxt; rt += nw) {
+                T* const Xr = &Xs[(16 * rt) * LD];
+                trsm_blk(Xr + 16 * j, j);
+#pragma unroll
+                for (int k = j + 1; k < 4; ++k) upd_blk(Xr + 16 * k, Xr + 16 * j, &Ds[(16 * k) * LD + 16 * j]);
+            }
+        }
+        __syncthreads();
+        PSTAMP();
     }
 
     PSTAMP();
