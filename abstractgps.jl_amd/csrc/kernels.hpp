@@ -20,7 +20,8 @@
 #define GPMI_GEMM_SCHED 1  // explicit MFMA / LDS interleave of the gemm k loop (sched_group_barrier)
 #endif
 #ifndef GPMI_POTF2_LDS
-#define GPMI_POTF2_LDS 1  // panel64: multipliers of the 16×16 block factorisation by LDS broadcast (0: v_readlane)
+#define GPMI_POTF2_LDS 2  // panel64, 16×16 block factorisation: 2 = four-column blocks (readlanes inside a block, one LDS publish per
+                          // block), 1 = one LDS publish per column, 0 = v_readlane only
 #endif
 #ifndef GPMI_ABL
 #define GPMI_ABL 0  // ablation switches of tools/gemm_ablate.hip (timing experiments only; 0 in the product build)
@@ -1456,11 +1457,16 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     using chunk_t = typename TR::chunk_t;
     using acc_t = typename TR::acc_t;
     constexpr int VEC = TR::VEC;
-    constexpr int LD = 65, LI = 17;
-    __shared__ T Ds[64 * LD];
-    __shared__ T Xs[XR * LD];
+    // row pitch: the MFMA operand reads (lane (li, lg) -> element li·LD + 4m + lg) hit distinct banks for a half-wave when the pitch is
+    // ≡ 2 (f64: 8-B elements) / ≡ 4 (f32) modulo the 64 dword banks' period; 65 was two-way conflicted (SQ_LDS_BANK_CONFLICT = 16 % of
+    // SQ_LDS_IDX_ACTIVE, profiles/r2/pmc_sq_summary.json).  An even pitch also keeps the 16-B staging chunks aligned.
+    constexpr int LD = sizeof(T) == 8 ? 66 : 68, LI = 17;
+    __shared__ __attribute__((aligned(16))) T Ds[64 * LD];
+    __shared__ __attribute__((aligned(16))) T Xs[XR * LD];
     __shared__ T Inv[4][16 * LI];
-    __shared__ T Lc[16 * LI];  // columns of the 16×16 block being factored (GPMI_POTF2_LDS)
+    __shared__ T Lc[16 * LI];  // columns of the 16×16 block being factored (GPMI_POTF2_LDS 1)
+    constexpr int LI2 = sizeof(T) == 8 ? 18 : 20;  // row pitch of Lr: a multiple of 16 B
+    __shared__ __attribute__((aligned(16))) T Lr[16 * LI2];  // rows of the 16×16 block being factored (GPMI_POTF2_LDS 2)
     __shared__ int writer_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #ifdef GPMI_PANEL_STAMPS
@@ -1611,7 +1617,96 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     };
     // wave 0 only: factor the 16×16 diagonal block j (L16 into Ds, inv(L16) into Inv[j])
     auto factor16 = [&](int j) {
-#if GPMI_POTF2_LDS
+#if GPMI_POTF2_LDS == 2
+            // Four-column blocks.  The serial chain is pivot -> rsqrt -> scale -> next pivot; everything a later pivot of the SAME
+            // block (and the first pivot of the next block) needs travels by v_readlane, so no LDS round trip sits on that chain.
+            // After a block the four finished entries of every row are published ONCE (Lr[row][c0..c0+3], 32 B per lane) and the
+            // columns further right are updated from broadcast ds_read_b128s (4 multipliers per row); the rows c0..c0+3 of L are
+            // then complete in LDS and the matching rows of inv(L16) follow (lane = column of the inverse).  The one-column variant
+            // paid a store -> wait -> load -> wait per column: ≈10 000 cycles per 16×16 block (tools/panel_stamps.hip).
+            T a[16], x[16], rin[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = Ds[(16 * j + li) * LD + 16 * j + c];
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                constexpr int NCH = 4 / VEC;
+                const int c0 = 4 * b4;
+                T v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + k;
+                    const T piv = lane_bcast<T>(a[c], c);
+                    if (!(piv > T(0)) && bad == 0) bad = 16 * j + c + 1;
+                    const T ri = fast_rsqrt<T>(piv);
+                    const T dd = piv * ri;
+                    rin[c] = ri;
+                    v[k] = (li == c) ? dd : a[c] * ri;
+                    a[c] = v[k];
+                    if (li == c) mydiag[j] = dd;
+#pragma unroll
+                    for (int t = c + 1; t <= c0 + 4; ++t)
+                        if (t < 16) a[t] = fma(-v[k], lane_bcast<T>(v[k], t < 16 ? t : 15), a[t]);
+                }
+                {  // publish L[li][c0..c0+3]
+                    chunk_t* dst = reinterpret_cast<chunk_t*>(&Lr[li * LI2 + c0]);
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) {
+                        chunk_t cv;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) cv[e] = v[q * VEC + e];
+                        dst[q] = cv;
+                    }
+                }
+#ifndef GPMI_EXP_NOUPD
+#pragma unroll
+                for (int t = c0 + 5; t < 16; ++t) {  // a[t] −= Σ_k L[li][c0+k] · L[t][c0+k]
+                    const chunk_t* src = reinterpret_cast<const chunk_t*>(&Lr[t * LI2 + c0]);
+                    T s0 = a[t], s1 = T(0);
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) {
+                        const chunk_t m = src[q];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            if ((q * VEC + e) & 1) s1 = fma(-v[q * VEC + e], m[e], s1);
+                            else s0 = fma(-v[q * VEC + e], m[e], s0);
+                        }
+                    }
+                    a[t] = s0 + s1;
+                }
+#endif
+#ifndef GPMI_EXP_NOINV
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // row c of inv(L16): x[c] = (δ − Σ_{m<c} L[c][m] x[m]) / L[c][c]
+                    const int c = c0 + k;
+                    T s0 = (li == c) ? T(1) : T(0), s1 = T(0);
+                    const chunk_t* src = reinterpret_cast<const chunk_t*>(&Lr[c * LI2]);
+#pragma unroll
+                    for (int q = 0; q * VEC < c; ++q) {
+                        const chunk_t m = src[q];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const int kk = q * VEC + e;
+                            if (kk < c) {
+                                if (kk & 1) s1 = fma(-m[e], x[kk], s1);
+                                else s0 = fma(-m[e], x[kk], s0);
+                            }
+                        }
+                    }
+                    x[c] = (s0 + s1) * rin[c];
+                }
+#else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[c0 + k] = rin[c0 + k];
+#endif
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c <= li) Ds[(16 * j + li) * LD + 16 * j + c] = a[c];
+                    Inv[j][c * LI + li] = x[c];
+                }
+            }
+#elif GPMI_POTF2_LDS
             // lane = row (factor) and lane = column (inverse); the finished column c is published in LDS (Lc[c][·]) and
             // every multiplier L[t][c] / L[c][k] is an LDS broadcast read — ~10 instructions per column instead of
             // ~30 v_readlane pairs; only the pivot travels by readlane

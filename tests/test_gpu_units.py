@@ -256,3 +256,50 @@ def test_gemm_wide_fp32_and_full_paths(agp):
     post = agp.posterior(fm(agp.RowVecs(x), 0.01), y)
     assert float(post.logpdf_value) == pytest.approx(ref, rel=1e-10)
     mctx.close()
+
+
+@pytest.mark.parametrize("group", [64, 128, 256, 512])
+def test_potrf_leaf_groups(lib, h, group):
+    """left-looking leaf groups: a leaf applies the kpre = 0..group/64−1 tiles to its left itself before factoring (64 = every
+    leaf is followed by its own GEMM).  Same contract as test_potrf_and_trsm, on shapes that exercise every kpre, ragged row
+    counts and more than 256 workgroups."""
+    from abstractgps_jl_amd._lib import check
+
+    check(lib.gp_ctx_set_param(h, b"leaf_group", group))
+    try:
+        for n, extra in ((512, 0), (576, 200 * 128 + 64), (1024, 320), (64, 64)):
+            test_potrf_and_trsm(lib, h, n, extra)
+        test_potrf_reports_first_bad_pivot(lib, h)
+    finally:
+        check(lib.gp_ctx_set_param(h, b"leaf_group", 128))
+
+
+@pytest.mark.parametrize("nbv", [128, 256, 512, 1024])
+def test_trsv_block_sizes(lib, h, nbv):
+    """diagonal block of the vector solves (one workgroup) = 128 … 1024; the rest goes to the multi-CU update kernels"""
+    from abstractgps_jl_amd._lib import check
+
+    check(lib.gp_ctx_set_param(h, b"trsv_nb", nbv))
+    try:
+        for np_, nrhs in ((128, 1), (1152, 2), (4096, 1)):
+            test_trsv_forward_backward(lib, h, np_, nrhs)
+    finally:
+        check(lib.gp_ctx_set_param(h, b"trsv_nb", 256))
+
+
+@pytest.mark.parametrize("sk", [0, 1])
+def test_fit_with_and_without_streamk(agp, sk):
+    """the few-tile GEMMs cut along k over all CUs (stream-K, hardware atomics) or not: same logpdf / α as the oracle"""
+    from oracle import gp_oracle as o
+
+    x, y = o.synth_inputs(4500, 3, 21)
+    fo = o.FiniteGP(o.GP(o.Kernel(o.MATERN52)), x, 0.02)
+    ref = float(o.logpdf(fo, y))
+    ctx = agp.Context(0)
+    ctx.set_param("gemm_streamk", sk)
+    ctx.set_param("nb", 1024)
+    post = agp.posterior(agp.GP(agp.Matern52Kernel(), ctx=ctx)(agp.RowVecs(x), 0.02), y)
+    assert float(post.logpdf_value) == pytest.approx(ref, rel=1e-10)
+    alpha = o.posterior(fo, y).alpha
+    assert np.linalg.norm(post.data.alpha - alpha) <= 1e-8 * np.linalg.norm(alpha)
+    ctx.close()
