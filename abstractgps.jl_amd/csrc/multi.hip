@@ -681,10 +681,15 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
         rk.r = r; rk.p = r / Q; rk.q = r % Q; rk.device = devices[r];
         rc = gp_ctx_create(&rk.c, devices[r], nullptr);
         if (rc != 0) break;
-        // comm stream: highest priority, so that a copy / RCCL kernel takes the next free CU slot ahead of the queued GEMM workgroups
+        // Rank contexts keep the round-2 mid-point configuration that passed every multi-device sweep (0 wrong fits in 425 under 16
+        // hardware queues): hardware-dispatched GEMMs (no stream-K) and a comm stream of default priority.  With stream-K in the rank
+        // contexts AND a high-priority comm stream, 11 of 501 fits of the n = 2 049 sweep cases were wrong under 16 hardware queues
+        // (mostly the first fit of a fresh context) — not root-caused; GPMI_COMM_PRIO=1 / gemm_streamk=1 re-enable them.
+        (void)gp_ctx_set_param(rk.c, "gemm_streamk", 0);
         int plo = 0, phi = 0;
+        const char* pe = getenv("GPMI_COMM_PRIO");
         if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess ||
-            hipStreamCreateWithPriority(&rk.sc, hipStreamNonBlocking, phi) != hipSuccess) {
+            hipStreamCreateWithPriority(&rk.sc, hipStreamNonBlocking, (pe && pe[0] == '1') ? phi : plo) != hipSuccess) {
             rc = set_err_text(-1997, "could not create the comm stream of a rank");
             break;
         }
