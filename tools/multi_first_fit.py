@@ -1,5 +1,7 @@
 """First fit on a FRESH multi-device context (virtual ranks, GPU_MAX_HW_QUEUES=16): failure counts per configuration of the
-rank contexts (stream-K on/off) and of the comm stream (priority), with and without a small warm-up fit."""
+rank contexts (stream-K on/off) and of the comm stream (priority), with and without a small warm-up fit.
+  python tools/multi_first_fit.py [reps] [variant indices, comma separated]   — run each call under `timeout`: one variant run of the
+  stress tool hung with 24 streams on 16 hardware queues."""
 import os
 import sys
 from pathlib import Path
@@ -29,8 +31,16 @@ for seed in (9069, 9092):
     depth = int(rng.integers(1, 4))
     lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, X, sig), y)
     cases.append((seed, kern, mean, X, y, sig, P, Q, nb, depth, lp_ref, opost.alpha))
-for name, sk, prio, warm in (("sk1 prio1", 1, "1", 0), ("sk0 prio0 (default)", 0, "0", 0), ("sk1 prio1 + warm-up fit", 1, "1", 1),
-                             ("sk1 prio0", 1, "0", 0), ("sk0 prio1", 0, "1", 0)):
+VARIANTS = [("sk1 prio1", 1, "1", 0, {}), ("sk0 prio0 (default)", 0, "0", 0, {}), ("sk1 prio1 + warm-up fit", 1, "1", 1, {}),
+            ("sk1 prio0", 1, "0", 0, {}), ("sk0 prio1", 0, "1", 0, {}),
+            # localisation (next round): own copy kernel instead of hipMemcpy2DAsync; host syncs after exchange / panel / bulk
+            ("sk0 prio1 copy_kernel", 0, "1", 0, {"copy_kernel": 1}), ("sk0 prio1 sync-after-exchange", 0, "1", 0, {"multi_debug_sync": 1}),
+            ("sk0 prio1 sync-after-panel", 0, "1", 0, {"multi_debug_sync": 8}), ("sk0 prio1 sync-after-bulk", 0, "1", 0, {"multi_debug_sync": 16}),
+            ("sk0 prio1 host-side event waits", 0, "1", 0, {"multi_debug_sync": 4})]
+pick = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+for vi, (name, sk, prio, warm, extra) in enumerate(VARIANTS):
+    if pick is not None and str(vi) not in pick:
+        continue
     os.environ["GPMI_COMM_PRIO"] = prio
     bad = tot = 0
     for seed, kern, mean, X, y, sig, P, Q, nb, depth, lp_ref, alpha in cases:
@@ -38,6 +48,8 @@ for name, sk, prio, warm in (("sk1 prio1", 1, "1", 0), ("sk0 prio0 (default)", 0
             ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
             ctx.set_param("lookahead_depth", depth)
             ctx.set_param("gemm_streamk", sk)
+            for k, v in extra.items():
+                ctx.set_param(k, v)
             f = agp.GP(kern, ctx=ctx) if mean is None else agp.GP(mean, kern, ctx=ctx)
             try:
                 if warm:
@@ -49,4 +61,4 @@ for name, sk, prio, warm in (("sk1 prio1", 1, "1", 0), ("sk0 prio0 (default)", 0
             tot += 1
             bad += not ok
             ctx.close()
-    print(f"{name:28s} wrong first fits: {bad}/{tot}", flush=True)
+    print(f"[{vi}] {name:34s} wrong first fits: {bad}/{tot}", flush=True)
