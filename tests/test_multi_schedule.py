@@ -11,12 +11,15 @@ sys.path.insert(0, str(ROOT / "tools"))
 import multi_schedule_check as M  # noqa: E402
 
 
+@pytest.mark.parametrize("rccl", [False, True], ids=["copies", "rccl"])
 @pytest.mark.parametrize("grid", M.GRIDS)
-def test_no_unordered_conflicts(grid):
+def test_no_unordered_conflicts(grid, rccl):
+    """both transports: consumer pulls (hipMemcpy2DAsync / copy kernel) and the grouped ncclSend / ncclRecv pairs with their
+    staging images (the RCCL schedule has never run on more than one GPU: this is its only check besides the API test)"""
     P, Q = grid
     for nblk in (1, 2, 3, 5, 9, 17):
         for depth in (1, 2, 3):
-            rs = M.races(M.build(P, Q, nblk, depth))
+            rs = M.races(M.build(P, Q, nblk, depth, rccl=rccl))
             assert not rs, (grid, nblk, depth, rs[:4])
 
 
@@ -43,3 +46,10 @@ def test_checker_finds_missing_bulk_wait_and_buffer_reuse():
     assert ns["races"](ns["build"](2, 2, 9, 2))
     ns = _variant("            sc[r].wait(bulk_done[r][k - NBUF])\n            sc[r].wait(la_done[r][k - NBUF])\n", "            pass\n")
     assert ns["races"](ns["build"](2, 2, 9, 2))
+
+
+def test_checker_finds_unstaged_rccl_sends():
+    """RCCL transport: without the wait for the rank's own panel in front of the group, the sends would read the staging image
+    before the panel stream has written it"""
+    ns = _variant("            if q == qk:\n                sc[r].wait(ready[r][k])\n        sends, recvs", "        sends, recvs")
+    assert ns["races"](ns["build"](2, 2, 9, 2, rccl=True))

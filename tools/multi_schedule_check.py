@@ -1,4 +1,4 @@
-"""Happens-before check of the multi-device schedule (abstractgps.jl_amd/csrc/multi.hip, fit_rank, copy transport).
+"""Happens-before check of the multi-device schedule (abstractgps.jl_amd/csrc/multi.hip, fit_rank; both transports).
 
 fit_rank (factorisation + backward block sweep) is replayed symbolically: every stream operation of every rank becomes a node with the
 set of BLOCKS it reads and writes (local matrix blocks, operand-buffer slots, the L_kk image), stream order and event waits
@@ -51,7 +51,7 @@ class Stream:
         return self.last
 
 
-def build(P, Q, nblk, depth):
+def build(P, Q, nblk, depth, rccl=False):
     g = Graph()
     R = P * Q
     NBUF = depth + 1
@@ -81,6 +81,8 @@ def build(P, Q, nblk, depth):
     arrived = [[None] * nblk for _ in range(R)]
     bulk_done = [[None] * nblk for _ in range(R)]
     la_done = [[None] * nblk for _ in range(R)]
+    lkk_free = [None] * R      # RCCL: my L_kk image may be overwritten again after this event
+    pending_send = {}          # RCCL: (src rank, dst rank, tag) -> send node, consumed by the matching receive
 
     # assembly + buffer clears on the main stream, then sp / sc wait for it
     for r in range(R):
@@ -88,6 +90,7 @@ def build(P, Q, nblk, depth):
         w += [("Ab", r, s, li) for s in range(NBUF) for li in list(range(nlb_r[r])) + ["rhs"]]
         w += [("Bb", r, s, lj) for s in range(NBUF) for lj in range(nlb_c[r])]
         w += [("Lkk", r)] + [("acc", r, lj) for lj in range(nlb_c[r])]
+        w += [("St", r, s, li) for s in range(NBUF) for li in list(range(nlb_r[r])) + ["rhs"]]
         sm[r].op("assemble", writes=w)
         ev = sm[r].record()
         sp[r].wait(ev)
@@ -127,17 +130,37 @@ def build(P, Q, nblk, depth):
             if p == pk:
                 d = A(r, k // P, c0)
                 sp[r].op(f"potrf_diag({k})", reads=[d], writes=[d])
-                lkk[r][k] = sp[r].record()
                 lread = [d]
+                if rccl:  # contiguous image for the sends, all RCCL calls of a rank on its comm stream
+                    sp[r].wait(lkk_free[r])
+                    sp[r].op(f"lkk_image({k})", reads=[d], writes=[("Lkk", r)])
+                    sc[r].wait(sp[r].record())
+                    for pp in range(P):
+                        if pp != pk:
+                            pending_send[(r, rank_of(pp, qk), ("lkk", k))] = sc[r].op(f"send_lkk({k}->{pp})", reads=[("Lkk", r)])
+                    lkk_free[r] = sc[r].record()
+                lkk[r][k] = sp[r].record()
             else:
                 own = rank_of(pk, qk)
-                sp[r].wait(lkk[own][k])
-                sp[r].op(f"pull_lkk({k})", reads=[A(own, k // P, c0)], writes=[("Lkk", r)])
+                if rccl:
+                    sc[r].wait(lkk_free[r])
+                    sc[r].wait(pending_send[(own, r, ("lkk", k))])
+                    sc[r].op(f"recv_lkk({k})", writes=[("Lkk", r)])
+                    sp[r].wait(sc[r].record())
+                else:
+                    sp[r].wait(lkk[own][k])
+                    sp[r].op(f"pull_lkk({k})", reads=[A(own, k // P, c0)], writes=[("Lkk", r)])
                 lread = [("Lkk", r)]
             rb = rows_ge(r, k + 1)
             if rb:
                 blocks = [A(r, li, c0) for li in rb]
                 sp[r].op(f"trsm({k})", reads=blocks + lread, writes=blocks)
+            if rccl and p != pk:
+                lkk_free[r] = sp[r].record()
+        if rccl:  # contiguous image of my piece of the panel for the sends of exchange(k)
+            rb = rows_ge(r, k + 1)
+            if rb:
+                sp[r].op(f"stage({k})", reads=[A(r, li, c0) for li in rb], writes=[("St", r, k % NBUF, li) for li in rb])
         ready[r][k] = sp[r].record()
 
     def exchange(r, k):
@@ -149,23 +172,26 @@ def build(P, Q, nblk, depth):
             sc[r].wait(la_done[r][k - NBUF])
         if q == qk:
             sc[r].wait(ready[r][k])
-        if q != qk:
-            src = rank_of(p, qk)
-            rb = rows_ge(r, k + 1)
-            if rb:
-                sc[r].wait(ready[src][k])
-                sc[r].op(f"pullA({k})", reads=[A(src, li, k // Q) for li in rb], writes=[("Ab", r, s, li) for li in rb])
-        for pp in range(P):
-            src = rank_of(pp, qk)
-            waited = False
-            for lj in range(nlb_before(k, q, Q), nlb_c[r]):
-                gj = lj * Q + q
-                if gj % P != pp:
-                    continue
-                if not waited:
+        if not rccl:
+            if q != qk:
+                src = rank_of(p, qk)
+                rb = rows_ge(r, k + 1)
+                if rb:
                     sc[r].wait(ready[src][k])
-                    waited = True
-                sc[r].op(f"pullB({k},{lj})", reads=[A(src, gj // P, k // Q)], writes=[("Bb", r, s, lj)])
+                    sc[r].op(f"pullA({k})", reads=[A(src, li, k // Q) for li in rb], writes=[("Ab", r, s, li) for li in rb])
+            for pp in range(P):
+                src = rank_of(pp, qk)
+                waited = False
+                for lj in range(nlb_before(k, q, Q), nlb_c[r]):
+                    gj = lj * Q + q
+                    if gj % P != pp:
+                        continue
+                    if not waited:
+                        sc[r].wait(ready[src][k])
+                        waited = True
+                    sc[r].op(f"pullB({k},{lj})", reads=[A(src, gj // P, k // Q)], writes=[("Bb", r, s, lj)])
+        else:
+            return ("rccl", r, k, s)   # sends / receives are generated for all ranks together (matched pairs)
         arrived[r][k] = sc[r].record()
 
     def la_update(r, j, i):
@@ -178,21 +204,64 @@ def build(P, Q, nblk, depth):
             sp[r].wait(bulk_done[r][first - 1])
         update(sp[r], r, i, j, [j // Q], f"la({j},{i})")
 
+    def exchange_all(k):
+        """exchange(k) of every rank.  RCCL: the same transfers as matched send / receive pairs, one group per rank, both sides
+        enumerating (source process row, destination rank, block) in the same order; a receive completes after its send started."""
+        if not rccl:
+            for r in range(R):
+                exchange(r, k)
+            return
+        qk, s = k % Q, k % NBUF
+        for r in range(R):   # the waits in front of the group
+            p, q = ranks[r]
+            if k - NBUF >= 0:
+                sc[r].wait(bulk_done[r][k - NBUF])
+                sc[r].wait(la_done[r][k - NBUF])
+            if q == qk:
+                sc[r].wait(ready[r][k])
+        sends, recvs = [], []
+        for pp in range(P):
+            src = rank_of(pp, qk)
+            rbs = rows_ge(src, k + 1)
+            for dp in range(P):
+                for dq in range(Q):
+                    dst = rank_of(dp, dq)
+                    if dp == pp and dq != qk and rbs:   # A part
+                        sends.append((src, dst, ("A", k), [("St", src, s, li) for li in rbs]))
+                        recvs.append((src, dst, ("A", k), [("Ab", dst, s, li) for li in rbs]))
+                    for lj in range(nlb_before(k, dq, Q), nlb_c[dst]):   # B part
+                        gj = lj * Q + dq
+                        if gj % P != pp:
+                            continue
+                        if src == dst:
+                            sc[src].op(f"selfB({k},{lj})", reads=[("St", src, s, gj // P)], writes=[("Bb", src, s, lj)])
+                        else:
+                            sends.append((src, dst, ("B", k, lj), [("St", src, s, gj // P)]))
+                            recvs.append((src, dst, ("B", k, lj), [("Bb", dst, s, lj)]))
+        for src, dst, tag, rd in sends:
+            pending_send[(src, dst, tag)] = sc[src].op(f"send{tag}->{dst}", reads=rd)
+        for src, dst, tag, wr in recvs:
+            sc[dst].wait(pending_send[(src, dst, tag)])
+            sc[dst].op(f"recv{tag}<-{src}", writes=wr)
+        for r in range(R):
+            arrived[r][k] = sc[r].record()
+
     # the host loops of every rank interleave arbitrarily; the graph only needs each rank's own program order, plus the
     # cross-rank events, which must exist before they are waited for -> build in rounds of k, owners before consumers
     def step(fn, *a):
         for r in range(R):
             fn(r, *a)
 
-    step(panel, 0)
-    step(exchange, 0)
+    for r in sorted(range(R), key=lambda r: 0 if ranks[r][0] == 0 else 1):
+        panel(r, 0)
+    exchange_all(0)
     for k in range(nblk):
         if k + 1 < nblk:
             step(la_update, k + 1, k)
             # diagonal owners publish lkk before their column peers wait for it
             for r in sorted(range(R), key=lambda r: 0 if ranks[r][0] == (k + 1) % P else 1):
                 panel(r, k + 1)
-            step(exchange, k + 1)
+            exchange_all(k + 1)
             for j in range(k + 2, min(k + depth, nblk - 1) + 1):
                 step(la_update, j, k)
         for r in range(R):
@@ -279,13 +348,13 @@ GRIDS = [(1, 1), (2, 1), (1, 2), (2, 2), (3, 1), (4, 1), (2, 3), (4, 2), (2, 4),
 
 if __name__ == "__main__":
     bad = 0
-    for (P, Q) in GRIDS:
+    for rccl, (P, Q) in itertools.product((False, True), GRIDS):
         for nblk in (1, 2, 3, 5, 9, 17):
             for depth in (1, 2, 3):
-                rs = races(build(P, Q, nblk, depth))
+                rs = races(build(P, Q, nblk, depth, rccl=rccl))
                 if rs:
                     bad += 1
-                    print(f"grid {P}x{Q} nblk {nblk} depth {depth}: {len(rs)} unordered conflicting pairs, e.g.")
+                    print(f"{'rccl' if rccl else 'copies'} grid {P}x{Q} nblk {nblk} depth {depth}: {len(rs)} unordered conflicting pairs, e.g.")
                     for r in rs[:6]:
                         print("   ", r)
     print("configurations with races:", bad)
