@@ -19,8 +19,11 @@ def test_no_unordered_conflicts(grid, rccl):
     P, Q = grid
     for nblk in (1, 2, 3, 5, 9, 17):
         for depth in (1, 2, 3):
-            rs = M.races(M.build(P, Q, nblk, depth, rccl=rccl))
+            g = M.build(P, Q, nblk, depth, rccl=rccl)
+            rs = M.races(g)
             assert not rs, (grid, nblk, depth, rs[:4])
+            if rccl:  # point-to-point operations of a pair of ranks match by posting order
+                assert not M.rccl_pair_order(g, P * Q), (grid, nblk, depth)
 
 
 def _variant(old, new):

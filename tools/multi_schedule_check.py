@@ -137,7 +137,7 @@ def build(P, Q, nblk, depth, rccl=False):
                     sc[r].wait(sp[r].record())
                     for pp in range(P):
                         if pp != pk:
-                            pending_send[(r, rank_of(pp, qk), ("lkk", k))] = sc[r].op(f"send_lkk({k}->{pp})", reads=[("Lkk", r)])
+                            pending_send[(r, rank_of(pp, qk), ("lkk", k))] = sc[r].op(f"send('lkk', {k})->{rank_of(pp, qk)}", reads=[("Lkk", r)])
                     lkk_free[r] = sc[r].record()
                 lkk[r][k] = sp[r].record()
             else:
@@ -145,7 +145,7 @@ def build(P, Q, nblk, depth, rccl=False):
                 if rccl:
                     sc[r].wait(lkk_free[r])
                     sc[r].wait(pending_send[(own, r, ("lkk", k))])
-                    sc[r].op(f"recv_lkk({k})", writes=[("Lkk", r)])
+                    sc[r].op(f"recv('lkk', {k})<-{own}", writes=[("Lkk", r)])
                     sp[r].wait(sc[r].record())
                 else:
                     sp[r].wait(lkk[own][k])
@@ -344,6 +344,22 @@ def races(g):
     return out
 
 
+def rccl_pair_order(g, R):
+    """RCCL matching rule: between any two ranks the sends of one and the receives of the other must be posted in the same
+    order (point-to-point operations of a pair match by posting order).  Returns the pairs whose sequences differ."""
+    import re
+
+    seq_s, seq_r = {}, {}
+    for lab, _, _ in g.nodes:
+        m = re.match(r"r(\d+)\.sc:send(.*)->(\d+)$", lab)
+        if m:
+            seq_s.setdefault((int(m.group(1)), int(m.group(3))), []).append(m.group(2))
+        m = re.match(r"r(\d+)\.sc:recv(.*)<-(\d+)$", lab)
+        if m:
+            seq_r.setdefault((int(m.group(3)), int(m.group(1))), []).append(m.group(2))
+    return [k for k in set(seq_s) | set(seq_r) if seq_s.get(k) != seq_r.get(k)]
+
+
 GRIDS = [(1, 1), (2, 1), (1, 2), (2, 2), (3, 1), (4, 1), (2, 3), (4, 2), (2, 4), (8, 1), (1, 3)]
 
 if __name__ == "__main__":
@@ -351,7 +367,11 @@ if __name__ == "__main__":
     for rccl, (P, Q) in itertools.product((False, True), GRIDS):
         for nblk in (1, 2, 3, 5, 9, 17):
             for depth in (1, 2, 3):
-                rs = races(build(P, Q, nblk, depth, rccl=rccl))
+                gr = build(P, Q, nblk, depth, rccl=rccl)
+                rs = races(gr)
+                if rccl and rccl_pair_order(gr, P * Q):
+                    bad += 1
+                    print(f"rccl grid {P}x{Q} nblk {nblk} depth {depth}: send / receive posting order differs for", rccl_pair_order(gr, P * Q)[:4])
                 if rs:
                     bad += 1
                     print(f"{'rccl' if rccl else 'copies'} grid {P}x{Q} nblk {nblk} depth {depth}: {len(rs)} unordered conflicting pairs, e.g.")
