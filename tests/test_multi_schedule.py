@@ -56,3 +56,13 @@ def test_checker_finds_unstaged_rccl_sends():
     before the panel stream has written it"""
     ns = _variant("            if q == qk:\n                sc[r].wait(ready[r][k])\n        sends, recvs", "        sends, recvs")
     assert ns["races"](ns["build"](2, 2, 9, 2, rccl=True))
+
+
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_rank_threads_cannot_block_each_other(grid):
+    """host side: every generation-numbered event a rank thread spins on is published by its owner without that owner waiting,
+    directly or through other ranks, for the spinning thread"""
+    P, Q = grid
+    for nblk in (1, 2, 3, 5, 9, 17):
+        for depth in (1, 2, 3):
+            assert not M.host_deadlock(P, Q, nblk, depth), (grid, nblk, depth)

@@ -360,6 +360,74 @@ def rccl_pair_order(g, R):
     return [k for k in set(seq_s) | set(seq_r) if seq_s.get(k) != seq_r.get(k)]
 
 
+def host_program(P, Q, nblk, depth, r):
+    """The cross-thread events one rank thread publishes / awaits on the HOST, in the program order of fit_rank (copy transport):
+    ('pub', kind, rank, k) after the hipEventRecord, ('await', kind, rank, k) = spin until that rank has published."""
+    p, q = r // Q, r % Q
+    nlb_c = nlb_before(nblk - 1, q, Q)
+    ev = []
+
+    def panel(k):
+        pk, qk = k % P, k % Q
+        if q != qk:
+            return
+        if P > 1:
+            if p == pk:
+                ev.append(("pub", "lkk", r, k))
+            else:
+                ev.append(("await", "lkk", pk * Q + qk, k))
+        ev.append(("pub", "ready", r, k))
+
+    def exchange(k):
+        qk = k % Q
+        if q != qk:
+            ev.append(("await", "ready", p * Q + qk, k))
+        for pp in range(P):
+            if any((lj * Q + q) % P == pp for lj in range(nlb_before(k, q, Q), nlb_c)):
+                ev.append(("await", "ready", pp * Q + qk, k))
+
+    panel(0)
+    exchange(0)
+    for k in range(nblk):
+        if k + 1 < nblk:
+            panel(k + 1)
+            exchange(k + 1)
+    for k in range(nblk - 1, -1, -1):
+        pk, qk = k % P, k % Q
+        if q == qk:
+            if p == pk:
+                for pp in range(P):
+                    if pp != pk:
+                        ev.append(("await", "accr", pp * Q + qk, k))
+                ev.append(("pub", "alr", r, k))
+            else:
+                ev.append(("pub", "accr", r, k))
+        if p == pk and k > 0 and nlb_before(k - 1, q, Q) > 0 and q != qk:
+            ev.append(("await", "alr", pk * Q + qk, k))
+    return ev
+
+
+def host_deadlock(P, Q, nblk, depth):
+    """run the rank threads' host programs to completion: returns the blocked (rank, event) list if they cannot all finish"""
+    R = P * Q
+    prog = [host_program(P, Q, nblk, depth, r) for r in range(R)]
+    pc = [0] * R
+    done = set()
+    progress = True
+    while progress:
+        progress = False
+        for r in range(R):
+            while pc[r] < len(prog[r]):
+                kind, what, who, k = prog[r][pc[r]]
+                if kind == "pub":
+                    done.add((what, who, k))
+                elif (what, who, k) not in done:
+                    break
+                pc[r] += 1
+                progress = True
+    return [(r, prog[r][pc[r]]) for r in range(R) if pc[r] < len(prog[r])]
+
+
 GRIDS = [(1, 1), (2, 1), (1, 2), (2, 2), (3, 1), (4, 1), (2, 3), (4, 2), (2, 4), (8, 1), (1, 3)]
 
 if __name__ == "__main__":
@@ -372,6 +440,9 @@ if __name__ == "__main__":
                 if rccl and rccl_pair_order(gr, P * Q):
                     bad += 1
                     print(f"rccl grid {P}x{Q} nblk {nblk} depth {depth}: send / receive posting order differs for", rccl_pair_order(gr, P * Q)[:4])
+                if not rccl and host_deadlock(P, Q, nblk, depth):
+                    bad += 1
+                    print(f"grid {P}x{Q} nblk {nblk} depth {depth}: rank threads block on", host_deadlock(P, Q, nblk, depth)[:4])
                 if rs:
                     bad += 1
                     print(f"{'rccl' if rccl else 'copies'} grid {P}x{Q} nblk {nblk} depth {depth}: {len(rs)} unordered conflicting pairs, e.g.")
