@@ -45,6 +45,7 @@ PROTOTYPES = {
     "gp_ctx_create": (i32, [C.POINTER(vp), i32, vp]),
     "gp_ctx_create_multi": (i32, [C.POINTER(vp), C.POINTER(i32), i32, i32, i32, i32]),
     "gp_ctx_multi_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "gp_multi_schedule_trace": (i32, [i32, i32, i32, i32, i32, C.c_char_p]),
     "gp_ctx_destroy": (i32, [vp]),
     "gp_ctx_set_param": (i32, [vp, C.c_char_p, i64]),
     "gp_get_timings": (i32, [vp, C.POINTER(gp_timings)]),
@@ -52,6 +53,8 @@ PROTOTYPES = {
     "gp_abi_version": (i32, []),
     "gp_kernelmatrix": (i32, [vp, PK, PP, PP, vp]),
     "gp_logpdf": (i32, [vp, PK, PP, PN, vp, vp, i64, i32, vp]),
+    "gp_logpdf_terms": (i32, [vp, PK, PP, PN, vp, vp, i64, i32, vp, vp]),
+    "gp_posterior_logdet": (i32, [vp, C.POINTER(dbl)]),
     "gp_posterior_fit": (i32, [vp, PK, PP, PN, vp, vp, C.POINTER(vp), vp, vp]),
     "gp_posterior_predict": (i32, [vp, PP, vp, i32, vp, vp, vp]),
     "gp_posterior_get_factor": (i32, [vp, vp]),
@@ -111,7 +114,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.gp_abi_version() != 2:
+    if lib.gp_abi_version() != 3:
         raise ImportError("libgpmi355.so ABI version mismatch")
     _lib = lib
     return lib

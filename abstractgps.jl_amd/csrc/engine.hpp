@@ -239,7 +239,9 @@ int32_t eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const double
 // ---- multi-device contexts (multi.hip) --------------------------------------------------------------
 void multi_destroy(gp_multi* m);
 int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null,
-                  const void* Y, long ldy, int ncols, double* logpdf_out, gp_post* post, void* alpha_out);
+                  const void* Y, long ldy, int ncols, double* logpdf_out, double* terms_out /* nullable: [0] logdet, [1+s] sqmahal_s */,
+                  gp_post* post, void* alpha_out);
+void multi_trim(gp_ctx* c);  // gp_ctx_trim of every rank context
 int32_t multi_gather(gp_post* post);  // block-cyclic pieces -> one row-major factor on the ctx's first device
 void multi_post_release(gp_post* post);
 int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v);  // 1 = not a multi parameter

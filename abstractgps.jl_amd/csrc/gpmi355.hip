@@ -701,6 +701,8 @@ template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k,
 
 struct FitOut {
     std::vector<double> logpdf;  // per RHS column
+    double logdet = 0;           // logdet(K + Σy)            (src/finite_gp_projection.jl:310)
+    std::vector<double> sqmahal; // ‖U⁻ᵀ(y_s − m)‖² per column (src/finite_gp_projection.jl:325-326)
     int32_t info = 0;
 };
 
@@ -777,9 +779,14 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
         HIPCHK(hipStreamSynchronize(c->sm));
         out.info = info_h;
         out.logpdf.resize(ncols);
+        out.sqmahal.resize(ncols);
         logdet_half_out = scal_h[0];
         const double logdet = 2.0 * scal_h[0];
-        for (int s = 0; s < ncols; ++s) out.logpdf[s] = -0.5 * ((double)n * LOG2PI + logdet + scal_h[8 + s]);
+        out.logdet = logdet;
+        for (int s = 0; s < ncols; ++s) {
+            out.sqmahal[s] = scal_h[8 + s];
+            out.logpdf[s] = -0.5 * ((double)n * LOG2PI + logdet + scal_h[8 + s]);
+        }
         // timings
         float ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[1]));
@@ -1428,7 +1435,8 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "gemm_wide_min")) c->gemm_wide_min = std::max<int64_t>(1, v);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
-    else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
+    else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
+             !strcmp(name, "multi_check") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }
@@ -1440,6 +1448,7 @@ int32_t gp_ctx_trim(gp_ctx* c) {
     (void)hipStreamSynchronize(c->sm);
     (void)hipStreamSynchronize(c->sp);
     while (!c->pool.empty()) pool_drop(c, c->pool.size() - 1);
+    if (c->multi) multi_trim(c);  // the rank contexts cache their own blocks (matrix pieces, operand buffers)
     return 0;
 }
 
@@ -1507,6 +1516,22 @@ static int32_t check_fit_args(gp_ctx* c, const gp_kernel* k, const gp_points* x,
     return 0;
 }
 
+// One (logpdf, posterior) pair on whatever the ctx drives: the 2D block-cyclic driver (multi.hip) for fp64 fits with at most
+// 128 right-hand sides on a multi-device ctx, the single-device engine (devices[0] of a multi-device ctx) for everything else.
+static int32_t fit_any(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean, const void* Y,
+                       long ldy, int ncols, FitOut& fo, gp_post* p, void* alpha_out) {
+    if (c->multi && k->dtype == 0 && ncols <= 128) {
+        fo.logpdf.assign((size_t)ncols, 0.0);
+        std::vector<double> terms((size_t)ncols + 1, 0.0);
+        RC(multi_fit(c, k, x, noise, mean, Y, ldy, ncols, fo.logpdf.data(), terms.data(), p, alpha_out));
+        fo.logdet = terms[0];
+        fo.sqmahal.assign(terms.begin() + 1, terms.end());
+        return 0;
+    }
+    return k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, Y, ldy, ncols, fo, p, alpha_out)
+                         : fit_impl<float>(c, k, x, noise, mean, Y, ldy, ncols, fo, p, alpha_out);
+}
+
 int32_t gp_logpdf(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean,
                   const void* Y, int64_t ldy, int32_t ncols, void* out) {
     RC(check_fit_args(c, k, x, noise));
@@ -1517,19 +1542,56 @@ int32_t gp_logpdf(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     std::lock_guard<std::mutex> l(c->mu);
     HIPCHK(hipSetDevice(c->device));
     FitOut fo;
-    int32_t rc;
-    if (c->multi) {  // 2D block-cyclic over the ctx's devices (multi.hip)
-        fo.logpdf.assign((size_t)ncols, 0.0);
-        rc = multi_fit(c, k, x, noise, mean, Y, ldy, ncols, fo.logpdf.data(), nullptr, nullptr);
-    } else {
-        rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr)
-                           : fit_impl<float>(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr);
-    }
+    const int32_t rc = fit_any(c, k, x, noise, mean, Y, ldy, ncols, fo, nullptr, nullptr);
     if (rc != 0) return rc;
     for (int s = 0; s < ncols; ++s) {
         if (k->dtype == 0) ((double*)out)[s] = fo.logpdf[s];
         else ((float*)out)[s] = (float)fo.logpdf[s];
     }
+    return 0;
+}
+
+// logdet(cov(fx)) and sqmahal(fx, Y) — the two terms logpdf adds up (src/finite_gp_projection.jl:306-311): `logdetcov` is not in
+// the reference's API by that name but `sqmahal` is (src/finite_gp_projection.jl:313-326), and `gradlogpdf` (:328-337) is −α of
+// the posterior fit.  Y may be NULL (ncols ignored): logdet only.  Outputs in the kernel's dtype; either may be NULL.
+int32_t gp_logpdf_terms(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean,
+                        const void* Y, int64_t ldy, int32_t ncols, void* logdet_out, void* sqmahal_out) {
+    RC(check_fit_args(c, k, x, noise));
+    if (Y) {
+        if (ncols < 1) return set_arg_err(8, "ncols must be >= 1");
+        if (ldy < x->n) return set_arg_err(7, "ldy < n");
+    } else if (sqmahal_out) {
+        return set_arg_err(6, "sqmahal needs Y");
+    }
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    FitOut fo;
+    std::vector<char> zero;
+    if (!Y) {  // a zero observation vector with a zero mean: the factorisation is all that is needed
+        zero.assign((size_t)x->n * (k->dtype == 0 ? 8 : 4), 0);
+        ncols = 1;
+        ldy = x->n;
+    }
+    const int32_t rc = fit_any(c, k, x, noise, Y ? mean : nullptr, Y ? Y : (const void*)zero.data(), ldy, ncols, fo, nullptr, nullptr);
+    if (rc != 0) return rc;
+    if (logdet_out) {
+        if (k->dtype == 0) *(double*)logdet_out = fo.logdet;
+        else *(float*)logdet_out = (float)fo.logdet;
+    }
+    if (sqmahal_out)
+        for (int s = 0; s < ncols; ++s) {
+            if (k->dtype == 0) ((double*)sqmahal_out)[s] = fo.sqmahal[s];
+            else ((float*)sqmahal_out)[s] = (float)fo.sqmahal[s];
+        }
+    return 0;
+}
+
+// logdet(C) of a posterior's factor (C = cholesky(K + Σy), `post.data.C`): 2 Σ log L_ii kept from the fit.
+int32_t gp_posterior_logdet(gp_post* post, double* out) {
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
+    if (!out) return set_arg_err(2, "out is NULL");
+    *out = 2.0 * post->logdet_half;
     return 0;
 }
 
@@ -1544,14 +1606,7 @@ int32_t gp_posterior_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     gp_post* p = new gp_post();
     p->ctx = c;
     FitOut fo;
-    int32_t rc;
-    if (c->multi) {
-        fo.logpdf.assign(1, 0.0);
-        rc = multi_fit(c, k, x, noise, mean, y, x->n, 1, fo.logpdf.data(), p, alpha_out);
-    } else {
-        rc = k->dtype == 0 ? fit_impl<double>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out)
-                           : fit_impl<float>(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out);
-    }
+    const int32_t rc = fit_any(c, k, x, noise, mean, y, x->n, 1, fo, p, alpha_out);
     if (rc != 0) {
         delete p;
         return rc;

@@ -1,4 +1,4 @@
-// multi.hip — multi-device 2D block-cyclic driver of the logpdf + posterior pair, INSIDE libgpmi355 (host code only).
+// multi.hip — multi-device 2D block-cyclic driver of the logpdf + posterior pair, INSIDE libgpmi355.
 //
 // The reference has no distributed path; its caller is ONE Julia process calling posterior(fx, y)
 // (src/exact_gpr_posterior.jl:29-35) / logpdf(fx, y) (src/finite_gp_projection.jl:306-311).  So the N devices of a node are
@@ -20,10 +20,16 @@
 //   main stream  : bulk(k) — ONE MFMA GEMM over all local columns right of the look-ahead window
 // Transport ("comm" parameter): 1 = RCCL grouped ncclSend/ncclRecv between distinct peers (every pair has its own xGMI link:
 // the transfers of one step run on several links at once — a ring broadcast would be bound by one), 2 = peer copies pulled by
-// the consumer (hipMemcpy2DAsync over xGMI; the only mode possible for virtual ranks sharing one device), 0 = auto.
-// Default grid for ndev devices: P = ndev, Q = 1 — on a full-mesh point-to-point fabric the per-link volume is what bounds
-// the exchange: a rank then receives (P−1)/P of each panel spread evenly over P−1 links (≈2.2 GB per link at N = 65 536 on 8
-// devices, against ≈10.7 GB on the busiest link of a 2×4 grid); any P×Q can be requested.
+// the consumer (hipMemcpy2DAsync over xGMI), 0 = auto.  GPMI_RCCL_LIB names the library to dlopen (tests: tests/rccl_mock,
+// a host-rendezvous stand-in that lets the RCCL branch run with virtual ranks on ONE device).
+//
+// Every stream operation, event record and event wait of a rank goes through RankRun (op / rec / wait / publish / await):
+//   * GPMI_TRACE_SCHEDULE=<file> (or gp_multi_schedule_trace, which runs the SAME fit_rank control flow without a device)
+//     writes them as JSON lines with their block footprints — tools/multi_schedule_check.py checks happens-before on that;
+//   * "multi_check" (ctx parameter): 1 = every event record is preceded by a marker kernel and every event wait followed by a
+//     checker kernel on the waiting stream (a waiter that runs before the recorded point is logged), 2 = every update GEMM
+//     first compares its operand buffers with the owners' final panel blocks, 4 = operand buffers poisoned with NaN instead
+//     of zeros.  Findings fail the fit with status −1990 and the list in gp_last_error().
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -35,6 +41,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <memory>
 #include <string>
 #include <thread>
@@ -44,6 +51,41 @@
 
 using namespace gpmi;
 
+// ------------------------------------------------------------------------------------------------
+// diagnostic kernels ("multi_check")
+// ------------------------------------------------------------------------------------------------
+__global__ void mk_mark_kernel(int* flag, int seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// log layout: [0] number of findings, then 4 ints per finding (code, a, b, c), at most 60 kept
+__device__ inline void mk_log(int* log, int code, int a, int b, int c) {
+    const int i = atomicAdd(log, 1);
+    if (i < 60) {
+        log[4 + 4 * i] = code;
+        log[5 + 4 * i] = a;
+        log[6 + 4 * i] = b;
+        log[7 + 4 * i] = c;
+    }
+}
+__global__ void mk_check_kernel(const int* flag, int seq, int* log, int owner, int id, int stream) {
+    const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v != seq) mk_log(log, 1, owner, id, stream * 65536 + (v & 0xffff));
+}
+// bitwise comparison of two rows×cols blocks; one finding per launch at most
+__global__ void mk_cmp_kernel(const double* a, long lda, const double* b, long ldb, long rows, long cols, int* log, int code, int k, int blk) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const long total = rows * cols;
+    int first = -1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i - r * cols;
+        const unsigned long long va = ((const unsigned long long*)a)[r * lda + c], vb = ((const unsigned long long*)b)[r * ldb + c];
+        if (va != vb && first < 0) first = (int)i;
+    }
+    if (first >= 0) atomicAdd(&bad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) mk_log(log, code, k, blk, bad);
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -52,6 +94,7 @@ namespace {
 typedef void* ncclComm_t_;
 struct Rccl {
     void* h = nullptr;
+    std::string name;
     int (*CommInitAll)(ncclComm_t_*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t_) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -62,21 +105,32 @@ struct Rccl {
     bool ok = false;
     std::string err;
     bool load() {
-        if (h) return ok;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (h) break;
+        const char* over = getenv("GPMI_RCCL_LIB");  // tests: a stand-in library (tests/rccl_mock)
+        const std::string want = over ? over : "";
+        if (h && want == name) return ok;
+        ok = false;
+        err.clear();
+        name = want;
+        h = nullptr;
+        if (over) {
+            h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
         }
         if (!h) {
-            err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "?");
+            const char* de = dlerror();
+            err = std::string("dlopen(") + (over ? over : "librccl") + "): " + (de ? de : "?");
             h = (void*)1;
             return false;
         }
-#define GPMI_SYM(field, name)                                 \
-    field = (decltype(field))dlsym(h, name);                  \
+#define GPMI_SYM(field, sym)                                  \
+    field = (decltype(field))dlsym(h, sym);                   \
     if (!field) {                                             \
-        err = std::string("librccl lacks ") + name;           \
+        err = std::string("librccl lacks ") + sym;            \
         return false;                                         \
     }
         GPMI_SYM(CommInitAll, "ncclCommInitAll");
@@ -96,15 +150,61 @@ Rccl g_rccl;
 std::mutex g_rccl_mu;
 
 // ------------------------------------------------------------------------------------------------
-// cross-thread event: the producer rank records it on one of its streams and publishes the fit sequence number; a consumer
-// (another rank's host thread) waits for the publication on the HOST, then makes ITS stream wait for the event on the device
+// events.  Ev: an event of rank `owner` with index `id` into that rank's marker-flag array (trace name "r<owner>e<id>").
+// XEvent (cross-thread): the producer rank records it on one of its streams and publishes the fit sequence number; a consumer
+// (another rank's host thread) waits for the publication on the HOST, then makes ITS stream wait for the event on the device.
 // ------------------------------------------------------------------------------------------------
-struct XEvent {
+struct Ev {
     hipEvent_t ev = nullptr;
+    int owner = -1, id = -1;
+    const char* tag = "";  // what the event stands for (trace only)
+    long k = 0;
+};
+struct XEvent : Ev {
     std::atomic<long> gen{0};
 };
 
 constexpr long RHS_ROWS = 128;
+enum { SM = 0, SP = 1, SC = 2 };
+const char* const SNAME[3] = {"sm", "sp", "sc"};
+const char* const XTAG[4] = {"ready", "lkk", "accr", "alr"};
+
+// block footprint of an operation (block units; the checker expands it):
+//   A   : rank, local block rows [a0, a1) (fl & 2: plus the RHS block row; fl & 4: the RHS block row only), local block columns
+//         [b0, b1), fl & 1: only blocks on/below the global diagonal
+//   Ab / St : rank, slot a0, local block rows [b0, b1) (fl & 2: plus the RHS block row)
+//   Bb  : rank, slot a0, local block columns [b0, b1)
+//   Lkk : rank            acc : rank, local block columns [b0, b1)       alb : rank, global block b0       tmp : rank, slot b0
+struct Fp {
+    const char* buf;
+    int rank;
+    long a0, a1, b0, b1;
+    int fl;
+};
+
+struct Trace {
+    FILE* f = nullptr;
+    std::mutex mu;
+    void line(const std::string& s) {
+        std::lock_guard<std::mutex> l(mu);
+        if (f) {
+            fputs(s.c_str(), f);
+            fputc('\n', f);
+        }
+    }
+    static std::string fps(std::initializer_list<Fp> v) {
+        std::string s = "[";
+        bool first = true;
+        for (const Fp& p : v) {
+            if (!first) s += ",";
+            first = false;
+            char b[160];
+            snprintf(b, sizeof b, "[\"%s\",%d,%ld,%ld,%ld,%ld,%d]", p.buf, p.rank, p.a0, p.a1, p.b0, p.b1, p.fl);
+            s += b;
+        }
+        return s + "]";
+    }
+};
 
 }  // namespace
 
@@ -122,6 +222,8 @@ struct MRank {
     double* stage[4] = {nullptr, nullptr, nullptr, nullptr};
     double* acc = nullptr;       // backward sweep: per local column partial sums
     double* alpha_blk = nullptr; // backward sweep: α blocks computed by this rank (diagonal owner), indexed by global block
+    int* flags = nullptr;        // "multi_check": marker flags of this rank's events
+    int* log = nullptr;          // "multi_check": findings
     int32_t rc = 0;
     std::string err;
     double gemm_ms = 0, gemm_flops = 0;
@@ -140,7 +242,10 @@ struct gp_multi {
     long seq = 0;    // fit sequence number (XEvent generations)
     int copy_kernel = 0;  // block copies by copy2d_kernel instead of hipMemcpy2DAsync ("copy_kernel" parameter)
     int debug_sync = 0;   // diagnostic: host-synchronise the rank's streams after every exchange ("multi_debug_sync")
+    int check = 0;        // "multi_check" (see the header comment)
+    double timeout_s = 600;  // a rank thread that waits longer than this for a peer or for its own streams fails the fit
     std::string comm_note;
+    Trace* tr = nullptr;  // schedule trace of the running fit
 };
 
 struct gp_multi_post {
@@ -169,45 +274,137 @@ struct Dims {
         if (e_ != hipSuccess) return set_hip_err(e_, #expr, __LINE__);      \
     } while (0)
 
-// ---- helpers of one rank thread ---------------------------------------------------------------------------------
+using Clock = std::chrono::steady_clock;
+
+// ---- one rank thread's view of its streams: every operation of the schedule goes through here --------------------------
 struct RankRun {
     gp_multi* M;
     MRank* me;
     Dims dm;
     long seq;
+    bool dry;      // schedule trace only: no device, no HIP call
+    int check;
+    Trace* tr;
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
     size_t own_used = 0;
+    long nflags = 0;
 
-    int32_t own_event(hipEvent_t* out) {
+    int32_t own_event(Ev* out, const char* tag = "", long k = 0) {
+        out->owner = me->r;
+        out->tag = tag;
+        out->k = k;
+        out->id = (int)(4 * dm.nblk + (long)own_used);
+        if (dry) {
+            ++own_used;
+            out->ev = nullptr;
+            return 0;
+        }
         if (own_used == me->own.size()) {
             hipEvent_t e;
             MCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             me->own.push_back(e);
         }
-        *out = me->own[own_used++];
+        out->ev = me->own[own_used++];
         return 0;
     }
-    int32_t publish(XEvent& x, hipStream_t s) {
-        MCHK(hipEventRecord(x.ev, s));
+    // a traced stream operation: fn issues the device work on stream s (skipped in a dry run)
+    template <class F>
+    int32_t op(int s, const char* name, long k0, long k1, std::initializer_list<Fp> rd, std::initializer_list<Fp> wr, F&& fn) {
+        if (tr) {
+            char b[96];
+            snprintf(b, sizeof b, "{\"t\":\"op\",\"r\":%d,\"s\":\"%s\",\"n\":\"%s\",\"k\":[%ld,%ld],\"R\":", me->r, SNAME[s], name, k0, k1);
+            tr->line(std::string(b) + Trace::fps(rd) + ",\"W\":" + Trace::fps(wr) + "}");
+        }
+        if (dry) return 0;
+        return fn();
+    }
+    int32_t rec(int s, const Ev& e) {
+        if (tr) {
+            char b[160];
+            snprintf(b, sizeof b, "{\"t\":\"rec\",\"r\":%d,\"s\":\"%s\",\"e\":\"r%de%d\",\"tag\":\"%s\",\"k\":%ld}", me->r, SNAME[s], e.owner, e.id, e.tag, e.k);
+            tr->line(b);
+        }
+        if (dry) return 0;
+        if ((check & 1) && e.id < nflags) {
+            hipLaunchKernelGGL(mk_mark_kernel, dim3(1), dim3(1), 0, st[s], M->ranks[(size_t)e.owner].flags + e.id, (int)seq);
+            MCHK(hipGetLastError());
+        }
+        MCHK(hipEventRecord(e.ev, st[s]));
+        return 0;
+    }
+    int32_t wait(int s, const Ev& e) {
+        if (e.id < 0) return 0;  // never recorded
+        if (tr) {
+            char b[160];
+            snprintf(b, sizeof b, "{\"t\":\"wait\",\"r\":%d,\"s\":\"%s\",\"e\":\"r%de%d\",\"tag\":\"%s\",\"k\":%ld}", me->r, SNAME[s], e.owner, e.id, e.tag, e.k);
+            tr->line(b);
+        }
+        if (dry) return 0;
+        if (M->debug_sync & 4) MCHK(hipEventSynchronize(e.ev));
+        else MCHK(hipStreamWaitEvent(st[s], e.ev, 0));
+        if ((check & 1) && e.id < nflags) {
+            hipLaunchKernelGGL(mk_check_kernel, dim3(1), dim3(1), 0, st[s], M->ranks[(size_t)e.owner].flags + e.id, (int)seq, me->log, e.owner,
+                               e.id, s);
+            MCHK(hipGetLastError());
+        }
+        return 0;
+    }
+    int32_t publish(XEvent& x, int s) {
+        RC(rec(s, x));
         x.gen.store(seq, std::memory_order_release);
         return 0;
     }
     // make stream s of THIS rank wait for x of another rank's thread
-    int32_t await(XEvent& x, hipStream_t s) {
+    int32_t await(XEvent& x, int s) {
         long spins = 0;
+        const auto t0 = Clock::now();
         while (x.gen.load(std::memory_order_acquire) < seq) {
             if (M->abort.load(std::memory_order_relaxed)) return set_err_text(-1999, "multi-device fit aborted: another rank failed");
-            if (++spins > 64) std::this_thread::yield();
+            if (++spins > 64) {
+                std::this_thread::yield();
+                if ((spins & 1023) == 0 && std::chrono::duration<double>(Clock::now() - t0).count() > M->timeout_s) {
+                    char b[160];
+                    snprintf(b, sizeof b, "rank %d waited more than %.0f s for event r%de%d of a peer (host level)", me->r, M->timeout_s, x.owner, x.id);
+                    return set_err_text(-1993, b);
+                }
+            }
         }
-        if (M->debug_sync & 4) MCHK(hipEventSynchronize(x.ev));
-        else MCHK(hipStreamWaitEvent(s, x.ev, 0));
-        return 0;
+        return wait(s, x);
     }
     // 2-D block copy into one of my buffers from a buffer of rank src (possibly on another device), on my stream s
-    int32_t pull(hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols) {
+    int32_t pull(int s, double* dst, long dld, const double* src, long sld, long rows, long cols) {
         if (rows <= 0 || cols <= 0) return 0;
-        if (M->copy_kernel && !(cols & 1)) return eng_copy2d(me->c, s, dst, dld, src, sld, rows, cols);
-        MCHK(hipMemcpy2DAsync(dst, sizeof(double) * dld, src, sizeof(double) * sld, sizeof(double) * cols, rows, hipMemcpyDefault, s));
+        if (M->copy_kernel && !(cols & 1)) return eng_copy2d(me->c, st[s], dst, dld, src, sld, rows, cols);
+        MCHK(hipMemcpy2DAsync(dst, sizeof(double) * dld, src, sizeof(double) * sld, sizeof(double) * cols, rows, hipMemcpyDefault, st[s]));
         return 0;
+    }
+    // "multi_check" & 2: my copy of a block must equal the owner's final block (bitwise)
+    int32_t verify(int s, const double* mine, long mld, const double* theirs, long tld, long rows, long cols, int code, long k, long blk) {
+        if (!(check & 2) || dry || rows <= 0 || cols <= 0) return 0;
+        hipLaunchKernelGGL(mk_cmp_kernel, dim3((unsigned)std::min<long>(64, (rows * cols + 255) / 256)), dim3(256), 0, st[s], mine, mld, theirs, tld,
+                           rows, cols, me->log, code, (int)k, (int)blk);
+        MCHK(hipGetLastError());
+        return 0;
+    }
+    // wait (bounded) until stream s has drained
+    int32_t drain(int s) {
+        if (dry) return 0;
+        const auto t0 = Clock::now();
+        long polls = 0;
+        while (true) {
+            const hipError_t e = hipStreamQuery(st[s]);
+            if (e == hipSuccess) return 0;
+            if (e != hipErrorNotReady) return set_hip_err(e, "hipStreamQuery", __LINE__);
+            (void)hipGetLastError();
+            if (++polls > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            else std::this_thread::yield();
+            if ((polls & 255) == 0 && std::chrono::duration<double>(Clock::now() - t0).count() > M->timeout_s) {
+                char b[160];
+                snprintf(b, sizeof b, "rank %d: stream %s did not drain within %.0f s (device-level wait that never completes)", me->r, SNAME[s],
+                         M->timeout_s);
+                return set_err_text(-1992, b);
+            }
+        }
     }
 };
 
@@ -217,87 +414,143 @@ int32_t nccl_err(int rc, const char* what) {
 }
 #define NCHK(expr) RC(nccl_err((expr), #expr))
 
+// trace lines of the point-to-point transfers (RCCL matches the i-th send of a pair with the i-th receive of the peer)
+void tr_send(RankRun& rr, int s, int peer, long count, Fp f) {
+    if (!rr.tr) return;
+    char b[128];
+    snprintf(b, sizeof b, "{\"t\":\"send\",\"r\":%d,\"s\":\"%s\",\"to\":%d,\"n\":%ld,\"R\":", rr.me->r, SNAME[s], peer, count);
+    rr.tr->line(std::string(b) + Trace::fps({f}) + "}");
+}
+void tr_group(RankRun& rr, int s, int begin) {  // the transfers between the two lines form ONE group: unordered among themselves
+    if (!rr.tr) return;
+    char b[96];
+    snprintf(b, sizeof b, "{\"t\":\"grp\",\"r\":%d,\"s\":\"%s\",\"b\":%d}", rr.me->r, SNAME[s], begin);
+    rr.tr->line(b);
+}
+void tr_recv(RankRun& rr, int s, int peer, long count, Fp f) {
+    if (!rr.tr) return;
+    char b[128];
+    snprintf(b, sizeof b, "{\"t\":\"recv\",\"r\":%d,\"s\":\"%s\",\"from\":%d,\"n\":%ld,\"W\":", rr.me->r, SNAME[s], peer, count);
+    rr.tr->line(std::string(b) + Trace::fps({f}) + "}");
+}
+
 // The whole pair on one rank.  Y-columns ride as RHS rows; alpha (column 0) only when want_alpha.
-int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double variance, const double* xs_h, const double* noise_h,
+// dry: only the schedule (operations, events, footprints) is produced — the same control flow, no device.
+int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, double variance, const double* xs_h, const double* noise_h,
                  const double* rhs_h /* ncols × npad */, int ncols, bool want_alpha, bool keep, double* alpha_host /* npad, pinned */,
-                 double* scal_out /* [0] Σlog L_ii, [1] unused, [8+s] ‖z_s‖² partial */, int* info_out, DevBufs& bufs, long seq) {
+                 double* scal_out /* [0] Σlog L_ii, [1] unused, [8+s] ‖z_s‖² partial */, int* info_out, DevBufs* bufs, long seq) {
     const int P = M->P, Q = M->Q, p = me->p, q = me->q, depth = M->depth;
     const long NB = dm.NB, nblk = dm.nblk, npad = dm.npad, n = dm.n, LDP = dm.LDP;
     const long nlb_r = dm.nlb_r, nlb_c = dm.nlb_c;
     const bool rhs_row = (p == 0);
+    const int RHSF = rhs_row ? 2 : 0;  // footprint flag: the RHS block row rides along
     const long m_loc = nlb_r * NB + (rhs_row ? RHS_ROWS : 0), n_loc = nlb_c * NB;
     const long ld = n_loc + 32;
     const int NBUF = depth + 1;
+    const int R_ = me->r;
     gp_ctx* c = me->c;
-    hipStream_t sm = c->sm, sp = c->sp, sc = me->sc;
-    RankRun rr{M, me, dm, seq};
-    MCHK(hipSetDevice(me->device));
+    RankRun rr{M, me, dm, seq, dry, dry ? 0 : M->check, M->tr};
+    if (!dry) {
+        rr.st[SM] = c->sm;
+        rr.st[SP] = c->sp;
+        rr.st[SC] = me->sc;
+        MCHK(hipSetDevice(me->device));
+        c->ev_used = 0;
+        c->gemm_recs.clear();
+        if (!c->info_dev) MCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+        RC(ctx_scal(c, 8 + RHS_ROWS));
+    }
+    hipStream_t sm = rr.st[SM], sp = rr.st[SP], sc = rr.st[SC];
     const bool rccl = (M->comm == 1);
-    c->ev_used = 0;
-    c->gemm_recs.clear();
-    if (!c->info_dev) MCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
-    RC(ctx_scal(c, 8 + RHS_ROWS));
+    const int check = rr.check;
 
     // ---- buffers
-    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0;
+    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0;
     void* Ab_v[4] = {0, 0, 0, 0};
     void* Bb_v[4] = {0, 0, 0, 0};
     void* St_v[4] = {0, 0, 0, 0};
     const size_t A_b = sizeof(double) * (size_t)(m_loc + 128) * ld;
-    RC(bufs.get(A_b, &A_v));
-    RC(bufs.get(sizeof(double) * (size_t)dm.d * npad, &xs_v));
-    RC(bufs.get(sizeof(double) * (size_t)npad, &nz_v));
-    RC(bufs.get(sizeof(double) * (size_t)(NB + 128) * LDP, &Lkk_v));
-    RC(bufs.get(sizeof(double) * (size_t)(n_loc + 128), &acc_v));
-    RC(bufs.get(sizeof(double) * (size_t)npad, &ab_v));
-    RC(bufs.get(sizeof(double) * (size_t)NB * (P + 1), &tmp_v));
-    for (int s = 0; s < NBUF; ++s) {
-        if (Q > 1) RC(bufs.get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &Ab_v[s]));
-        RC(bufs.get(sizeof(double) * (size_t)(n_loc + 128) * LDP, &Bb_v[s]));
-        if (rccl) RC(bufs.get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &St_v[s]));
+    const long own_cap = 10 * nblk + 64;
+    rr.nflags = 4 * nblk + own_cap;
+    if (!dry) {
+        RC(bufs->get(A_b, &A_v));
+        RC(bufs->get(sizeof(double) * (size_t)dm.d * npad, &xs_v));
+        RC(bufs->get(sizeof(double) * (size_t)npad, &nz_v));
+        RC(bufs->get(sizeof(double) * (size_t)(NB + 128) * LDP, &Lkk_v));
+        RC(bufs->get(sizeof(double) * (size_t)(n_loc + 128), &acc_v));
+        RC(bufs->get(sizeof(double) * (size_t)npad, &ab_v));
+        RC(bufs->get(sizeof(double) * (size_t)NB * (P + 1), &tmp_v));
+        for (int s = 0; s < NBUF; ++s) {
+            if (Q > 1) RC(bufs->get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &Ab_v[s]));
+            RC(bufs->get(sizeof(double) * (size_t)(n_loc + 128) * LDP, &Bb_v[s]));
+            if (rccl) RC(bufs->get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &St_v[s]));
+        }
+        if (check) RC(bufs->get(sizeof(int) * (size_t)(rr.nflags + 256), &chk_v));
     }
     double* A = (double*)A_v;
     me->A = A; me->ld = ld; me->m_loc = m_loc; me->n_loc = n_loc;
     me->Lkk = (double*)Lkk_v;
     me->acc = (double*)acc_v;
     me->alpha_blk = (double*)ab_v;
+    me->flags = (int*)chk_v;
+    me->log = chk_v ? (int*)chk_v + rr.nflags : nullptr;
     for (int s = 0; s < 4; ++s) me->stage[s] = (double*)St_v[s];
 
     GridMap g = plain_map(1, 0, 0);
     g.P = P; g.p = p; g.Q = Q; g.q = q; g.nb = NB;
 
-    auto rows_from = [&](long gblk, int pp) { return nlb_before(gblk - 1, pp, P) * NB; };  // first local row (process row pp) with global block >= gblk
+    auto lrow_from = [&](long gblk, int pp) { return nlb_before(gblk - 1, pp, P); };          // first local block row (process row pp) with global block >= gblk
+    auto rows_from = [&](long gblk, int pp) { return nlb_before(gblk - 1, pp, P) * NB; };     // ... as a row index
     auto mloc_of = [&](int pp) { return nlb_r * NB + (pp == 0 ? RHS_ROWS : 0); };
-    auto cols_from = [&](long gblk) { return nlb_before(gblk - 1, q, Q) * NB; };             // first local column with global block >= gblk
+    auto lcol_from = [&](long gblk) { return nlb_before(gblk - 1, q, Q); };                   // first local block column with global block >= gblk
     auto rank_of = [&](int pp, int qq) -> MRank& { return M->ranks[(size_t)pp * Q + qq]; };
+    auto rrank = [&](int pp, int qq) { return pp * Q + qq; };
 
-    // ---- upload + assemble
-    MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)dm.d * npad, hipMemcpyHostToDevice, sm));
-    MCHK(hipMemcpyAsync(nz_v, noise_h, sizeof(double) * (size_t)npad, hipMemcpyHostToDevice, sm));
-    MCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), sm));
-    MCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * (8 + RHS_ROWS), sm));
-    MCHK(hipMemsetAsync(acc_v, 0, sizeof(double) * (size_t)(n_loc + 128), sm));
-    MCHK(hipMemsetAsync(A + nlb_r * NB * ld, 0, sizeof(double) * (size_t)(m_loc - nlb_r * NB + 128) * ld, sm));  // RHS + slack rows
-    for (int s = 0; s < NBUF; ++s) {  // slack rows of the operand buffers are over-read by the GEMM: keep them finite
-        if (Ab_v[s]) MCHK(hipMemsetAsync(Ab_v[s], 0, sizeof(double) * (size_t)(m_loc + 128) * LDP, sm));
-        MCHK(hipMemsetAsync(Bb_v[s], 0, sizeof(double) * (size_t)(n_loc + 128) * LDP, sm));
-        if (St_v[s]) MCHK(hipMemsetAsync(St_v[s], 0, sizeof(double) * (size_t)(m_loc + 128) * LDP, sm));
-    }
-    MCHK(hipMemsetAsync(Lkk_v, 0, sizeof(double) * (size_t)(NB + 128) * LDP, sm));
-    RC(eng_assemble(c, sm, kind, variance, (const double*)xs_v, n, npad, dm.d, (const double*)nz_v, g, A, ld, nlb_r * NB, n_loc));
-    if (rhs_row) {  // RHS rows: δ_sᵀ restricted to my local columns (global block lj·Q + q)
-        for (int s = 0; s < ncols; ++s)
-            for (long lj = 0; lj < nlb_c; ++lj)
-                MCHK(hipMemcpyAsync(A + (nlb_r * NB + s) * ld + lj * NB, rhs_h + (size_t)s * npad + (lj * Q + q) * NB, sizeof(double) * NB,
-                                    hipMemcpyHostToDevice, sm));
-    }
-    hipEvent_t ev_asm;
-    RC(rr.own_event(&ev_asm));
-    MCHK(hipEventRecord(ev_asm, sm));
-    MCHK(hipStreamWaitEvent(sp, ev_asm, 0));
-    MCHK(hipStreamWaitEvent(sc, ev_asm, 0));
+    // ---- upload + assemble (one traced operation: everything below is issued back to back on the main stream)
+    RC(rr.op(SM, "init", 0, 0, {},
+             {Fp{"A", R_, 0, nlb_r, 0, nlb_c, RHSF}, Fp{"Ab", R_, 0, NBUF, 0, nlb_r, 2}, Fp{"Bb", R_, 0, NBUF, 0, nlb_c, 0},
+              Fp{"St", R_, 0, NBUF, 0, nlb_r, 2}, Fp{"Lkk", R_, 0, 0, 0, 0, 0}, Fp{"acc", R_, 0, 0, 0, nlb_c, 0}},
+             [&]() -> int32_t {
+                 MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)dm.d * npad, hipMemcpyHostToDevice, sm));
+                 MCHK(hipMemcpyAsync(nz_v, noise_h, sizeof(double) * (size_t)npad, hipMemcpyHostToDevice, sm));
+                 MCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), sm));
+                 MCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * (8 + RHS_ROWS), sm));
+                 MCHK(hipMemsetAsync(acc_v, 0, sizeof(double) * (size_t)(n_loc + 128), sm));
+                 MCHK(hipMemsetAsync(A + nlb_r * NB * ld, 0, sizeof(double) * (size_t)(m_loc - nlb_r * NB + 128) * ld, sm));  // RHS + slack rows
+                 if (chk_v) MCHK(hipMemsetAsync(chk_v, 0, sizeof(int) * (size_t)(rr.nflags + 256), sm));
+                 // operand buffers: the 128 slack rows are over-read by the GEMM and must stay finite; the payload rows are zero, or NaN
+                 // under "multi_check" & 4 so that a read before arrival cannot pass as a plausible number
+                 const int fill = (check & 4) ? 0xFF : 0;
+                 for (int s = 0; s < NBUF; ++s) {
+                     if (Ab_v[s]) {
+                         MCHK(hipMemsetAsync(Ab_v[s], fill, sizeof(double) * (size_t)m_loc * LDP, sm));
+                         MCHK(hipMemsetAsync((double*)Ab_v[s] + m_loc * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
+                     }
+                     MCHK(hipMemsetAsync(Bb_v[s], fill, sizeof(double) * (size_t)n_loc * LDP, sm));
+                     MCHK(hipMemsetAsync((double*)Bb_v[s] + n_loc * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
+                     if (St_v[s]) {
+                         MCHK(hipMemsetAsync(St_v[s], fill, sizeof(double) * (size_t)m_loc * LDP, sm));
+                         MCHK(hipMemsetAsync((double*)St_v[s] + m_loc * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
+                     }
+                 }
+                 MCHK(hipMemsetAsync(Lkk_v, fill, sizeof(double) * (size_t)NB * LDP, sm));
+                 MCHK(hipMemsetAsync((double*)Lkk_v + NB * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
+                 RC(eng_assemble(c, sm, kind, variance, (const double*)xs_v, n, npad, dm.d, (const double*)nz_v, g, A, ld, nlb_r * NB, n_loc));
+                 if (rhs_row) {  // RHS rows: δ_sᵀ restricted to my local columns (global block lj·Q + q)
+                     for (int s = 0; s < ncols; ++s)
+                         for (long lj = 0; lj < nlb_c; ++lj)
+                             MCHK(hipMemcpyAsync(A + (nlb_r * NB + s) * ld + lj * NB, rhs_h + (size_t)s * npad + (lj * Q + q) * NB, sizeof(double) * NB,
+                                                 hipMemcpyHostToDevice, sm));
+                 }
+                 return 0;
+             }));
+    Ev ev_asm;
+    RC(rr.own_event(&ev_asm, "assembled"));
+    RC(rr.rec(SM, ev_asm));
+    RC(rr.wait(SP, ev_asm));
+    RC(rr.wait(SC, ev_asm));
 
-    std::vector<hipEvent_t> arrived((size_t)nblk, nullptr), bulk_done((size_t)nblk, nullptr), la_done((size_t)nblk, nullptr);
+    std::vector<Ev> arrived((size_t)nblk), bulk_done((size_t)nblk), la_done((size_t)nblk);
 
     // A operand of panel i for my rows: my own matrix columns when I sit in the owner column, else the fetched copy
     auto a_operand = [&](long i, const double** ptr, long* lda) {
@@ -310,96 +563,135 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         }
     };
     // C[rows >= global block gr0, local columns [c_lo, c_hi)] -= panel_i(rows) · panel_i(cols)ᵀ   (lower part only)
-    auto update = [&](hipStream_t s, long i, long gr0, long c_lo, long c_hi) -> int32_t {
+    auto update = [&](int s, const char* name, long j, long i, long gr0, long c_lo, long c_hi) -> int32_t {
         const long r0 = rows_from(gr0, p);
         const long mrows = m_loc - r0, ncolsu = c_hi - c_lo;
         if (mrows <= 0 || ncolsu <= 0) return 0;
-        const double* ap;
-        long lda;
-        a_operand(i, &ap, &lda);
-        GridMap gm = g;
-        gm.row0 = r0;
-        gm.col0 = c_lo;
-        const size_t before = c->gemm_recs.size();
-        RC(eng_gemm_nt(c, s, A + r0 * ld + c_lo, ld, ap + r0 * lda, lda, (const double*)Bb_v[i % NBUF] + c_lo * LDP, LDP, mrows, ncolsu, NB, gm));
-        if (c->gemm_recs.size() > before) {  // exact algorithmic flops of this launch: local elements on/below the global diagonal × 2·NB
-            double cnt = 0;
-            for (long lj = c_lo / NB; lj < c_hi / NB; ++lj) {
-                const long gj = lj * Q + q;
-                for (long li = r0 / NB; li < nlb_r; ++li) {
-                    const long gi = li * P + p;
-                    cnt += gi > gj ? (double)NB * NB : (gi == gj ? (double)NB * (NB + 1) / 2 : 0.0);
+        const long lr0 = r0 / NB, lc0 = c_lo / NB, lc1 = c_hi / NB;
+        const int slot = (int)(i % NBUF);
+        const bool own_col = (q == (int)(i % Q));
+        const Fp fa = own_col ? Fp{"A", R_, lr0, nlb_r, i / Q, i / Q + 1, RHSF} : Fp{"Ab", R_, slot, slot + 1, lr0, nlb_r, RHSF};
+        const Fp fc = Fp{"A", R_, lr0, nlb_r, lc0, lc1, 1 | RHSF};
+        return rr.op(s, name, j, i, {fa, Fp{"Bb", R_, slot, slot + 1, lc0, lc1, 0}, fc}, {fc}, [&]() -> int32_t {
+            const double* ap;
+            long lda;
+            a_operand(i, &ap, &lda);
+            const double* Bb = (const double*)Bb_v[slot];
+            if (check & 2) {  // the operands this GEMM is about to read vs the owners' final panel blocks
+                const int qi = (int)(i % Q);
+                if (!own_col) {
+                    MRank& src = rank_of(p, qi);
+                    RC(rr.verify(s, ap + r0 * lda, lda, src.A + r0 * src.ld + (i / Q) * NB, src.ld, mrows, NB, 2, i, -1));
                 }
-                if (rhs_row) cnt += (double)RHS_ROWS * NB;
+                for (long lj = lc0; lj < lc1; ++lj) {
+                    const long gj = lj * Q + q;
+                    MRank& src = rank_of((int)(gj % P), qi);
+                    RC(rr.verify(s, Bb + lj * NB * LDP, LDP, src.A + (gj / P) * NB * src.ld + (i / Q) * NB, src.ld, NB, NB, 3, i, lj));
+                }
             }
-            c->gemm_recs.back().flops = 2.0 * NB * cnt;
-        }
-        return 0;
+            GridMap gm = g;
+            gm.row0 = r0;
+            gm.col0 = c_lo;
+            const size_t before = c->gemm_recs.size();
+            RC(eng_gemm_nt(c, rr.st[s], A + r0 * ld + c_lo, ld, ap + r0 * lda, lda, Bb + c_lo * LDP, LDP, mrows, ncolsu, NB, gm));
+            if (c->gemm_recs.size() > before) {  // exact algorithmic flops of this launch: local elements on/below the global diagonal × 2·NB
+                double cnt = 0;
+                for (long lj = lc0; lj < lc1; ++lj) {
+                    const long gj = lj * Q + q;
+                    for (long li = lr0; li < nlb_r; ++li) {
+                        const long gi = li * P + p;
+                        cnt += gi > gj ? (double)NB * NB : (gi == gj ? (double)NB * (NB + 1) / 2 : 0.0);
+                    }
+                    if (rhs_row) cnt += (double)RHS_ROWS * NB;
+                }
+                c->gemm_recs.back().flops = 2.0 * NB * cnt;
+            }
+            return 0;
+        });
     };
 
-    hipEvent_t lkk_free = nullptr;  // RCCL: my L_kk image may be overwritten again after this event
+    Ev lkk_free;  // RCCL: my L_kk image may be overwritten again after this event
     // factor block column k on its owners (panel stream) and publish it
     auto panel = [&](long k) -> int32_t {
         const int pk = (int)(k % P), qk = (int)(k % Q);
         if (q != qk) return 0;
-        const long c0 = (k / Q) * NB;
+        const long c0 = (k / Q) * NB, lc = k / Q;
         if (P == 1) {
             const long r0 = k * NB;  // (k / P) * NB
-            RC(eng_potrf(c, sp, A + r0 * ld + c0, ld, m_loc - r0, NB, c->info_dev, k * NB, n, c->scal_dev));
+            const Fp f = Fp{"A", R_, k, nlb_r, lc, lc + 1, RHSF};
+            RC(rr.op(SP, "potrf", k, 0, {f}, {f}, [&]() { return eng_potrf(c, sp, A + r0 * ld + c0, ld, m_loc - r0, NB, c->info_dev, k * NB, n, c->scal_dev); }));
         } else {
-            const double* lkk_ptr;
-            long lkk_ld;
+            const double* lkk_ptr = nullptr;
+            long lkk_ld = 0;
+            Fp f_l;
             // (RCCL: every collective of a rank is issued on ITS comm stream, in the same global order on all ranks — L_kk(k),
             //  then exchange(k) — and chained to the panel stream by events)
             if (p == pk) {
                 const long r0 = (k / P) * NB;
-                RC(eng_potrf(c, sp, A + r0 * ld + c0, ld, NB, NB, c->info_dev, k * NB, n, c->scal_dev));
+                const Fp fd = Fp{"A", R_, k / P, k / P + 1, lc, lc + 1, 0};
+                RC(rr.op(SP, "potrf_diag", k, 0, {fd}, {fd}, [&]() { return eng_potrf(c, sp, A + r0 * ld + c0, ld, NB, NB, c->info_dev, k * NB, n, c->scal_dev); }));
                 lkk_ptr = A + r0 * ld + c0;
                 lkk_ld = ld;
+                f_l = fd;
                 if (rccl) {  // contiguous image for the sends
-                    if (lkk_free) MCHK(hipStreamWaitEvent(sp, lkk_free, 0));
-                    RC(rr.pull(sp, me->Lkk, LDP, lkk_ptr, ld, NB, NB));
-                    hipEvent_t e;
-                    RC(rr.own_event(&e));
-                    MCHK(hipEventRecord(e, sp));
-                    MCHK(hipStreamWaitEvent(sc, e, 0));
-                    NCHK(g_rccl.GroupStart());
+                    RC(rr.wait(SP, lkk_free));
+                    RC(rr.op(SP, "lkk_image", k, 0, {fd}, {Fp{"Lkk", R_, 0, 0, 0, 0, 0}}, [&]() { return rr.pull(SP, me->Lkk, LDP, lkk_ptr, ld, NB, NB); }));
+                    Ev e;
+                    RC(rr.own_event(&e, "lkk_image", k));
+                    RC(rr.rec(SP, e));
+                    RC(rr.wait(SC, e));
+                    tr_group(rr, SC, 1);
+                    if (!dry) NCHK(g_rccl.GroupStart());
                     for (int pp = 0; pp < P; ++pp)
-                        if (pp != pk) NCHK(g_rccl.Send(me->Lkk, (size_t)NB * LDP, NCCL_FLOAT64, rank_of(pp, qk).r, me->comm, sc));
-                    NCHK(g_rccl.GroupEnd());
-                    RC(rr.own_event(&lkk_free));
-                    MCHK(hipEventRecord(lkk_free, sc));
+                        if (pp != pk) {
+                            tr_send(rr, SC, rrank(pp, qk), (long)NB * LDP, Fp{"Lkk", R_, 0, 0, 0, 0, 0});
+                            if (!dry) NCHK(g_rccl.Send(me->Lkk, (size_t)NB * LDP, NCCL_FLOAT64, rank_of(pp, qk).r, me->comm, sc));
+                        }
+                    if (!dry) NCHK(g_rccl.GroupEnd());
+                    tr_group(rr, SC, 0);
+                    RC(rr.own_event(&lkk_free, "lkk_free", k));
+                    RC(rr.rec(SC, lkk_free));
                 }
-                RC(rr.publish(me->lkk[k], sp));
+                RC(rr.publish(me->lkk[k], SP));
             } else {
                 MRank& own = rank_of(pk, qk);
                 if (rccl) {
-                    if (lkk_free) MCHK(hipStreamWaitEvent(sc, lkk_free, 0));  // the previous L_kk image has been consumed by my trsm
-                    NCHK(g_rccl.Recv(me->Lkk, (size_t)NB * LDP, NCCL_FLOAT64, own.r, me->comm, sc));
-                    hipEvent_t e;
-                    RC(rr.own_event(&e));
-                    MCHK(hipEventRecord(e, sc));
-                    MCHK(hipStreamWaitEvent(sp, e, 0));
+                    RC(rr.wait(SC, lkk_free));  // the previous L_kk image has been consumed by my trsm
+                    tr_recv(rr, SC, own.r, (long)NB * LDP, Fp{"Lkk", R_, 0, 0, 0, 0, 0});
+                    if (!dry) NCHK(g_rccl.Recv(me->Lkk, (size_t)NB * LDP, NCCL_FLOAT64, own.r, me->comm, sc));
+                    Ev e;
+                    RC(rr.own_event(&e, "lkk_recv", k));
+                    RC(rr.rec(SC, e));
+                    RC(rr.wait(SP, e));
                 } else {
-                    RC(rr.await(own.lkk[k], sp));
-                    RC(rr.pull(sp, me->Lkk, LDP, own.A + (k / P) * NB * own.ld + c0, own.ld, NB, NB));
+                    RC(rr.await(own.lkk[k], SP));
+                    RC(rr.op(SP, "pull_lkk", k, 0, {Fp{"A", own.r, k / P, k / P + 1, lc, lc + 1, 0}}, {Fp{"Lkk", R_, 0, 0, 0, 0, 0}},
+                             [&]() { return rr.pull(SP, me->Lkk, LDP, own.A + (k / P) * NB * own.ld + c0, own.ld, NB, NB); }));
                 }
                 lkk_ptr = me->Lkk;
                 lkk_ld = LDP;
+                f_l = Fp{"Lkk", R_, 0, 0, 0, 0, 0};
             }
             const long r0b = rows_from(k + 1, p);
-            if (m_loc - r0b > 0) RC(eng_trsm(c, sp, A + r0b * ld + c0, ld, m_loc - r0b, lkk_ptr, lkk_ld, NB));
+            if (m_loc - r0b > 0) {
+                const Fp fx = Fp{"A", R_, r0b / NB, nlb_r, lc, lc + 1, RHSF};
+                RC(rr.op(SP, "trsm", k, 0, {fx, f_l}, {fx}, [&]() { return eng_trsm(c, sp, A + r0b * ld + c0, ld, m_loc - r0b, lkk_ptr, lkk_ld, NB); }));
+            }
             if (rccl && p != pk) {
-                RC(rr.own_event(&lkk_free));
-                MCHK(hipEventRecord(lkk_free, sp));
+                RC(rr.own_event(&lkk_free, "lkk_free", k));
+                RC(rr.rec(SP, lkk_free));
             }
         }
         if (rccl) {  // contiguous image of my piece (rows below k, all of them incl. RHS rows) for the sends of exchange(k)
             const long r0b = rows_from(k + 1, p);
-            RC(rr.pull(sp, me->stage[k % NBUF] + r0b * LDP, LDP, A + r0b * ld + c0, ld, m_loc - r0b, NB));
+            if (m_loc - r0b > 0) {
+                const int slot = (int)(k % NBUF);
+                RC(rr.op(SP, "stage", k, 0, {Fp{"A", R_, r0b / NB, nlb_r, lc, lc + 1, RHSF}}, {Fp{"St", R_, slot, slot + 1, r0b / NB, nlb_r, RHSF}},
+                         [&]() { return rr.pull(SP, me->stage[slot] + r0b * LDP, LDP, A + r0b * ld + c0, ld, m_loc - r0b, NB); }));
+            }
         }
-        RC(rr.publish(me->ready[k], sp));
-        if (M->debug_sync & 8) MCHK(hipStreamSynchronize(sp));
+        RC(rr.publish(me->ready[k], SP));
+        if (!dry && (M->debug_sync & 8)) MCHK(hipStreamSynchronize(sp));
         return 0;
     };
 
@@ -407,22 +699,26 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
     auto exchange = [&](long k) -> int32_t {
         const int qk = (int)(k % Q);
         const int s = (int)(k % NBUF);
+        const long lc = k / Q;
         if (k - NBUF >= 0) {  // the set's previous panel must have been consumed
-            if (bulk_done[k - NBUF]) MCHK(hipStreamWaitEvent(sc, bulk_done[k - NBUF], 0));
-            if (la_done[k - NBUF]) MCHK(hipStreamWaitEvent(sc, la_done[k - NBUF], 0));
+            RC(rr.wait(SC, bulk_done[k - NBUF]));
+            RC(rr.wait(SC, la_done[k - NBUF]));
         }
         double* Ab = (double*)Ab_v[s];
         double* Bb = (double*)Bb_v[s];
         // my own piece of panel k (when I sit in the owner column) is read straight from my matrix by my updates: arrived[k]
         // must therefore also cover MY panel-stream work — with gcd(P, Q) > 1 a rank may fetch nothing from itself below
-        if (q == qk) MCHK(hipStreamWaitEvent(sc, me->ready[k].ev, 0));
+        if (q == qk) RC(rr.wait(SC, me->ready[k]));
         if (!rccl) {
             // A part: my process row's piece, rows in local row order (nothing to fetch when I own the column)
             if (q != qk) {
                 MRank& src = rank_of(p, qk);
                 const long r0 = rows_from(k + 1, p);
-                RC(rr.await(src.ready[k], sc));
-                RC(rr.pull(sc, Ab + r0 * LDP, LDP, src.A + r0 * src.ld + (k / Q) * NB, src.ld, m_loc - r0, NB));
+                if (m_loc - r0 > 0) {
+                    RC(rr.await(src.ready[k], SC));
+                    RC(rr.op(SC, "pullA", k, 0, {Fp{"A", src.r, r0 / NB, nlb_r, lc, lc + 1, RHSF}}, {Fp{"Ab", R_, s, s + 1, r0 / NB, nlb_r, RHSF}},
+                             [&]() { return rr.pull(SC, Ab + r0 * LDP, LDP, src.A + r0 * src.ld + lc * NB, src.ld, m_loc - r0, NB); }));
+                }
             }
             // B part: the global blocks of my process column, rows in local column order
             for (int pp = 0; pp < P; ++pp) {
@@ -432,50 +728,65 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
                     const long gj = lj * Q + q;
                     if ((int)(gj % P) != pp) continue;
                     if (!waited) {
-                        RC(rr.await(src.ready[k], sc));
+                        RC(rr.await(src.ready[k], SC));
                         waited = true;
                     }
-                    RC(rr.pull(sc, Bb + lj * NB * LDP, LDP, src.A + (gj / P) * NB * src.ld + (k / Q) * NB, src.ld, NB, NB));
+                    RC(rr.op(SC, "pullB", k, lj, {Fp{"A", src.r, gj / P, gj / P + 1, lc, lc + 1, 0}}, {Fp{"Bb", R_, s, s + 1, lj, lj + 1, 0}},
+                             [&]() { return rr.pull(SC, Bb + lj * NB * LDP, LDP, src.A + (gj / P) * NB * src.ld + lc * NB, src.ld, NB, NB); }));
                 }
             }
         } else {
             // the same transfers as matched ncclSend / ncclRecv pairs of ONE group per rank (all peers progress concurrently);
             // both sides enumerate (source process row, destination rank, block) in the same order
-            NCHK(g_rccl.GroupStart());
+            tr_group(rr, SC, 1);
+            if (!dry) NCHK(g_rccl.GroupStart());
             for (int pp = 0; pp < P; ++pp) {
                 MRank& src = rank_of(pp, qk);
                 const long r0s = rows_from(k + 1, pp), ms = mloc_of(pp);
+                const int srhs = pp == 0 ? 2 : 0;
                 for (int dp = 0; dp < P; ++dp)
                     for (int dq = 0; dq < Q; ++dq) {
                         MRank& dst = rank_of(dp, dq);
                         const bool i_send = (&src == me), i_recv = (&dst == me);
                         if (!i_send && !i_recv) continue;
                         if (dp == pp && dq != qk && ms - r0s > 0) {  // A part
-                            if (i_send) NCHK(g_rccl.Send(me->stage[s] + r0s * LDP, (size_t)(ms - r0s) * LDP, NCCL_FLOAT64, dst.r, me->comm, sc));
-                            if (i_recv) NCHK(g_rccl.Recv(Ab + r0s * LDP, (size_t)(ms - r0s) * LDP, NCCL_FLOAT64, src.r, me->comm, sc));
+                            if (i_send) {
+                                tr_send(rr, SC, dst.r, (ms - r0s) * LDP, Fp{"St", R_, s, s + 1, r0s / NB, nlb_r, srhs});
+                                if (!dry) NCHK(g_rccl.Send(me->stage[s] + r0s * LDP, (size_t)(ms - r0s) * LDP, NCCL_FLOAT64, dst.r, me->comm, sc));
+                            }
+                            if (i_recv) {
+                                tr_recv(rr, SC, src.r, (ms - r0s) * LDP, Fp{"Ab", R_, s, s + 1, r0s / NB, nlb_r, srhs});
+                                if (!dry) NCHK(g_rccl.Recv(Ab + r0s * LDP, (size_t)(ms - r0s) * LDP, NCCL_FLOAT64, src.r, me->comm, sc));
+                            }
                         }
                         for (long lj = nlb_before(k, dq, Q); lj < nlb_c; ++lj) {  // B part
                             const long gj = lj * Q + dq;
                             if ((int)(gj % P) != pp) continue;
                             const long srow = (gj / P) * NB;
                             if (i_send && i_recv) {
-                                RC(rr.pull(sc, Bb + lj * NB * LDP, LDP, me->stage[s] + srow * LDP, LDP, NB, NB));
+                                RC(rr.op(SC, "selfB", k, lj, {Fp{"St", R_, s, s + 1, gj / P, gj / P + 1, 0}}, {Fp{"Bb", R_, s, s + 1, lj, lj + 1, 0}},
+                                         [&]() { return rr.pull(SC, Bb + lj * NB * LDP, LDP, me->stage[s] + srow * LDP, LDP, NB, NB); }));
                             } else if (i_send) {
-                                NCHK(g_rccl.Send(me->stage[s] + srow * LDP, (size_t)NB * LDP, NCCL_FLOAT64, dst.r, me->comm, sc));
+                                tr_send(rr, SC, dst.r, NB * LDP, Fp{"St", R_, s, s + 1, gj / P, gj / P + 1, 0});
+                                if (!dry) NCHK(g_rccl.Send(me->stage[s] + srow * LDP, (size_t)NB * LDP, NCCL_FLOAT64, dst.r, me->comm, sc));
                             } else {
-                                NCHK(g_rccl.Recv(Bb + lj * NB * LDP, (size_t)NB * LDP, NCCL_FLOAT64, src.r, me->comm, sc));
+                                tr_recv(rr, SC, src.r, NB * LDP, Fp{"Bb", R_, s, s + 1, lj, lj + 1, 0});
+                                if (!dry) NCHK(g_rccl.Recv(Bb + lj * NB * LDP, (size_t)NB * LDP, NCCL_FLOAT64, src.r, me->comm, sc));
                             }
                         }
                     }
             }
-            NCHK(g_rccl.GroupEnd());
+            if (!dry) NCHK(g_rccl.GroupEnd());
+            tr_group(rr, SC, 0);
         }
-        RC(rr.own_event(&arrived[k]));
-        MCHK(hipEventRecord(arrived[k], sc));
-        if (M->debug_sync & 1) MCHK(hipStreamSynchronize(sc));
-        if (M->debug_sync & 2) {
-            MCHK(hipStreamSynchronize(sp));
-            MCHK(hipStreamSynchronize(sm));
+        RC(rr.own_event(&arrived[k], "arrived", k));
+        RC(rr.rec(SC, arrived[k]));
+        if (!dry) {
+            if (M->debug_sync & 1) MCHK(hipStreamSynchronize(sc));
+            if (M->debug_sync & 2) {
+                MCHK(hipStreamSynchronize(sp));
+                MCHK(hipStreamSynchronize(sm));
+            }
         }
         return 0;
     };
@@ -483,11 +794,11 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
     // look-ahead update of block column j with panel i on the panel stream
     auto la_update = [&](long j, long i) -> int32_t {
         if (q != (int)(j % Q)) return 0;
-        MCHK(hipStreamWaitEvent(sp, arrived[i], 0));
+        RC(rr.wait(SP, arrived[i]));
         const long first = std::max(0L, j - depth);
-        if (i == first && first - 1 >= 0 && bulk_done[first - 1]) MCHK(hipStreamWaitEvent(sp, bulk_done[first - 1], 0));
+        if (i == first && first - 1 >= 0) RC(rr.wait(SP, bulk_done[first - 1]));
         const long c0 = (j / Q) * NB;
-        return update(sp, i, j, c0, c0 + NB);
+        return update(SP, "la", j, i, j, c0, c0 + NB);
     };
 
     RC(panel(0));
@@ -499,31 +810,29 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
             RC(exchange(k + 1));
             for (long j = k + 2; j <= std::min(k + depth, nblk - 1); ++j) RC(la_update(j, k));
         }
-        RC(rr.own_event(&la_done[k]));
-        MCHK(hipEventRecord(la_done[k], sp));
+        RC(rr.own_event(&la_done[k], "la_done", k));
+        RC(rr.rec(SP, la_done[k]));
         // bulk of the trailing update: every local column right of the look-ahead window
-        MCHK(hipStreamWaitEvent(sm, arrived[k], 0));
+        RC(rr.wait(SM, arrived[k]));
         const long gfirst = k + depth + 1;
-        if (gfirst < nblk) RC(update(sm, k, gfirst, cols_from(gfirst), n_loc));
-        else if (rhs_row) {
-            // no matrix columns left, nothing to do (RHS rows were updated with their columns)
-        }
-        RC(rr.own_event(&bulk_done[k]));
-        MCHK(hipEventRecord(bulk_done[k], sm));
-        if (M->debug_sync & 16) MCHK(hipStreamSynchronize(sm));
+        if (gfirst < nblk) RC(update(SM, "bulk", gfirst, k, gfirst, lcol_from(gfirst) * NB, n_loc));
+        RC(rr.own_event(&bulk_done[k], "bulk_done", k));
+        RC(rr.rec(SM, bulk_done[k]));
+        if (!dry && (M->debug_sync & 16)) MCHK(hipStreamSynchronize(sm));
     }
-    // join the panel stream into the main stream
+    // join the panel and comm streams into the main stream
     {
-        hipEvent_t e;
-        RC(rr.own_event(&e));
-        MCHK(hipEventRecord(e, sp));
-        MCHK(hipStreamWaitEvent(sm, e, 0));
-        RC(rr.own_event(&e));
-        MCHK(hipEventRecord(e, sc));
-        MCHK(hipStreamWaitEvent(sm, e, 0));
+        Ev e;
+        RC(rr.own_event(&e, "join_sp"));
+        RC(rr.rec(SP, e));
+        RC(rr.wait(SM, e));
+        RC(rr.own_event(&e, "join_sc"));
+        RC(rr.rec(SC, e));
+        RC(rr.wait(SM, e));
     }
     // ---- ‖z_s‖² over my local columns of the RHS rows
-    if (rhs_row) RC(eng_rowsumsq(c, sm, A + nlb_r * NB * ld, ld, ncols, n_loc, c->scal_dev + 8));
+    if (rhs_row)
+        RC(rr.op(SM, "rowsumsq", 0, 0, {Fp{"A", R_, 0, 0, 0, nlb_c, 4}}, {}, [&]() { return eng_rowsumsq(c, sm, A + nlb_r * NB * ld, ld, ncols, n_loc, c->scal_dev + 8); }));
 
     // ---- backward substitution α = L⁻ᵀ z (column 0), block sweep from the last block column
     if (want_alpha) {
@@ -531,67 +840,99 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         double* tmp = (double*)tmp_v;
         for (long k = nblk - 1; k >= 0; --k) {
             const int pk = (int)(k % P), qk = (int)(k % Q);
-            const long c0 = (k / Q) * NB;
+            const long c0 = (k / Q) * NB, lc = k / Q;
+            const Fp f_acc = Fp{"acc", R_, 0, 0, lc, lc + 1, 0};
+            const Fp f_alb = Fp{"alb", R_, 0, 0, k, k + 1, 0};
             if (q == qk) {
-                if (rhs_row) RC(eng_add_vec(c, sm, acc + c0, A + nlb_r * NB * ld + c0, NB));  // + z_k from the RHS row
+                if (rhs_row)  // + z_k from the RHS row
+                    RC(rr.op(SM, "addz", k, 0, {Fp{"A", R_, 0, 0, lc, lc + 1, 4}, f_acc}, {f_acc}, [&]() { return eng_add_vec(c, sm, acc + c0, A + nlb_r * NB * ld + c0, NB); }));
                 if (p == pk) {
                     double* ak = me->alpha_blk + k * NB;
-                    MCHK(hipMemcpyAsync(ak, acc + c0, sizeof(double) * NB, hipMemcpyDeviceToDevice, sm));
+                    RC(rr.op(SM, "ak", k, 0, {f_acc}, {f_alb}, [&]() -> int32_t {
+                        MCHK(hipMemcpyAsync(ak, acc + c0, sizeof(double) * NB, hipMemcpyDeviceToDevice, sm));
+                        return 0;
+                    }));
                     for (int pp = 0; pp < P; ++pp) {  // + the partial sums of the other process rows
                         if (pp == pk) continue;
                         MRank& src = rank_of(pp, qk);
+                        const Fp f_tmp = Fp{"tmp", R_, 0, 0, pp, pp + 1, 0};
                         if (rccl) {
-                            NCHK(g_rccl.Recv(tmp + (size_t)pp * NB, (size_t)NB, NCCL_FLOAT64, src.r, me->comm, sm));
+                            tr_recv(rr, SM, src.r, NB, f_tmp);
+                            if (!dry) NCHK(g_rccl.Recv(tmp + (size_t)pp * NB, (size_t)NB, NCCL_FLOAT64, src.r, me->comm, sm));
                         } else {
-                            RC(rr.await(src.accr[k], sm));
-                            RC(rr.pull(sm, tmp + (size_t)pp * NB, NB, src.acc + c0, NB, 1, NB));
+                            RC(rr.await(src.accr[k], SM));
+                            RC(rr.op(SM, "pull_acc", k, pp, {Fp{"acc", src.r, 0, 0, lc, lc + 1, 0}}, {f_tmp}, [&]() { return rr.pull(SM, tmp + (size_t)pp * NB, NB, src.acc + c0, NB, 1, NB); }));
                         }
-                        RC(eng_add_vec(c, sm, ak, tmp + (size_t)pp * NB, NB));
+                        RC(rr.op(SM, "add_acc", k, pp, {f_tmp, f_alb}, {f_alb}, [&]() { return eng_add_vec(c, sm, ak, tmp + (size_t)pp * NB, NB); }));
                     }
-                    RC(eng_trsv(c, sm, A + (k / P) * NB * ld + c0, ld, NB, ak, NB, 1, false));
-                    MCHK(hipMemcpyAsync(alpha_host + k * NB, ak, sizeof(double) * NB, hipMemcpyDeviceToHost, sm));
-                    if (rccl) {
-                        NCHK(g_rccl.GroupStart());
-                        for (int qq = 0; qq < Q; ++qq)
-                            if (qq != qk) NCHK(g_rccl.Send(ak, (size_t)NB, NCCL_FLOAT64, rank_of(pk, qq).r, me->comm, sm));
-                        NCHK(g_rccl.GroupEnd());
+                    RC(rr.op(SM, "trsv", k, 0, {Fp{"A", R_, k / P, k / P + 1, lc, lc + 1, 0}, f_alb}, {f_alb}, [&]() -> int32_t {
+                        RC(eng_trsv(c, sm, A + (k / P) * NB * ld + c0, ld, NB, ak, NB, 1, false));
+                        MCHK(hipMemcpyAsync(alpha_host + k * NB, ak, sizeof(double) * NB, hipMemcpyDeviceToHost, sm));
+                        return 0;
+                    }));
+                    if (rccl) {  // α_k to the ranks of my process row that hold columns left of k (exactly those post the receive)
+                        bool any = false;
+                        for (int qq = 0; qq < Q; ++qq) any = any || (qq != qk && k > 0 && nlb_before(k - 1, qq, Q) > 0);
+                        if (any) {
+                            tr_group(rr, SM, 1);
+                            if (!dry) NCHK(g_rccl.GroupStart());
+                            for (int qq = 0; qq < Q; ++qq)
+                                if (qq != qk && k > 0 && nlb_before(k - 1, qq, Q) > 0) {
+                                    tr_send(rr, SM, rrank(pk, qq), NB, f_alb);
+                                    if (!dry) NCHK(g_rccl.Send(ak, (size_t)NB, NCCL_FLOAT64, rank_of(pk, qq).r, me->comm, sm));
+                                }
+                            if (!dry) NCHK(g_rccl.GroupEnd());
+                            tr_group(rr, SM, 0);
+                        }
                     }
-                    RC(rr.publish(me->alr[k], sm));
+                    RC(rr.publish(me->alr[k], SM));
                 } else {
-                    if (rccl) NCHK(g_rccl.Send(acc + c0, (size_t)NB, NCCL_FLOAT64, rank_of(pk, qk).r, me->comm, sm));
-                    RC(rr.publish(me->accr[k], sm));
+                    if (rccl) {
+                        tr_send(rr, SM, rrank(pk, qk), NB, f_acc);
+                        if (!dry) NCHK(g_rccl.Send(acc + c0, (size_t)NB, NCCL_FLOAT64, rank_of(pk, qk).r, me->comm, sm));
+                    }
+                    RC(rr.publish(me->accr[k], SM));
                 }
             }
             if (p == pk && k > 0) {  // my block row k: acc_j −= L[k][j]ᵀ α_k for my local columns j < k
                 const long ncb = nlb_before(k - 1, q, Q);
                 if (ncb > 0) {
                     const double* ak;
+                    Fp f_ak = f_alb;
                     if (q == qk) {
                         ak = me->alpha_blk + k * NB;
                     } else {
                         MRank& own = rank_of(pk, qk);
                         double* dst = tmp + (size_t)P * NB;
+                        f_ak = Fp{"tmp", R_, 0, 0, P, P + 1, 0};
                         if (rccl) {
-                            NCHK(g_rccl.Recv(dst, (size_t)NB, NCCL_FLOAT64, own.r, me->comm, sm));
+                            tr_recv(rr, SM, own.r, NB, f_ak);
+                            if (!dry) NCHK(g_rccl.Recv(dst, (size_t)NB, NCCL_FLOAT64, own.r, me->comm, sm));
                         } else {
-                            RC(rr.await(own.alr[k], sm));
-                            RC(rr.pull(sm, dst, NB, own.alpha_blk + k * NB, NB, 1, NB));
+                            RC(rr.await(own.alr[k], SM));
+                            RC(rr.op(SM, "pull_alpha", k, 0, {Fp{"alb", own.r, 0, 0, k, k + 1, 0}}, {f_ak}, [&]() { return rr.pull(SM, dst, NB, own.alpha_blk + k * NB, NB, 1, NB); }));
                         }
                         ak = dst;
                     }
-                    RC(eng_gemv_t(c, sm, A + (k / P) * NB * ld, ld, NB, ncb * NB, ak, acc));
+                    const Fp f_accs = Fp{"acc", R_, 0, 0, 0, ncb, 0};
+                    RC(rr.op(SM, "gemv", k, 0, {Fp{"A", R_, k / P, k / P + 1, 0, ncb, 0}, f_ak, f_accs}, {f_accs},
+                             [&]() { return eng_gemv_t(c, sm, A + (k / P) * NB * ld, ld, NB, ncb * NB, ak, acc); }));
                 }
-            } else if (rccl && p == pk && k == 0) {
-                // nothing to receive: block row 0 has no columns left of the diagonal
             }
         }
     }
+    if (dry) return 0;
     // ---- results of this rank
+    std::vector<int> log_h;
+    if (chk_v) {
+        log_h.assign(256, 0);
+        MCHK(hipMemcpyAsync(log_h.data(), me->log, sizeof(int) * 256, hipMemcpyDeviceToHost, sm));
+    }
     MCHK(hipMemcpyAsync(info_out, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, sm));
     MCHK(hipMemcpyAsync(scal_out, c->scal_dev, sizeof(double) * (8 + RHS_ROWS), hipMemcpyDeviceToHost, sm));
-    MCHK(hipStreamSynchronize(sm));
-    MCHK(hipStreamSynchronize(sp));
-    MCHK(hipStreamSynchronize(sc));
+    RC(rr.drain(SM));
+    RC(rr.drain(SP));
+    RC(rr.drain(SC));
     me->gemm_ms = me->gemm_flops = 0;
     me->gemm_launches = (long)c->gemm_recs.size();
     for (auto& r : c->gemm_recs) {
@@ -600,7 +941,21 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, int kind, double varian
         me->gemm_ms += ms;
         me->gemm_flops += r.flops;
     }
-    if (keep) bufs.keep(A_v);
+    if (chk_v && log_h[0] > 0) {
+        std::string msg = "multi_check: rank " + std::to_string(me->r) + " logged " + std::to_string(log_h[0]) + " finding(s):";
+        for (int i = 0; i < std::min(log_h[0], 12); ++i) {
+            const int* e = &log_h[4 + 4 * i];
+            char b[200];
+            if (e[0] == 1)
+                snprintf(b, sizeof b, " [stream %s ran past its wait for event r%de%d: marker holds generation %d, expected %ld]", SNAME[(e[3] >> 16) & 3], e[1], e[2],
+                         e[3] & 0xffff, seq & 0xffff);
+            else
+                snprintf(b, sizeof b, " [%s operand of panel %d, local block %d differs from the owner's final block]", e[0] == 2 ? "A" : "B", e[1], e[2]);
+            msg += b;
+        }
+        return set_err_text(-1990, msg);
+    }
+    if (keep) bufs->keep(A_v);
     return 0;
 }
 
@@ -639,13 +994,34 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
         m->debug_sync = (int)v;
         return 0;
     }
+    if (!strcmp(name, "multi_check")) {
+        m->check = (int)v;
+        return 0;
+    }
+    if (!strcmp(name, "multi_timeout_s")) {
+        m->timeout_s = (double)std::max<int64_t>(1, v);
+        return 0;
+    }
     if (!strcmp(name, "dist_nb")) {
         m->nb = std::max<int64_t>(128, (v + 127) / 128 * 128);
         return 0;
     }
+    if (!strcmp(name, "multi_gemm_streamk")) {  // stream-K cuts of the few-tile GEMMs inside the rank contexts (see gp_ctx_create_multi)
+        for (auto& rk : m->ranks) (void)gp_ctx_set_param(rk.c, "gemm_streamk", v);
+        return 0;
+    }
+    if (!strcmp(name, "gemm_streamk")) return 1;  // the main ctx only (everything that runs on devices[0] alone)
     // every other parameter also goes to the rank contexts (kernel variants, timing switches)
     for (auto& rk : m->ranks) (void)gp_ctx_set_param(rk.c, name, v);
     return 1;
+}
+
+// drop the cached device blocks of the rank contexts (gp_ctx_trim on a multi-device ctx)
+void multi_trim(gp_ctx* c) {
+    gp_multi* m = c->multi;
+    if (!m) return;
+    for (auto& rk : m->ranks) (void)gp_ctx_trim(rk.c);
+    (void)hipSetDevice(c->device);
 }
 
 extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int32_t ndev, int32_t P, int32_t Q, int32_t nb) {
@@ -674,6 +1050,8 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
     RC(gp_ctx_create(&main_ctx, devices[0], nullptr));
     gp_multi* m = new gp_multi();
     m->P = P; m->Q = Q; m->R = ndev; m->nb = nb; m->virt = dup;
+    if (const char* ts = getenv("GPMI_MULTI_TIMEOUT_S")) m->timeout_s = std::max(1.0, atof(ts));
+    if (const char* cs = getenv("GPMI_MULTI_CHECK")) m->check = atoi(cs);
     m->ranks.resize((size_t)ndev);
     int32_t rc = 0;
     for (int r = 0; r < ndev && rc == 0; ++r) {
@@ -681,11 +1059,10 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
         rk.r = r; rk.p = r / Q; rk.q = r % Q; rk.device = devices[r];
         rc = gp_ctx_create(&rk.c, devices[r], nullptr);
         if (rc != 0) break;
-        // Rank contexts keep the round-2 mid-point configuration that passed every multi-device sweep (0 wrong fits in 425 under 16
-        // hardware queues): hardware-dispatched GEMMs (no stream-K) and a comm stream of default priority.  With stream-K in the rank
-        // contexts AND a high-priority comm stream, 11 of 501 fits of the n = 2 049 sweep cases were wrong under 16 hardware queues
-        // (mostly the first fit of a fresh context) — not root-caused; GPMI_COMM_PRIO=1 / gemm_streamk=1 re-enable them.
-        (void)gp_ctx_set_param(rk.c, "gemm_streamk", 0);
+        // Rank contexts: hardware-dispatched GEMMs unless "multi_gemm_streamk" / GPMI_MULTI_SK=1 asks for the stream-K cuts, comm
+        // stream of the LOWEST priority unless GPMI_COMM_PRIO=1 (the first-fit item of round 2).
+        const char* ske = getenv("GPMI_MULTI_SK");
+        (void)gp_ctx_set_param(rk.c, "gemm_streamk", (ske && ske[0] == '1') ? 1 : 0);
         int plo = 0, phi = 0;
         const char* pe = getenv("GPMI_COMM_PRIO");
         if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess ||
@@ -701,11 +1078,13 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
             }
         }
     }
-    // transport: RCCL between distinct devices unless told otherwise (GPMI_COMM=rccl|p2p); virtual ranks can only copy
+    // transport: RCCL between distinct devices unless told otherwise (GPMI_COMM=rccl|p2p); virtual ranks can only copy — unless a
+    // stand-in library that accepts duplicate devices is named (GPMI_RCCL_LIB, tests/rccl_mock)
     const char* want = getenv("GPMI_COMM");
     m->comm = 2;
     const bool force_rccl = want && !strcmp(want, "rccl");  // also with ONE device: exercises dlopen + ncclCommInitAll (API check)
-    if (rc == 0 && !dup && (ndev > 1 || force_rccl) && !(want && !strcmp(want, "p2p"))) {
+    const bool standin = getenv("GPMI_RCCL_LIB") != nullptr;
+    if (rc == 0 && (!dup || (force_rccl && standin)) && (ndev > 1 || force_rccl) && !(want && !strcmp(want, "p2p"))) {
         std::lock_guard<std::mutex> l(g_rccl_mu);
         if (g_rccl.load()) {
             std::vector<ncclComm_t_> comms((size_t)ndev, nullptr);
@@ -714,14 +1093,14 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
             if (nrc == 0) {
                 for (int r = 0; r < ndev; ++r) m->ranks[r].comm = comms[r];
                 m->comm = 1;
-                m->comm_note = "RCCL grouped send/recv over xGMI (ncclCommInitAll)";
+                m->comm_note = standin ? "grouped send/recv through the stand-in library of GPMI_RCCL_LIB" : "RCCL grouped send/recv over xGMI (ncclCommInitAll)";
             } else {
                 m->comm_note = std::string("peer copies (ncclCommInitAll failed: ") + g_rccl.GetErrorString(nrc) + ")";
             }
         } else {
             m->comm_note = "peer copies (" + g_rccl.err + ")";
         }
-        if (want && !strcmp(want, "rccl") && m->comm != 1) rc = set_err_text(-1996, "GPMI_COMM=rccl but RCCL is unavailable: " + m->comm_note);
+        if (force_rccl && m->comm != 1) rc = set_err_text(-1996, "GPMI_COMM=rccl but RCCL is unavailable: " + m->comm_note);
     } else if (rc == 0) {
         m->comm_note = dup ? "same-device copies (virtual ranks)" : (ndev > 1 ? "peer copies (GPMI_COMM=p2p)" : "single rank");
     }
@@ -748,22 +1127,84 @@ extern "C" int32_t gp_ctx_multi_info(gp_ctx* c, int32_t* P, int32_t* Q, int32_t*
     return 0;
 }
 
-// fit on a multi-device ctx (called with the main ctx locked).  fp64 only.
-int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null, const void* Yv,
-                  long ldy, int ncols, double* logpdf_out, gp_post* post, void* alpha_out) {
-    gp_multi* M = c->multi;
-    if (k->dtype != 0) return set_arg_err(2, "multi-device contexts compute in fp64 (kernel dtype must be 0)");
-    if (ncols > RHS_ROWS) return set_arg_err(8, "at most 128 right-hand sides on a multi-device ctx");
-    const int P = M->P, Q = M->Q, R = M->R;
-    const long n = x->n, NB = M->nb;
-    const int d = x->d;
-    long lcm = (long)P * Q;
-    for (long a = P, b = Q; b;) {
+static long lcm_of(long a0, long b0) {
+    long a = a0, b = b0;
+    while (b) {
         const long t = a % b;
         a = b;
         b = t;
-        if (!b) lcm = (long)P * Q / a;
     }
+    return a0 / a * b0;
+}
+
+// The schedule of a P×Q fit over nblk block columns as fit_rank issues it — the SAME control flow, run by one host thread per
+// rank without any device (operations, event records / waits, transfers with their block footprints as JSON lines):
+// what tools/multi_schedule_check.py checks on a machine without a GPU.  comm: 1 = RCCL-style send/recv, 2 = copies.
+extern "C" int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk_in, int32_t depth, int32_t comm, const char* path) {
+    if (P < 1 || Q < 1 || P * Q > 64) return set_arg_err(1, "P, Q");
+    if (nblk_in < 1 || nblk_in > 4096) return set_arg_err(3, "nblk");
+    if (depth < 1 || depth > 3) return set_arg_err(4, "depth must be 1..3");
+    if (comm != 1 && comm != 2) return set_arg_err(5, "comm must be 1 (send/recv) or 2 (copies)");
+    if (!path) return set_arg_err(6, "path is NULL");
+    Trace tr;
+    tr.f = fopen(path, "w");
+    if (!tr.f) return set_arg_err(6, "cannot open the trace file");
+    gp_multi M;
+    M.P = P; M.Q = Q; M.R = P * Q; M.nb = 128; M.depth = depth; M.comm = comm; M.tr = &tr; M.timeout_s = 60;
+    const long lcm = lcm_of(P, Q);
+    const long nblk = (nblk_in + lcm - 1) / lcm * lcm;
+    Dims dm{nblk * 128, nblk * 128, nblk, 128, nblk / P, nblk / Q, 128 + 32, 1};
+    M.ranks.resize((size_t)M.R);
+    for (int r = 0; r < M.R; ++r) {
+        MRank& rk = M.ranks[r];
+        rk.r = r; rk.p = r / Q; rk.q = r % Q;
+        int kind = 0;
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr}) {
+            std::vector<XEvent> nv((size_t)nblk);
+            for (long i = 0; i < nblk; ++i) {
+                nv[i].owner = r;
+                nv[i].id = (int)(kind * nblk + i);
+                nv[i].tag = XTAG[kind];
+                nv[i].k = i;
+            }
+            v->swap(nv);
+            ++kind;
+        }
+    }
+    {
+        char b[160];
+        snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"dry\":1}", P, Q, nblk, depth, comm);
+        tr.line(b);
+    }
+    std::vector<std::thread> th;
+    for (int r = 0; r < M.R; ++r)
+        th.emplace_back([&, r]() {
+            MRank& rk = M.ranks[r];
+            rk.rc = fit_rank(&M, &rk, dm, true, 0, 1.0, nullptr, nullptr, nullptr, 1, true, false, nullptr, nullptr, nullptr, nullptr, 1);
+            if (rk.rc != 0) {
+                rk.err = gp_last_error();
+                M.abort.store(1);
+            }
+        });
+    for (auto& t : th) t.join();
+    fclose(tr.f);
+    tr.f = nullptr;
+    for (int r = 0; r < M.R; ++r)
+        if (M.ranks[r].rc != 0 && M.ranks[r].rc != -1999) return set_err_text(M.ranks[r].rc, "rank " + std::to_string(r) + ": " + M.ranks[r].err);
+    return 0;
+}
+
+// fit on a multi-device ctx (called with the main ctx locked).  fp64, at most RHS_ROWS right-hand sides (the caller routes
+// everything else to the single-device engine on devices[0]).
+int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null, const void* Yv,
+                  long ldy, int ncols, double* logpdf_out, double* terms_out, gp_post* post, void* alpha_out) {
+    gp_multi* M = c->multi;
+    if (k->dtype != 0) return set_arg_err(2, "multi-device fits compute in fp64 (kernel dtype must be 0)");
+    if (ncols > RHS_ROWS) return set_arg_err(8, "at most 128 right-hand sides per multi-device fit");
+    const int P = M->P, Q = M->Q, R = M->R;
+    const long n = x->n, NB = M->nb;
+    const int d = x->d;
+    const long lcm = lcm_of(P, Q);
     long nblk = (n + NB - 1) / NB;
     nblk = (nblk + lcm - 1) / lcm * lcm;  // every rank owns the same number of block rows / columns
     Dims dm{n, nblk * NB, nblk, NB, nblk / P, nblk / Q, NB + 32, d};
@@ -789,9 +1230,10 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     MCHK(hipHostMalloc((void**)&alpha_pin, sizeof(double) * (size_t)npad, hipHostMallocPortable));
     memset(alpha_pin, 0, sizeof(double) * (size_t)npad);
 
-    // ---- events sized for this nblk
+    // ---- events sized for this nblk (ids: kind · nblk + k — the layout of the marker flags and of the trace names)
     for (auto& rk : M->ranks) {
         (void)hipSetDevice(rk.device);
+        int kind = 0;
         for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr}) {
             if ((long)v->size() < nblk) {
                 std::vector<XEvent> nv((size_t)nblk);
@@ -806,12 +1248,30 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
                     }
                 v->swap(nv);
             }
+            for (size_t i = 0; i < v->size(); ++i) {
+                (*v)[i].owner = rk.r;
+                (*v)[i].id = (long)i < nblk ? (int)(kind * nblk + (long)i) : -1;
+                (*v)[i].tag = XTAG[kind];
+                (*v)[i].k = (long)i;
+            }
+            ++kind;
         }
     }
     (void)hipSetDevice(c->device);
     const long seq = ++M->seq;
     M->abort.store(0);
     const bool keep = post != nullptr;
+
+    Trace tr;
+    if (const char* tp = getenv("GPMI_TRACE_SCHEDULE")) {
+        tr.f = fopen(tp, "w");  // the LAST fit of the process is what the file holds
+        if (tr.f) {
+            char b[160];
+            snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"dry\":0}", P, Q, nblk, M->depth, M->comm);
+            tr.line(b);
+        }
+    }
+    M->tr = tr.f ? &tr : nullptr;
 
     std::vector<std::vector<double>> scal((size_t)R, std::vector<double>(8 + RHS_ROWS, 0.0));
     std::vector<int> infos((size_t)R, 0);
@@ -824,19 +1284,26 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
             th.emplace_back([&, r]() {
                 MRank& rk = M->ranks[r];
                 std::lock_guard<std::mutex> l(rk.c->mu);
-                rk.rc = fit_rank(M, &rk, dm, k->kind, k->variance, xs_h.data(), noise_h.data(), rhs_h.data(), ncols, keep, keep, alpha_pin,
-                                 scal[r].data(), &infos[r], *bufs[r], seq);
+                rk.rc = fit_rank(M, &rk, dm, false, k->kind, k->variance, xs_h.data(), noise_h.data(), rhs_h.data(), ncols, keep, keep, alpha_pin,
+                                 scal[r].data(), &infos[r], bufs[r].get(), seq);
                 if (rk.rc != 0) {
                     rk.err = gp_last_error();
                     M->abort.store(1);
-                    (void)hipStreamSynchronize(rk.c->sm);
-                    (void)hipStreamSynchronize(rk.c->sp);
-                    (void)hipStreamSynchronize(rk.sc);
+                    if (rk.rc != -1992) {  // (a stream that never drains would block these as well)
+                        (void)hipStreamSynchronize(rk.c->sm);
+                        (void)hipStreamSynchronize(rk.c->sp);
+                        (void)hipStreamSynchronize(rk.sc);
+                    }
                 }
             });
         for (auto& t : th) t.join();
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    M->tr = nullptr;
+    if (tr.f) {
+        fclose(tr.f);
+        tr.f = nullptr;
+    }
     (void)hipSetDevice(c->device);
     int32_t rc = 0;
     for (int r = 0; r < R; ++r)
@@ -869,6 +1336,10 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     }
     const double LOG2PI_ = 1.8378770664093454835606594728112;
     for (int s = 0; s < ncols; ++s) logpdf_out[s] = -0.5 * ((double)n * LOG2PI_ + 2.0 * logdet_half + ss[s]);
+    if (terms_out) {
+        terms_out[0] = 2.0 * logdet_half;
+        for (int s = 0; s < ncols; ++s) terms_out[1 + s] = ss[s];
+    }
     // timings of rank 0 for gp_get_timings (bench roofline)
     c->tm = gp_timings{};
     c->tm.total_ms = wall_ms;

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GPMI355_ABI_VERSION 2
+#define GPMI355_ABI_VERSION 3
 
 typedef struct gp_ctx gp_ctx;   /* device + streams + workspace                          */
 typedef struct gp_post gp_post; /* PosteriorGP state: device-resident factor, alpha, x   */
@@ -98,10 +98,21 @@ int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null);
  * times ("virtual ranks": the full schedule on one GPU with same-device copies — how CI exercises it).  Every other entry
  * point works unchanged on such a ctx: fp64 fits are distributed, everything else (and everything downstream of a fit:
  * predictions, updates, sampling — the factor is gathered onto devices[0] on first need) runs on devices[0].
- * Extra parameters: "lookahead_depth" (1..3, default 2), "dist_nb". */
+ * fp32 fits and fits with more than 128 right-hand-side columns also run on devices[0] (single-device engine).
+ * Extra parameters: "lookahead_depth" (1..3, default 2), "dist_nb", "multi_gemm_streamk" (stream-K cuts inside the rank
+ * contexts, default 0), "multi_timeout_s" (a rank that waits longer for a peer or for its own streams fails the fit instead
+ * of hanging, default 600), "multi_check" (diagnostics: 1 marker/checker kernels around every event record / wait, 2 operand
+ * buffers compared with the owners' blocks before every update, 4 NaN-poisoned operand buffers; findings fail the fit with
+ * status -1990).  Environment: GPMI_COMM=rccl|p2p, GPMI_RCCL_LIB=<library to dlopen instead of librccl>, GPMI_COMM_PRIO=1
+ * (high-priority comm stream), GPMI_TRACE_SCHEDULE=<file> (JSON-lines schedule trace of the last fit). */
 int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int32_t ndev, int32_t P, int32_t Q, int32_t nb);
 /* Grid / transport of a ctx (1×1, nb 0, comm 0 for a single-device ctx).  comm: 1 RCCL, 2 peer / same-device copies. */
 int32_t gp_ctx_multi_info(gp_ctx* ctx, int32_t* P, int32_t* Q, int32_t* nb, int32_t* comm, int32_t* depth);
+/* The schedule the multi-device driver issues for a P×Q grid over nblk block columns (look-ahead depth 1..3; comm 1 =
+ * send/recv transport, 2 = copies), written as JSON lines to `path`: every stream operation with its block footprint, every
+ * event record / wait, every transfer — produced by the SAME rank-thread code that drives the devices, run without a device
+ * (works on a machine without a GPU).  tools/multi_schedule_check.py checks happens-before on it. */
+int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk, int32_t depth, int32_t comm, const char* path);
 int32_t gp_ctx_destroy(gp_ctx* ctx);
 /* Tuning / diagnostic parameters (all optional; the GPMI_PARAMS="name=value,..." environment variable applies the same
  * names at gp_ctx_create):
@@ -148,6 +159,13 @@ int32_t gp_kernelmatrix(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, con
  * src/finite_gp_projection.jl:306-311, 325-326. */
 int32_t gp_logpdf(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_noise* noise,
                   const void* mean_or_null, const void* Y, int64_t ldy, int32_t ncols, void* out);
+
+/* The two terms of logpdf separately — sqmahal(fx, Y) (src/finite_gp_projection.jl:313-326: ‖U⁻ᵀ(y_s − m)‖² per column) and
+ * logdet(cov(fx)) (:310) — from ONE factorisation.  Y may be NULL (logdet only; sqmahal_out must then be NULL too).
+ * logdet_out: 1 entry, sqmahal_out: ncols entries, kernel dtype; either may be NULL.  (gradlogpdf(fx, y), :328-337, is −α of
+ * gp_posterior_fit.) */
+int32_t gp_logpdf_terms(gp_ctx* ctx, const gp_kernel* k, const gp_points* x, const gp_noise* noise, const void* mean_or_null,
+                        const void* Y_or_null, int64_t ldy, int32_t ncols, void* logdet_out_or_null, void* sqmahal_out_or_null);
 
 /* posterior(f(x, Σy), y): ONE Gram assembly + ONE factorisation serve both results.
  * alpha_out_or_null: length n (α = C \ (y - m));  logpdf_out_or_null: 1 entry (= logpdf(fx, y)).
@@ -201,6 +219,8 @@ int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, vo
 
 /* C.U (n×n column-major upper, strictly-lower part zero) to the host — parity / debugging only. */
 int32_t gp_posterior_get_factor(gp_post* post, void* U_out);
+/* logdet(post.data.C) = 2 Σ log U_ii, kept from the fit (always double). */
+int32_t gp_posterior_logdet(gp_post* post, double* out);
 int64_t gp_posterior_n(gp_post* post);
 int32_t gp_posterior_free(gp_post* post); /* NULL or already-freed handle: returns -1, never UB-free twice */
 

@@ -1,6 +1,11 @@
-"""CPU: happens-before check of the multi-device schedule (tools/multi_schedule_check.py replays the stream operations, event
-waits and block accesses of abstractgps.jl_amd/csrc/multi.hip::fit_rank for the copy transport).  Every pair of operations that
-touches the same matrix block / operand-buffer slot / partial-sum block with at least one write must be ordered."""
+"""CPU: happens-before check of the multi-device schedule ON THE SCHEDULE THE LIBRARY EMITS.
+
+gp_multi_schedule_trace runs the rank threads of abstractgps.jl_amd/csrc/multi.hip::fit_rank without a device — the same control
+flow that drives the GPUs — and writes every stream operation (with its block footprint), event record / wait and send / receive
+as JSON lines; tools/multi_schedule_check.py rebuilds the dependency graph from that and looks for unordered conflicting
+accesses and for protocol errors (send / receive sequences of a rank pair that do not match, waits on unrecorded events).
+The rank threads really run (generation-numbered events, host spins): a schedule whose threads could block each other fails the
+trace call itself after its time-out.  The checker is shown to FIND the defects it is there for by editing recorded traces."""
 import sys
 from pathlib import Path
 
@@ -10,59 +15,113 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tools"))
 import multi_schedule_check as M  # noqa: E402
 
+COPIES, SENDRECV = 2, 1
 
-@pytest.mark.parametrize("rccl", [False, True], ids=["copies", "rccl"])
+
+@pytest.fixture(scope="module", autouse=True)
+def _built(agp):  # the .so (cross-compiled here when missing); no GPU is needed to load it or to trace schedules
+    return agp
+
+
+@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
 @pytest.mark.parametrize("grid", M.GRIDS)
-def test_no_unordered_conflicts(grid, rccl):
-    """both transports: consumer pulls (hipMemcpy2DAsync / copy kernel) and the grouped ncclSend / ncclRecv pairs with their
-    staging images (the RCCL schedule has never run on more than one GPU: this is its only check besides the API test)"""
+def test_no_unordered_conflicts(grid, comm):
     P, Q = grid
     for nblk in (1, 2, 3, 5, 9, 17):
         for depth in (1, 2, 3):
-            g = M.build(P, Q, nblk, depth, rccl=rccl)
-            rs = M.races(g)
+            problems, rs = M.check_config(P, Q, nblk, depth, comm)
+            assert not problems, (grid, nblk, depth, problems[:4])
             assert not rs, (grid, nblk, depth, rs[:4])
-            if rccl:  # point-to-point operations of a pair of ranks match by posting order
-                assert not M.rccl_pair_order(g, P * Q), (grid, nblk, depth)
 
 
-def _variant(old, new):
-    src = (ROOT / "tools" / "multi_schedule_check.py").read_text().split("if __name__")[0]
-    assert old in src
-    ns = {}
-    exec(compile(src.replace(old, new), "variant", "exec"), ns)
-    return ns
+def test_trace_covers_the_backward_sweep_transfers():
+    """the send/recv transport of the backward sweep (partial sums to the diagonal owner, alpha blocks along the process row) is in
+    the trace: round 2's branch sent alpha blocks that no rank received — the pair sequences must now match exactly"""
+    with __import__("tempfile").TemporaryDirectory() as td:
+        path = Path(td) / "t.jsonl"
+        M.emit_trace(2, 4, 9, 2, SENDRECV, path)
+        hdr, lines = M.load(path)
+    sm_sends = [ln for ln in lines if ln["t"] == "send" and ln["s"] == "sm"]
+    sm_recvs = [ln for ln in lines if ln["t"] == "recv" and ln["s"] == "sm"]
+    assert sm_sends and len(sm_sends) == len(sm_recvs)
+    g, problems = M.build(hdr, lines)
+    assert not problems and not M.races(g)
+    # an unmatched alpha send (what round 2's code issued for ranks without columns left of k) is a protocol finding
+    extra = dict(sm_sends[-1])
+    g, problems = M.build(hdr, lines + [extra])
+    assert any("sends but" in p for p in problems)
+
+
+def _drop(pred, first_per=None):
+    """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
+    def f(lines):
+        out, seen, dropped = [], set(), 0
+        for ln in lines:
+            if pred(ln):
+                key = first_per(ln) if first_per else None
+                if first_per is None or key not in seen:
+                    seen.add(key)
+                    dropped += 1
+                    continue
+            out.append(ln)
+        assert dropped, "the edit did not match any trace line"
+        return out
+    return f
 
 
 def test_checker_finds_the_round2_bug():
     """the dependency that was missing during development (a rank in the owner column whose updates read its own matrix did
     not wait for its own panel when it pulled nothing from itself): grids with gcd(P, Q) > 1 must be flagged without it"""
-    ns = _variant("        if q == qk:\n            sc[r].wait(ready[r][k])\n", "")
-    assert ns["races"](ns["build"](2, 2, 9, 2))
-    assert ns["races"](ns["build"](4, 2, 9, 2))
-    assert not ns["races"](ns["build"](2, 1, 9, 2))
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln["s"] == "sc" and ln.get("tag") == "ready" and ln["e"].startswith(f"r{ln['r']}e"),
+                 first_per=lambda ln: (ln["r"], ln["k"]))
+    assert M.check_config(2, 2, 9, 2, COPIES, mutate=edit)[1]
+    assert M.check_config(4, 2, 9, 2, COPIES, mutate=edit)[1]
+    assert not M.check_config(2, 1, 9, 2, COPIES, mutate=edit)[1]  # there every rank pulls from itself and waits again
 
 
 def test_checker_finds_missing_bulk_wait_and_buffer_reuse():
-    ns = _variant("        if i == first and first - 1 >= 0 and bulk_done[r][first - 1] is not None:\n"
-                  "            sp[r].wait(bulk_done[r][first - 1])\n", "")
-    assert ns["races"](ns["build"](2, 2, 9, 2))
-    ns = _variant("            sc[r].wait(bulk_done[r][k - NBUF])\n            sc[r].wait(la_done[r][k - NBUF])\n", "            pass\n")
-    assert ns["races"](ns["build"](2, 2, 9, 2))
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln["s"] == "sp" and ln.get("tag") == "bulk_done")
+    assert M.check_config(2, 2, 9, 2, COPIES, mutate=edit)[1]
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln["s"] == "sc" and ln.get("tag") in ("bulk_done", "la_done"))
+    assert M.check_config(2, 2, 9, 2, COPIES, mutate=edit)[1]
 
 
-def test_checker_finds_unstaged_rccl_sends():
-    """RCCL transport: without the wait for the rank's own panel in front of the group, the sends would read the staging image
-    before the panel stream has written it"""
-    ns = _variant("            if q == qk:\n                sc[r].wait(ready[r][k])\n        sends, recvs", "        sends, recvs")
-    assert ns["races"](ns["build"](2, 2, 9, 2, rccl=True))
+def test_checker_finds_unstaged_sends_and_unfinished_lkk_image():
+    """send/recv transport: without the wait for the rank's own panel in front of the group the sends read the staging image
+    before the panel stream has written it; without the lkk_image / lkk_recv events the comm stream sends an L_kk image that is
+    still being copied, or the panel stream solves with one that has not arrived.  (The lkk_free waits are implied by the
+    arrived -> look-ahead chain: dropping them alone leaves the schedule ordered — they stay as a guard against reordering.)"""
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln["s"] == "sc" and ln.get("tag") == "ready")
+    assert M.check_config(2, 2, 9, 2, SENDRECV, mutate=edit)[1]
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln.get("tag") == "lkk_image")
+    assert M.check_config(2, 2, 9, 2, SENDRECV, mutate=edit)[1]
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln.get("tag") == "lkk_recv")
+    assert M.check_config(2, 2, 9, 2, SENDRECV, mutate=edit)[1]
+    edit = _drop(lambda ln: ln["t"] == "wait" and ln.get("tag") == "lkk_free")
+    assert not M.check_config(2, 2, 9, 2, SENDRECV, mutate=edit)[1]
 
 
-@pytest.mark.parametrize("grid", M.GRIDS)
-def test_rank_threads_cannot_block_each_other(grid):
-    """host side: every generation-numbered event a rank thread spins on is published by its owner without that owner waiting,
-    directly or through other ranks, for the spinning thread"""
-    P, Q = grid
-    for nblk in (1, 2, 3, 5, 9, 17):
-        for depth in (1, 2, 3):
-            assert not M.host_deadlock(P, Q, nblk, depth), (grid, nblk, depth)
+def test_checker_flags_unrecorded_events_and_size_mismatch():
+    def unrecord(lines):
+        return [ln for ln in lines if not (ln["t"] == "rec" and ln.get("tag") == "arrived" and ln["k"] == 3 and ln["r"] == 1)]
+    problems, _ = M.check_config(2, 2, 9, 2, COPIES, mutate=unrecord)
+    assert any("has not been recorded" in p for p in problems)
+
+    def shrink(lines):
+        out, done = [], False
+        for ln in lines:
+            if not done and ln["t"] == "recv":
+                ln = dict(ln, n=ln["n"] - 1)
+                done = True
+            out.append(ln)
+        return out
+    problems, _ = M.check_config(2, 2, 5, 2, SENDRECV, mutate=shrink)
+    assert any("elements" in p for p in problems)
+
+
+def test_trace_arguments_are_validated(agp):
+    lib = agp._lib.load()
+    assert lib.gp_multi_schedule_trace(0, 1, 4, 2, 2, b"/tmp/x") < 0
+    assert lib.gp_multi_schedule_trace(2, 2, 4, 5, 2, b"/tmp/x") < 0
+    assert lib.gp_multi_schedule_trace(2, 2, 4, 2, 3, b"/tmp/x") < 0
+    assert lib.gp_multi_schedule_trace(2, 2, 4, 2, 2, b"/nonexistent-dir/x") < 0
