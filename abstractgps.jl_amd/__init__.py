@@ -10,6 +10,6 @@ The directory name contains a dot, so import it through the root-level shim:
 from .api import *  # noqa: F401,F403
 from .api import (GP, ARDTransform, ColVecs, Context, FiniteGP, Kernel, Matern12Kernel, Matern32Kernel,
                   Matern52Kernel, PosteriorGP, RowVecs, ScaleTransform, SqExponentialKernel, cov, default_context,
-                  kernelmatrix, loglikelihood, VFE, DTC, ExactInference, ApproxPosteriorGP, approx_log_evidence, elbo, inducing_points, logpdf, logpdf_and_grad, marginals, mean, mean_and_cov, mean_and_var, posterior, rand, rand_, update_posterior, var,
+                  kernelmatrix, loglikelihood, VFE, DTC, ExactInference, ApproxPosteriorGP, approx_log_evidence, elbo, inducing_points, logpdf, logpdf_and_grad, sqmahal, logdetcov, gradlogpdf, marginals, mean, mean_and_cov, mean_and_var, posterior, rand, rand_, update_posterior, var,
                   with_lengthscale)
 from ._lib import GpmiError, PosDefException  # noqa: F401

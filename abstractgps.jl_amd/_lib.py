@@ -61,6 +61,7 @@ PROTOTYPES = {
     "gp_logpdf_grad": (i32, [vp, PK, PP, PN, vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl), vp, vp, vp]),
     "gp_posterior_update": (i32, [vp, PP, PN, vp, C.POINTER(vp), vp, vp]),
     "gp_posterior_factor_mul": (i32, [vp, vp, i32, vp]),
+    "gp_posterior_solve": (i32, [vp, vp, i32, vp]),
     "gp_posterior_n": (i64, [vp]),
     "gp_posterior_free": (i32, [vp]),
     "gp_vfe_fit": (i32, [vp, PK, PP, PP, PN, dbl, vp, vp, i32, C.POINTER(vp), vp]),

@@ -398,6 +398,62 @@ def logpdf(fx: FiniteGP, y):
     return out[0] if y.ndim == 1 else out
 
 
+def _terms(fx: FiniteGP, y, want_logdet: bool, want_sqmahal: bool):
+    """gp_logpdf_terms: logdet(cov(fx)) and / or sqmahal(fx, y) from ONE factorisation on the device."""
+    f = fx.f
+    if not isinstance(f, GP):
+        raise TypeError("only GP priors are accelerated here (the shim falls back to the stock methods otherwise)")
+    ctx = f.context()
+    ydt = np.float64 if y is None or np.asarray(y).dtype != np.float32 else np.float32
+    dt = np.result_type(_input_dtype(fx.x), ydt).type
+    m = _Marshal(dt)
+    px = m.points(fx.x)
+    kk = m.kernel(f.kernel, px.d)
+    nz = m.noise(fx.sigma2, px.n)
+    mean = _mean_vector(f.mean_fn, fx.x, dt)
+    mean = None if mean is None else m.arr(mean)
+    Y = None if y is None else m.arr(y if y.ndim == 2 else y[:, None], order="F")
+    ld = np.empty(1, dtype=dt)
+    sq = np.empty(1 if Y is None else Y.shape[1], dtype=dt)
+    check(ctx.lib.gp_logpdf_terms(ctx.handle, C.byref(kk), C.byref(px), C.byref(nz), m.ptr(mean), m.ptr(Y), px.n,
+                                  0 if Y is None else Y.shape[1], ld.ctypes.data if want_logdet else None,
+                                  sq.ctypes.data if want_sqmahal else None))
+    return ld[0], sq
+
+
+def sqmahal(fx: FiniteGP, y):
+    """Distributions.sqmahal(f::FiniteGP, x) — src/finite_gp_projection.jl:315-326: (y − m)ᵀ C⁻¹ (y − m); one value per column."""
+    y = _check_y(fx, y)
+    sq = _terms(fx, y, False, True)[1]
+    return sq[0] if y.ndim == 1 else sq
+
+
+def logdetcov(fx: FiniteGP):
+    """Distributions.logdetcov(f::FiniteGP) = logdet(cov(f)) — src/finite_gp_projection.jl:313."""
+    return _terms(fx, None, True, False)[0]
+
+
+def gradlogpdf(fx: FiniteGP, y):
+    """Distributions.gradlogpdf(f::FiniteGP, x) = C \\ (m .- x) — src/finite_gp_projection.jl:328-337: −α for a vector; for a matrix
+    the factor of the first column's fit is reused for all columns (gp_posterior_solve)."""
+    y = _check_y(fx, y)
+    f = fx.f
+    if not isinstance(f, GP):
+        raise TypeError("only GP priors are accelerated here")
+    post = _posterior_exact(fx, y if y.ndim == 1 else y[:, 0])
+    try:
+        if y.ndim == 1:
+            return -post.data.alpha
+        dt = post.data.alpha.dtype
+        mean = _mean_vector(f.mean_fn, fx.x, dt)
+        D = np.asfortranarray((np.asarray(y, dtype=dt) - (0 if mean is None else np.asarray(mean, dtype=dt)[:, None])))
+        out = np.empty_like(D, order="F")
+        check(post.data.C.ctx.lib.gp_posterior_solve(post.data.C.handle, D.ctypes.data, D.shape[1], out.ctypes.data))
+        return -out
+    finally:
+        post.data.C.free()
+
+
 def logpdf_and_grad(fx: FiniteGP, y, wrt_x: bool = False) -> tuple:
     """Value and gradient of logpdf(fx, y) for the rrule of the accelerated path (the reference differentiates the same
     expression by AD — test/finite_gp_projection.jl:152-178).  Returns (logpdf, grads) with grads =

@@ -931,7 +931,6 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
                          const void* y, void* logpdf_out, double* dvar, double* dscale, void* dnoise, void* dy, void* dx) {
     const long n = x->n;
     const int d = x->d;
-    if (d > 16) return set_arg_err(3, "gradients support D <= 16");
     gp_post post{};
     post.ctx = c;
     FitOut fo;
@@ -943,16 +942,18 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     void *W_v = 0, *Ci_v = 0, *g_v = 0, *dn_v = 0, *sc_v = 0, *gx_v = 0;
     const size_t gx_b = sizeof(double) * (size_t)d * np;
     std::vector<double> gx_h(dx ? (size_t)d * np : 0);
-    const size_t M_b = sizeof(T) * (size_t)(np + 128) * ld, g_b = sizeof(double) * 32, dn_b = sizeof(T) * (size_t)np;
-    const size_t sc_b = sizeof(double) * 16;
+    const int nsc = std::max(k->nscale, 1);
+    const size_t M_b = sizeof(T) * (size_t)(np + 128) * ld, g_b = sizeof(double) * (size_t)(2 + nsc), dn_b = sizeof(T) * (size_t)np;
+    const size_t sc_b = sizeof(double) * (size_t)nsc;
     DevBufs bufs(c);
     bufs.v.push_back(post.A);  // the temporary posterior's blocks go back to the cache with everything else
     bufs.v.push_back(post.xs);
     bufs.v.push_back(post.alpha);
-    double g_h[32] = {0};
+    std::vector<double> g_hv((size_t)(2 + nsc), 0.0);  // [0] ∂/∂variance, [1] Σ_i ∂/∂Σy_ii, [2 + p] ∂/∂scale_p
+    double* g_h = g_hv.data();
     std::vector<T> dn_h((size_t)n);
-    std::vector<double> sc_h(16, 1.0);
-    for (int p = 0; p < k->nscale && p < 16; ++p) sc_h[p] = k->scale[p];
+    std::vector<double> sc_h((size_t)nsc, 1.0);
+    for (int p = 0; p < k->nscale; ++p) sc_h[p] = k->scale[p];
     int32_t rc = [&]() -> int32_t {
         RC(bufs.get(M_b, &W_v));
         RC(bufs.get(M_b, &Ci_v));
@@ -982,17 +983,22 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
             HIPCHK(hipGetLastError());
         }
         dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
-        hipLaunchKernelGGL((kgrad_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
-                           (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)g_v);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(noise_grad_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)Ci, ld,
-                           (const T*)post.alpha, n, (T*)dn_v, (double*)g_v + 24);
-        HIPCHK(hipGetLastError());
-        if (dx) {  // ∂/∂x: full-square pass (the mirrored C⁻¹ entry serves the tiles above the diagonal)
-            HIPCHK(hipMemsetAsync(gx_v, 0, gx_b, s));
-            hipLaunchKernelGGL((kgradx_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
-                               (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)gx_v, np);
+        // one launch per chunk of 16 ARD scales (a single launch for scalar / no transform, whatever D is)
+        for (int p0 = 0; p0 < (post.nscale > 1 ? post.nscale : 1); p0 += 16) {
+            hipLaunchKernelGGL(kgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
+                               (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)g_v, p0);
             HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(noise_grad_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)Ci, ld,
+                           (const T*)post.alpha, n, (T*)dn_v, (double*)g_v + 1);
+        HIPCHK(hipGetLastError());
+        if (dx) {  // ∂/∂x: full-square pass (the mirrored C⁻¹ entry serves the tiles above the diagonal), 16 dimensions per launch
+            HIPCHK(hipMemsetAsync(gx_v, 0, gx_b, s));
+            for (int p0 = 0; p0 < d; p0 += 16) {
+                hipLaunchKernelGGL(kgradx_kernel<T>, grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
+                                   (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)gx_v, np, p0);
+                HIPCHK(hipGetLastError());
+            }
             HIPCHK(hipMemcpyAsync(gx_h.data(), gx_v, gx_b, hipMemcpyDeviceToHost, s));
         }
         HIPCHK(hipMemcpyAsync(g_h, g_v, g_b, hipMemcpyDeviceToHost, s));
@@ -1008,9 +1014,9 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
     *(T*)logpdf_out = (T)fo.logpdf[0];
     if (dvar) *dvar = g_h[0];
     if (dscale)
-        for (int p = 0; p < k->nscale; ++p) dscale[p] = g_h[1 + p];
+        for (int p = 0; p < k->nscale; ++p) dscale[p] = g_h[2 + p];
     if (dnoise) {
-        if (noise->kind == 0) *(T*)dnoise = (T)g_h[24];
+        if (noise->kind == 0) *(T*)dnoise = (T)g_h[1];
         else memcpy(dnoise, dn_h.data(), sizeof(T) * (size_t)n);
     }
     if (dy)
@@ -1161,6 +1167,28 @@ template <typename T> static int32_t factor_mul_impl(gp_post* post, const void* 
                            ncols, (T*)out_v);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(out, sizeof(T) * n, out_v, sizeof(T) * np, sizeof(T) * n, ncols, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) (void)hipStreamSynchronize(s);
+    return rc;
+}
+
+// out[:, s] = C \ B[:, s] with the resident factor (forward + backward vector sweeps, all columns per sweep)
+template <typename T> static int32_t solve_impl(gp_post* post, const void* B, int ncols, void* out) {
+    gp_ctx* c = post->ctx;
+    const long n = post->n, np = post->np;
+    void* r_v = 0;
+    const size_t b = sizeof(T) * (size_t)np * ncols;
+    DevBufs bufs(c);
+    RC(bufs.get(b, &r_v));
+    hipStream_t s = c->sm;
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipMemsetAsync(r_v, 0, b, s));
+        HIPCHK(hipMemcpy2DAsync(r_v, sizeof(T) * np, B, sizeof(T) * n, sizeof(T) * n, ncols, hipMemcpyHostToDevice, s));
+        RC(trsv<T>(c, s, (const T*)post->A, post->ld, np, (T*)r_v, np, ncols, true));
+        RC(trsv<T>(c, s, (const T*)post->A, post->ld, np, (T*)r_v, np, ncols, false));
+        HIPCHK(hipMemcpy2DAsync(out, sizeof(T) * n, r_v, sizeof(T) * np, sizeof(T) * n, ncols, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         return 0;
     }();
@@ -1691,6 +1719,18 @@ int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, vo
     HIPCHK(hipSetDevice(c->device));
     RC(multi_gather(post));
     return post->dtype == 0 ? factor_mul_impl<double>(post, xi, ncols, out) : factor_mul_impl<float>(post, xi, ncols, out);
+}
+
+int32_t gp_posterior_solve(gp_post* post, const void* B, int32_t ncols, void* out) {
+    Guard gd(post);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_post");
+    if (!B) return set_arg_err(2, "B is NULL");
+    if (ncols < 1) return set_arg_err(3, "ncols must be >= 1");
+    if (!out) return set_arg_err(4, "out is NULL");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    RC(multi_gather(post));
+    return post->dtype == 0 ? solve_impl<double>(post, B, ncols, out) : solve_impl<float>(post, B, ncols, out);
 }
 
 int64_t gp_posterior_n(gp_post* post) {

@@ -1173,26 +1173,71 @@ template <typename T> __device__ __forceinline__ void kappa_and_dr2(int kind, T 
     dk = T(-5.0 / 6.0) * (T(1) + a) * e;
 }
 
-template <typename T, int NSMAX>
+// Both gradient kernels take any input dimension D: r² needs every dimension, the per-dimension sums only the 16 of the
+// launch's chunk [p0, p0 + 16) — the dimension-major tiles are staged through LDS 16 dimensions at a time, r² of the thread's
+// 64 (row, column) pairs accumulates in registers, and the chunk's own tiles stay in a second LDS image for the sums.
+// The host launches once per chunk (one launch for D <= 16, and for scalar / no transforms whatever D is).
+template <typename T>
+__device__ __forceinline__ void grad_stage_d2(T (*xi)[128], T (*xj)[128], T (*xpi)[128], T (*xpj)[128], const T* __restrict__ x, long ldx,
+                                              int d, int p0, int m0, int n0, T (&d2r)[32][2]) {
+    constexpr int DC = 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) d2r[rr][0] = d2r[rr][1] = T(0);
+    for (int dc = 0; dc < d; dc += DC) {
+        __syncthreads();
+        for (int e = tid; e < DC * 128; e += 256) {
+            const int dd = e >> 7, i = e & 127;
+            const bool in = dc + dd < d;
+            const T vi = in ? x[(long)(dc + dd) * ldx + m0 + i] : T(0), vj = in ? x[(long)(dc + dd) * ldx + n0 + i] : T(0);
+            xi[dd][i] = vi;
+            xj[dd][i] = vj;
+            if (dc == p0) {
+                xpi[dd][i] = vi;
+                xpj[dd][i] = vj;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+            const int row = w + 4 * rr;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int col = 2 * lane + cc;
+                T acc = d2r[rr][cc];
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) {
+                    const T t = xi[dd][row] - xj[dd][col];
+                    acc = fma(t, t, acc);
+                }
+                d2r[rr][cc] = acc;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// g layout: [0] ∂/∂variance, [1] (noise sum, written by noise_grad_kernel), [2 + p] ∂/∂scale_p
+template <typename T>
 __global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ x, long ldx, int d,
                                                      int kind, T variance, int nscale, const double* __restrict__ scale,
-                                                     const T* __restrict__ alpha, long n, double* __restrict__ g) {
+                                                     const T* __restrict__ alpha, long n, double* __restrict__ g, int p0) {
     constexpr int DC = 16;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     if (n0 > m0) return;
     __shared__ T xi[DC][128];
     __shared__ T xj[DC][128];
-    __shared__ double red[4][1 + NSMAX];
+    __shared__ T xpi[DC][128];
+    __shared__ T xpj[DC][128];
+    __shared__ double red[4][1 + DC];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < d * 128; e += 256) {  // d <= DC (checked by the host)
-        const int dd = e >> 7, i = e & 127;
-        xi[dd][i] = x[(long)dd * ldx + m0 + i];
-        xj[dd][i] = x[(long)dd * ldx + n0 + i];
-    }
-    __syncthreads();
-    double acc[1 + NSMAX];
+    T d2r[32][2];
+    grad_stage_d2<T>(xi, xj, xpi, xpj, x, ldx, d, p0, m0, n0, d2r);
+    const int np_ = nscale > 1 ? min(DC, nscale - p0) : 0;  // ARD scales of this chunk
+    double acc[1 + DC];
 #pragma unroll
-    for (int p = 0; p <= NSMAX; ++p) acc[p] = 0.0;
+    for (int p = 0; p <= DC; ++p) acc[p] = 0.0;
+#pragma unroll 2
     for (int rr = 0; rr < 32; ++rr) {
         const int row = w + 4 * rr;
         const long gi = m0 + row;
@@ -1203,11 +1248,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, 
             const int col = 2 * lane + cc;
             const long gj = n0 + col;
             if (gj > gi || gj >= n) continue;
-            T d2 = 0;
-            for (int dd = 0; dd < d; ++dd) {
-                const T t = xi[dd][row] - xj[dd][col];
-                d2 = fma(t, t, d2);
-            }
+            const T d2 = d2r[rr][cc];
             T kap, dk;
             kappa_and_dr2<T>(kind, d2, kap, dk);
             const double wgt = ((double)ai * (double)alpha[gj] - (double)Cinv[gi * ld + gj]) * (gi == gj ? 0.5 : 1.0);
@@ -1217,84 +1258,83 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, 
                 acc[1] += wk * (double)d2;
             } else if (nscale > 1) {
 #pragma unroll
-                for (int p = 0; p < NSMAX; ++p)
-                    if (p < nscale) {
-                        const T t = xi[p][row] - xj[p][col];
+                for (int p = 0; p < DC; ++p)
+                    if (p < np_) {
+                        const T t = xpi[p][row] - xpj[p][col];
                         acc[1 + p] += wk * (double)(t * t);
                     }
             }
         }
     }
 #pragma unroll
-    for (int p = 0; p <= NSMAX; ++p) {
+    for (int p = 0; p <= DC; ++p) {
         double v = acc[p];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) red[w][p] = v;
     }
     __syncthreads();
-    if (tid <= nscale && tid <= NSMAX) {
-        double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        if (tid >= 1) v /= scale[tid - 1];  // the 1/s (1/v_p) factor of ∂r²
-        atomicAdd(g + tid, v);
+    const int nout = nscale == 1 ? 1 : np_;
+    if (tid <= nout) {
+        const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid == 0) {
+            if (p0 == 0) atomicAdd(g, v);  // the variance term once
+        } else {
+            atomicAdd(g + 2 + p0 + tid - 1, v / scale[p0 + tid - 1]);  // the 1/s (1/v_p) factor of ∂r²
+        }
     }
 }
 // kgradx: ∂logpdf/∂x_ip = 2 s_p σ² Σ_j (α_i α_j − C⁻¹_ij) dκ/dr²(r²_ij) (u_ip − u_jp)   (u = s∘x; both orders of the symmetric pair
 //   folded in) — the input gradient a deep-kernel model back-propagates (examples/2-deep-kernel-learning/script.jl).  One
 //   128×128 tile of the FULL square per workgroup (C⁻¹ is stored lower: the mirrored entry is read for tiles above the diagonal);
-//   row sums by wave shuffles, one atomicAdd per (row, p).  gx: double [d][ldg] (dimension-major like x).
-template <typename T, int NSMAX>
+//   row sums by wave shuffles, one atomicAdd per (row, p).  gx: double [d][ldg] (dimension-major like x); dimensions [p0, p0+16).
+template <typename T>
 __global__ __launch_bounds__(256) void kgradx_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ x, long ldx, int d,
                                                       int kind, T variance, int nscale, const double* __restrict__ scale,
-                                                      const T* __restrict__ alpha, long n, double* __restrict__ gx, long ldg) {
+                                                      const T* __restrict__ alpha, long n, double* __restrict__ gx, long ldg, int p0) {
     constexpr int DC = 16;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     __shared__ T xi[DC][128];
     __shared__ T xj[DC][128];
+    __shared__ T xpi[DC][128];
+    __shared__ T xpj[DC][128];
     __shared__ T aj[128];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < d * 128; e += 256) {  // d <= DC (checked by the host)
-        const int dd = e >> 7, i = e & 127;
-        xi[dd][i] = x[(long)dd * ldx + m0 + i];
-        xj[dd][i] = x[(long)dd * ldx + n0 + i];
-    }
     if (tid < 128) aj[tid] = (n0 + tid < n) ? alpha[n0 + tid] : T(0);
-    __syncthreads();
+    T d2r[32][2];
+    grad_stage_d2<T>(xi, xj, xpi, xpj, x, ldx, d, p0, m0, n0, d2r);
+    const int np_ = min(DC, d - p0);
+#pragma unroll 2
     for (int rr = 0; rr < 32; ++rr) {
         const int row = w + 4 * rr;
         const long gi = m0 + row;
         if (gi >= n) continue;  // wave-uniform
         const T ai = alpha[gi];
-        double acc[NSMAX];
+        double acc[DC];
 #pragma unroll
-        for (int p = 0; p < NSMAX; ++p) acc[p] = 0.0;
+        for (int p = 0; p < DC; ++p) acc[p] = 0.0;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int col = 2 * lane + cc;
             const long gj = n0 + col;
             if (gj >= n || gj == gi) continue;
-            T d2 = 0;
-            for (int dd = 0; dd < d; ++dd) {
-                const T t = xi[dd][row] - xj[dd][col];
-                d2 = fma(t, t, d2);
-            }
             T kap, dk;
-            kappa_and_dr2<T>(kind, d2, kap, dk);
+            kappa_and_dr2<T>(kind, d2r[rr][cc], kap, dk);
             const T ci = gi >= gj ? Cinv[gi * ld + gj] : Cinv[gj * ld + gi];
             const double wgt = ((double)ai * (double)aj[col] - (double)ci) * (double)dk;
 #pragma unroll
-            for (int p = 0; p < NSMAX; ++p)
-                if (p < d) acc[p] += wgt * (double)(xi[p][row] - xj[p][col]);
+            for (int p = 0; p < DC; ++p)
+                if (p < np_) acc[p] += wgt * (double)(xpi[p][row] - xpj[p][col]);
         }
 #pragma unroll
-        for (int p = 0; p < NSMAX; ++p) {
-            if (p >= d) break;
+        for (int p = 0; p < DC; ++p) {
+            if (p >= np_) break;
             double v = acc[p];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             if (lane == 0) {
-                const double sp = nscale == 0 ? 1.0 : (nscale == 1 ? scale[0] : scale[p]);
-                atomicAdd(gx + (long)p * ldg + gi, 2.0 * sp * (double)variance * v);
+                const double sp = nscale == 0 ? 1.0 : (nscale == 1 ? scale[0] : scale[p0 + p]);
+                atomicAdd(gx + (long)(p0 + p) * ldg + gi, 2.0 * sp * (double)variance * v);
             }
         }
     }

@@ -332,7 +332,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 HIPCHK(hipMemcpy2DAsync((T*)zsT_v + m_old, sizeof(T) * mp, zn_v, sizeof(T) * m2p, sizeof(T) * m2, d, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpy2DAsync(zsD_v, sizeof(double) * mp, prev->zs, sizeof(double) * mpo, sizeof(double) * m_old, d, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpy2DAsync((double*)zsD_v + m_old, sizeof(double) * mp, znD_v, sizeof(double) * m2p, sizeof(double) * m2, d, hipMemcpyDeviceToDevice, s));
-                // X = K(z_new, z_old) L11⁻ᵀ = U12ᵀ (in Ld's storage, free until the finalisation), S = C22 + jitter − U12ᵀU12 (in I's)
+                // X = K(z_new, z_old) L11⁻ᵀ = U12ᵀ (in Ld's storage, free until the finalisation), S = C22 − U12ᵀU12 (in I's)
                 double* Xb = Ld;
                 double* Sb = (double*)I_v;
                 const long ldx = ldo, lds = m2p + c->ldpad;
@@ -348,8 +348,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 {
                     GridMap g = plain_map(1, 0, 0);
                     dim3 grid((unsigned)(m2p / 128), (unsigned)(m2p / 128));
+                    // C22 = _symmetric(cov(prior, z_new)) carries NO jitter in the reference (src/sparse_approximations.jl:138)
                     hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Sb, lds, (const double*)znD_v, m2p,
-                                       (const double*)znD_v, m2p, d, k->kind, k->variance, (const double*)jit_v, m2, m2, 1, g,
+                                       (const double*)znD_v, m2p, d, k->kind, k->variance, (const double*)nullptr, m2, m2, 1, g,
                                        (const double*)nullptr, (const double*)nullptr);
                     HIPCHK(hipGetLastError());
                 }

@@ -1,5 +1,5 @@
 # HipGPs.jl — Julia host shim: keeps the AbstractGP / FiniteGP / PosteriorGP surface of AbstractGPs.jl
-# and routes the logpdf / posterior hot path through `ccall` into libgpmi355.so (include/gpmi355.h, ABI v2).
+# and routes the logpdf / posterior hot path through `ccall` into libgpmi355.so (include/gpmi355.h, ABI v3).
 #
 # NOT EXECUTED in the build container (Julia is not installed there — SURVEY.md §0 F3); it is the
 # reference-side binding a maintainer adds (INTEGRATION.md).  abstractgps.jl_amd/api.py is its ctypes
@@ -197,6 +197,53 @@ function Distributions.logpdf(fx::FiniteGP{<:HipGP}, Y::AbstractVecOrMat{<:Real}
             fx.f.ctx.handle, a.ck, a.cx, a.cn, mptr, Yd, size(Yd, 1), size(Yd, 2), out))
     end
     return Y isa AbstractVector ? out[1] : out
+end
+
+# ---- the two terms of logpdf on their own (src/finite_gp_projection.jl:313-337): sqmahal, logdetcov, gradlogpdf ----------------
+function logpdf_terms(fx::FiniteGP{<:HipGP}, Y::Union{Nothing,AbstractVecOrMat{<:Real}}; logdet::Bool, sq::Bool)
+    a = marshal(fx, Y === nothing ? input_eltype(fx.x) : eltype(Y))
+    a === nothing && return nothing
+    T = a.T
+    Yd = Y === nothing ? nothing : Matrix{T}(reshape(Y, size(Y, 1), :))
+    Yd === nothing || size(Yd, 1) == length(fx) || throw(DimensionMismatch("length(fx) = $(length(fx)) but Y has $(size(Yd, 1)) rows"))
+    ld = Ref{T}(zero(T))
+    out = Vector{T}(undef, Yd === nothing ? 1 : size(Yd, 2))
+    mptr = a.m === nothing ? C_NULL : pointer(a.m)
+    GC.@preserve a Yd out begin
+        check(ccall((:gp_logpdf_terms, libgpmi355), Int32,
+            (Ptr{Cvoid}, Ref{CKernel}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+            fx.f.ctx.handle, a.ck, a.cx, a.cn, mptr, Yd === nothing ? C_NULL : pointer(Yd), length(fx),
+            Yd === nothing ? 0 : size(Yd, 2), logdet ? Base.unsafe_convert(Ptr{Cvoid}, ld) : C_NULL, sq ? pointer(out) : C_NULL))
+    end
+    return (ld[], out)
+end
+function Distributions.logdetcov(fx::FiniteGP{<:HipGP})                                  # :313
+    r = logpdf_terms(fx, nothing; logdet=true, sq=false)
+    return r === nothing ? logdetcov(stock(fx)) : r[1]
+end
+function Distributions.sqmahal(fx::FiniteGP{<:HipGP}, x::AbstractVector)                 # :315-318
+    r = logpdf_terms(fx, x; logdet=false, sq=true)
+    return r === nothing ? sqmahal(stock(fx), x) : r[2][1]
+end
+function Distributions.sqmahal(fx::FiniteGP{<:HipGP}, X::AbstractMatrix)                 # :320-323
+    r = logpdf_terms(fx, X; logdet=false, sq=true)
+    return r === nothing ? sqmahal(stock(fx), X) : r[2]
+end
+# gradlogpdf(f, x) = C \ (m .- x) (:328-337): −α of the posterior fit; further columns reuse that fit's resident factor
+function Distributions.gradlogpdf(fx::FiniteGP{<:HipGP}, x::AbstractVector)
+    marshal(fx, eltype(x)) === nothing && return gradlogpdf(stock(fx), x)
+    return -posterior(fx, x).data.α
+end
+function Distributions.gradlogpdf(fx::FiniteGP{<:HipGP}, X::AbstractMatrix)
+    a = marshal(fx, eltype(X))
+    a === nothing && return gradlogpdf(stock(fx), X)
+    post = posterior(fx, X[:, 1])
+    T = a.T
+    D = a.m === nothing ? Matrix{T}(X) : Matrix{T}(X) .- a.m
+    out = similar(D)
+    GC.@preserve D out check(ccall((:gp_posterior_solve, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+        getfield(post.data.C, :handle), D, size(D, 2), out))
+    return -out
 end
 
 # ---- value + gradient: one factorisation, C⁻¹ by blocked TRSM + MFMA SYRK, one fused ½Σ(αᵢαⱼ − C⁻¹ᵢⱼ)∂Cᵢⱼ pass ----------

@@ -196,7 +196,7 @@ int32_t gp_posterior_rand(gp_post* post, const gp_points* xs, const void* prior_
  *   ∂/∂θ = ½ Σ_ij (α_i α_j − C⁻¹_ij) ∂C_ij/∂θ.
  * Outputs (all optional except logpdf_out; kernel dtype unless noted):
  *   dvariance_out  double[1]        ∂/∂(kernel variance)
- *   dscale_out     double[nscale]   ∂/∂scale (ScaleTransform s, or ARDTransform v_p; D <= 16)
+ *   dscale_out     double[nscale]   ∂/∂scale (ScaleTransform s, or ARDTransform v_p; any D: 16 dimensions per pass)
  *   dnoise_out     noise.kind 0: 1 entry ∂/∂σ² = ½(αᵀα − tr C⁻¹);  kind 1: n entries ½(α_i² − C⁻¹_ii)
  *   dy_out         n entries ∂/∂y = −α   (∂/∂m = +α for a mean vector m)
  *   dx_out         n×d entries ∂/∂x in the container layout of x (what a deep-kernel model back-propagates into its feature
@@ -216,6 +216,11 @@ int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* n
 /* out[:, s] = C.U' * xi[:, s] (n×ncols column-major host arrays, leading dimension n): the sampling transform of
  * rand / _rand! (src/finite_gp_projection.jl:233-237, 271-277); the caller draws xi = randn(rng, n, ncols). */
 int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, void* out);
+
+/* out[:, s] = C \ B[:, s] (n×ncols column-major host arrays) by forward + backward sweeps over the resident factor — what
+ * gradlogpdf(fx, X) = C \ (m .- X) (src/finite_gp_projection.jl:328-337) needs for the columns beyond the fitted one, and
+ * `post.data.C \ v` of user code. */
+int32_t gp_posterior_solve(gp_post* post, const void* B, int32_t ncols, void* out);
 
 /* C.U (n×n column-major upper, strictly-lower part zero) to the host — parity / debugging only. */
 int32_t gp_posterior_get_factor(gp_post* post, void* U_out);
@@ -240,8 +245,8 @@ int32_t gp_vfe_update(gp_vfe* old, const gp_points* x2, const gp_noise* noise2, 
 /* update_posterior(f_post_approx, fz) — append pseudo-points (src/sparse_approximations.jl:131-176): bordered Cholesky of
  * K_zz against the resident factor (update_chol, src/util/common_covmat_ops.jl:38-42), then the retained observations are
  * streamed once more to form ONLY the new block rows of B Bᵀ / B b_y / ‖B‖²_F (the reference keeps B_εf, x, Σy, b_y in its
- * cache for this; here x, Σy^-1/2 and b_y stay on the device and B is never stored).  jitter of the new points = the old
- * one.  `old` stays valid.  objective_out: ELBO / DTC evidence with the enlarged pseudo-point set. */
+ * cache for this; here x, Σy^-1/2 and b_y stay on the device and B is never stored).  As in the reference (:138) the new
+ * diagonal block C22 = cov(prior, z2) carries no jitter.  `old` stays valid.  objective_out: ELBO / DTC evidence with the enlarged pseudo-point set. */
 int32_t gp_vfe_append(gp_vfe* old, const gp_points* z2, gp_vfe** out, void* objective_out_or_null);
 /* mean / var / cov / mean_and_var / mean_and_cov (src/sparse_approximations.jl:183-217).  what: bit0 mean, bit1 var,
  * bit2 full cov (ns×ns column-major) = K** − AᵀA + (Λ_ε.U⁻ᵀA)ᵀ(Λ_ε.U⁻ᵀA). */

@@ -13,7 +13,7 @@ def test_exports_every_declared_symbol(agp):
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert set(declared) == set(agp._lib.PROTOTYPES), set(declared) ^ set(agp._lib.PROTOTYPES)
-    assert lib.gp_abi_version() == 2
+    assert lib.gp_abi_version() == 3
 
 
 def test_dead_handles_are_rejected_not_ub(agp):

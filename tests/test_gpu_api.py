@@ -173,15 +173,20 @@ def test_vfe_append_pseudo_points(agp, dtype, m1, m2):
     tol = 1e-6 if dtype == np.float64 else 2e-2
     np.testing.assert_allclose(m3, o3.mean(xs), atol=tol)
     np.testing.assert_allclose(v3, o3.var(xs), atol=tol)
-    np.testing.assert_allclose(m3, ob.mean(xs), atol=tol)
-    # the objective of the enlarged approximation == batch ELBO
+    # Against a BATCH fit the appended approximation differs by O(jitter): the reference's append puts no jitter on the new
+    # diagonal block C22 = cov(prior, z_new) (src/sparse_approximations.jl:138) while a batch fit has it on all of K_zz.
+    # Quantified here: 1e-6 jitter moves the predictions by < 1e-4 and the ELBO by < 1e-5 relative.
+    tol_b = 1e-4 if dtype == np.float64 else 2e-2
+    np.testing.assert_allclose(m3, ob.mean(xs), atol=tol_b)
+    # the objective of the enlarged approximation vs the reference-algorithm oracle (tight) and vs the batch ELBO (O(jitter))
+    assert float(p3.objective) == pytest.approx(o.objective_from_posterior(o3, o.FiniteGP(of, x, s2), y), rel=1e-8 if dtype == np.float64 else 2e-4)
     elbo_b = o.elbo(of, np.concatenate([z1, z2]), jitter, o.FiniteGP(of, x, s2), y)
-    assert float(p3.objective) == pytest.approx(elbo_b, rel=1e-8 if dtype == np.float64 else 2e-4)
+    assert float(p3.objective) == pytest.approx(elbo_b, rel=1e-5 if dtype == np.float64 else 2e-4)
     # and == the device batch fit
     pb = agp.posterior(agp.VFE(f(agp.RowVecs(np.concatenate([z1, z2]).astype(dtype)), jitter)), f(agp.RowVecs(xd), s2d), yd)
     mb, vb = pb.mean_and_var(agp.RowVecs(xs.astype(dtype)))
-    np.testing.assert_allclose(m3, mb, atol=tol)
-    np.testing.assert_allclose(v3, vb, atol=tol)
+    np.testing.assert_allclose(m3, mb, atol=tol_b)
+    np.testing.assert_allclose(v3, vb, atol=tol_b)
     if dtype == np.float64:
         assert _relnorm(p3.data["m_eps"], o3.m_eps) <= 1e-5
         np.testing.assert_allclose(p3.cov(agp.RowVecs(xs)), o3.cov(xs), atol=1e-6)
@@ -347,3 +352,93 @@ def test_conformance_approx_posterior(agp):
     xs = rng.random(19) * 3
     zs = rng.random(12) * 3
     _internal_interface(agp, rng, ap, xs, zs, np.float64, atol=1e-8, s2=1e-1, vfe_checks=False, check_posterior=False)
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["one-device", "virtual-2x2"])
+def test_sqmahal_logdetcov_gradlogpdf(agp, multi):
+    """Distributions.sqmahal / logdetcov / gradlogpdf on a FiniteGP (src/finite_gp_projection.jl:313-337) from the device's own
+    factorisation — the two terms logpdf adds up, returned separately (gp_logpdf_terms), and C \\ (m .- x) for vectors and
+    matrices (gp_posterior_solve for the columns beyond the fitted one)."""
+    x, y, s2, f, of, xin, rng = _setup(agp, 700, 3, 3)
+    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128) if multi else None
+    try:
+        if ctx is not None:
+            f = agp.GP(f.mean_fn, f.kernel, ctx=ctx)
+        fx, ofx = f(xin, s2), o.FiniteGP(of, x, s2)
+        m, Cm = o.mean_and_cov(ofx)
+        U = o.cholesky_upper(Cm)
+        Y = np.stack([y, np.cos(3 * y), y[::-1]], axis=1)
+        assert agp.logdetcov(fx) == pytest.approx(o.logdet_chol(U), rel=1e-12)
+        assert agp.sqmahal(fx, y) == pytest.approx(float(o._sqmahal(m, U, y)), rel=1e-10)
+        np.testing.assert_allclose(agp.sqmahal(fx, Y), o._sqmahal(m, U, Y), rtol=1e-10)
+        # logpdf = −½ (N log 2π + logdetcov + sqmahal)                                           :306-311
+        assert agp.logpdf(fx, y) == pytest.approx(-0.5 * (len(y) * np.log(2 * np.pi) + agp.logdetcov(fx) + agp.sqmahal(fx, y)), rel=1e-13)
+        g = agp.gradlogpdf(fx, y)
+        go = o.chol_solve(U, m - y)                                                               # _gradlogpdf :337
+        assert _relnorm(g, go) <= 1e-8
+        G = agp.gradlogpdf(fx, Y)
+        Go = o.chol_solve(U, m[:, None] - Y)
+        assert G.shape == Y.shape and _relnorm(G, Go) <= 1e-8
+        # the factor's logdet is also available from a posterior handle (gp_posterior_logdet)
+        post = agp.posterior(fx, y)
+        ld = agp._lib.C.c_double()
+        agp._lib.check(post.data.C.ctx.lib.gp_posterior_logdet(post.data.C.handle, agp._lib.C.byref(ld)))
+        assert ld.value == pytest.approx(o.logdet_chol(U), rel=1e-12)
+    finally:
+        if ctx is not None:
+            ctx.close()
+
+
+def test_sqmahal_fp32_and_argument_errors(agp):
+    x, y, s2, f, of, xin, rng = _setup(agp, 300, 2, 0, vec_noise=False)
+    x32, y32 = x.astype(np.float32), y.astype(np.float32)
+    fx32 = f(agp.RowVecs(x32), np.float32(s2))
+    m, Cm = o.mean_and_cov(o.FiniteGP(of, x32.astype(np.float64), s2))
+    U = o.cholesky_upper(Cm)
+    v = agp.sqmahal(fx32, y32)
+    assert isinstance(v, np.float32) and float(v) == pytest.approx(float(o._sqmahal(m, U, y32.astype(np.float64))), rel=2e-3)
+    assert isinstance(agp.logdetcov(fx32), np.float32)
+    with pytest.raises(ValueError):
+        agp.sqmahal(f(xin, s2), y[:-1])                                                           # DimensionMismatch
+
+
+def test_predictive_marginals_many_test_points(agp):
+    """N* = 10 000 at N = 4 096: the predictive variance streams x* in chunks of 4 096 (three chunks, the last one ragged) —
+    mean_and_var / marginals at scale (src/exact_gpr_posterior.jl:85-90) against the oracle."""
+    n, ns, d = 4096, 10000, 3
+    x, y = o.synth_inputs(n, d, 31)
+    rng = np.random.default_rng(8)
+    xs = rng.standard_normal((ns, d)) * 1.2
+    f = agp.GP(0.2, 1.1 * agp.Matern52Kernel() @ agp.ScaleTransform(0.9))
+    of = o.GP(o.Kernel(o.MATERN52, 1.1, 0.9), 0.2)
+    post = agp.posterior(f(agp.RowVecs(x), 0.05), y)
+    opost = o.posterior(o.FiniteGP(of, x, 0.05), y)
+    m, v = post.mean_and_var(agp.RowVecs(xs))
+    mo, vo = opost.mean_and_var(xs)
+    np.testing.assert_allclose(m, mo, atol=1e-8)
+    np.testing.assert_allclose(v, vo, atol=1e-9)
+    np.testing.assert_allclose(post.var(agp.RowVecs(xs[4000:4200])), vo[4000:4200], atol=1e-9)   # a window across a chunk boundary
+    mm, sd = agp.marginals(post(agp.RowVecs(xs), 0.01))
+    np.testing.assert_allclose(sd, np.sqrt(vo + 0.01), atol=1e-9)
+
+
+@pytest.mark.parametrize("d,ard", [(17, True), (40, True), (33, False), (16, True)])
+def test_gradient_for_inputs_of_any_dimension(agp, d, ard):
+    """gp_logpdf_grad for D > 16 (round 2 refused it): the gradient kernels stage the dimension-major tiles 16 dimensions at a
+    time, one launch per chunk of ARD scales / input dimensions — value, ∂/∂variance, ∂/∂scale (scalar and ARD), ∂/∂noise and
+    ∂/∂x against the oracle's dense-calculus gradient (finite-difference checked in tests/test_oracle.py)."""
+    n = 260
+    x, y = o.synth_inputs(n, d, 3)
+    x *= 0.4
+    rng = np.random.default_rng(d)
+    sc = (0.3 + 0.4 * rng.random(d)) if ard else 0.5
+    k = 1.3 * agp.Matern52Kernel() @ (agp.ARDTransform(sc) if ard else agp.ScaleTransform(sc))
+    fx = agp.GP(k)(agp.RowVecs(x), 0.1)
+    ofx = o.FiniteGP(o.GP(o.Kernel(o.MATERN52, 1.3, sc)), x, 0.1)
+    lp, g = agp.logpdf_and_grad(fx, y, wrt_x=True)
+    go = o.logpdf_grad(ofx, y)
+    assert lp == pytest.approx(float(o.logpdf(ofx, y)), rel=1e-10)
+    assert g["variance"] == pytest.approx(go["variance"], rel=1e-7)
+    np.testing.assert_allclose(g["scale"], go["scale"], rtol=1e-6, atol=1e-9)
+    assert g["noise"] == pytest.approx(go["noise"], rel=1e-7)
+    np.testing.assert_allclose(g["x"], go["x"], rtol=1e-6, atol=1e-8)

@@ -114,18 +114,24 @@ def test_multi_not_positive_definite_reports_first_minor(agp):
         one.close()
 
 
-def test_multi_fp32_is_rejected_and_other_entry_points_run_on_device0(agp):
+def test_multi_fp32_and_wide_Y_and_other_entry_points_run_on_device0(agp):
+    """what the block-cyclic driver does not take (fp32, more than 128 right-hand-side columns) runs on the single-device engine of
+    devices[0] — `every other entry point works unchanged` of include/gpmi355.h"""
     x, y = o.synth_inputs(600, 3, 9)
     ctx = agp.Context(devices=[0, 0], nb=128)
     try:
         assert ctx.multi_info()["P"] == 2 and ctx.multi_info()["Q"] == 1       # default grid: P = ndev, Q = 1
         f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
-        with pytest.raises(ValueError):
-            agp.logpdf(f(agp.RowVecs(x.astype(np.float32)), 0.1), y.astype(np.float32))
+        of = o.GP(o.Kernel(o.SE))
+        lp32 = agp.logpdf(f(agp.RowVecs(x.astype(np.float32)), np.float32(0.1)), y.astype(np.float32))
+        assert isinstance(lp32, np.float32)
+        assert float(lp32) == pytest.approx(float(o.logpdf(o.FiniteGP(of, x.astype(np.float32).astype(np.float64), 0.1), y.astype(np.float32).astype(np.float64))), rel=1e-3)
+        Y = np.random.default_rng(0).standard_normal((600, 130))                # 130 columns > 128 RHS rows of the multi-device layout
+        np.testing.assert_allclose(agp.logpdf(f(agp.RowVecs(x), 0.1), Y), o.logpdf(o.FiniteGP(of, x, 0.1), Y), rtol=1e-10)
+        ctx.trim()                                                              # also empties the rank contexts' caches
         # VFE / kernelmatrix / gradients on a multi ctx run on its first device
         z = x[:50]
         e = agp.elbo(agp.VFE(f(agp.RowVecs(z), 1e-6)), f(agp.RowVecs(x), 0.1), y)
-        of = o.GP(o.Kernel(o.SE))
         assert e == pytest.approx(o.elbo(of, z, 1e-6, o.FiniteGP(of, x, 0.1), y), rel=1e-8)
         lp, g = agp.logpdf_and_grad(f(agp.RowVecs(x), 0.1), y)
         assert lp == pytest.approx(float(o.logpdf(o.FiniteGP(of, x, 0.1), y)), rel=1e-10)

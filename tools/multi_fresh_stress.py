@@ -1,0 +1,68 @@
+"""Fresh-context stress of the multi-device driver (virtual ranks on one GPU): every repetition creates a NEW context and checks
+its FIRST fit against the oracle — round 2's wrong results were all first fits of fresh contexts (later fits of the same problem
+can read stale-but-correct data from recycled buffers).  Inputs vary per repetition for the same reason.
+   python tools/multi_fresh_stress.py REPS [sk=0|1] [prio=0|1] [check=N] [comm=p2p|rccl] [hwq=16] [grids=4x2,8x1,...]
+Environment is set up here (GPU_MAX_HW_QUEUES must precede HIP's initialisation).  Prints one line per failure with the
+library's diagnostics and, for wrong numbers, the first wrong block column of the factor; exit status 1 on any failure."""
+import os
+import sys
+import time
+from pathlib import Path
+
+args = dict(a.split("=") for a in sys.argv[2:] if "=" in a)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+os.environ["GPU_MAX_HW_QUEUES"] = args.get("hwq", "16")
+os.environ["GPMI_COMM_PRIO"] = args.get("prio", "1")
+os.environ["GPMI_MULTI_SK"] = args.get("sk", "1")
+ROOT = Path(__file__).resolve().parents[1]
+if args.get("comm") == "rccl":
+    os.environ["GPMI_COMM"] = "rccl"
+    os.environ["GPMI_RCCL_LIB"] = str(ROOT / "tests" / "rccl_mock" / "librccl_mock.so")
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+import abstractgps_jl_amd as agp  # noqa: E402
+from oracle import gp_oracle as o  # noqa: E402
+
+check = int(args.get("check", "0"))
+grids = [tuple(int(v) for v in g.split("x")) for g in args.get("grids", "4x2,8x1,2x4,2x3").split(",")]
+n, nb = int(args.get("n", "2049")), int(args.get("nb", "128"))
+bad = tot = 0
+t0 = time.time()
+for rep in range(reps):
+    for gi, (P, Q) in enumerate(grids):
+        rng = np.random.default_rng(1000 * rep + gi)
+        d = int(rng.integers(1, 4))
+        X = rng.standard_normal((n, d))
+        y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+        sig = float(rng.uniform(0.03, 0.3))
+        depth = int(rng.integers(1, 4))
+        of = o.GP(o.Kernel(o.SE, 1.0, 1.0))
+        lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, X, sig), y)
+        ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+        ctx.set_param("lookahead_depth", depth)
+        ctx.set_param("multi_timeout_s", 120)
+        if check:
+            ctx.set_param("multi_check", check)
+        tot += 1
+        try:
+            post = agp.posterior(agp.GP(agp.SqExponentialKernel(), ctx=ctx)(agp.RowVecs(X), sig), y)
+            rel = abs(float(post.logpdf_value) - lp_ref) / abs(lp_ref)
+            arel = float(np.linalg.norm(post.data.alpha - opost.alpha) / np.linalg.norm(opost.alpha))
+            if not (rel <= 1e-10 and arel <= 1e-8):
+                bad += 1
+                U = post.data.C.U
+                err = np.abs(U - opost.U)
+                cols = np.where(err.max(axis=0) > 1e-9)[0]
+                rows = np.where(err.max(axis=1) > 1e-9)[0]
+                print(f"WRONG rep {rep} grid {P}x{Q} depth {depth} d {d}: logpdf rel {rel:.2e} alpha rel {arel:.2e}; factor differs first at "
+                      f"U row {rows.min() if rows.size else -1} (L column block {rows.min() // nb if rows.size else -1}), "
+                      f"U col {cols.min() if cols.size else -1} (L row block {cols.min() // nb if cols.size else -1}), nan {int(np.isnan(U).sum())}", flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print(f"ERROR rep {rep} grid {P}x{Q} depth {depth} d {d}: {type(e).__name__}: {str(e)[:1500]}", flush=True)
+        ctx.close()
+print(f"fresh-context first fits: {bad} bad of {tot} (sk={os.environ['GPMI_MULTI_SK']} prio={os.environ['GPMI_COMM_PRIO']} check={check} "
+      f"comm={args.get('comm', 'copies')} hwq={os.environ['GPU_MAX_HW_QUEUES']} n={n} nb={nb}) in {time.time() - t0:.0f}s", flush=True)
+sys.exit(1 if bad else 0)
