@@ -1,8 +1,8 @@
 """abstractgps.jl_amd — MI355X-native engine for the AbstractGPs.jl logpdf / posterior hot path.
 
 Holds only what the path needs: `csrc/` (hand-written HIP kernels + the C ABI of include/gpmi355.h),
-the Python mirror of the reference's FiniteGP API (`api.py`, what the tests run), the multi-process
-block-cyclic driver (`dist.py`) and the Julia shim source (`julia/HipGPs.jl`).
+the Python mirror of the reference's FiniteGP API (`api.py`, what the tests run) and the Julia shim source
+(`julia/HipGPs.jl`).  Multi-device fits are driven inside the library (`csrc/multi.hip`, gp_ctx_create_multi).
 
 The directory name contains a dot, so import it through the root-level shim:
     import abstractgps_jl_amd as agp

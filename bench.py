@@ -133,6 +133,77 @@ def pmc_traffic(n: int) -> dict:
                                                    "read": rd, "write": wr, "source": str(path.relative_to(ROOT))}}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
+
+
+def other_configs(agp, ctx, steps: int = 3) -> dict:
+    """The other single-GPU BASELINE configs, driver-observed: C2 (N = 16 384, D = 3, SE), C3 (N = 32 768, D = 8,
+    Matern32 ∘ ScaleTransform(0.5)) — one (logpdf, posterior) pair per step, fraction of the fp64 MFMA peak with F_pair = N³/3 + 3N² —
+    and C5 (VFE, N = 262 144, M = 4 096, fp32: posterior + ELBO per step, F = 2NM² + 2M³/3 against the fp32 MFMA peak).
+    Untimed with respect to the headline: runs after the C4 loop; one warm-up step each, `steps` timed steps, wall clock."""
+    out = {}
+
+    def timed(fn):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        return (time.perf_counter() - t0) / steps
+
+    for name, n, d, seed, kern, desc in (
+            ("C2", 16384, 3, 2, agp.SqExponentialKernel(), "GP(SqExponentialKernel()) on 16384 3-D points, sigma2=0.01, fp64"),
+            ("C3", 32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5), "GP(Matern32Kernel() ∘ ScaleTransform(0.5)) on 32768 8-D points, sigma2=0.01, fp64")):
+        x, y = synth_inputs(n, d, seed)
+        fx = agp.GP(kern, ctx=ctx)(agp.RowVecs(x), 0.01)
+
+        def pair():
+            agp.posterior(fx, y).data.C.free()
+
+        dt = timed(pair)
+        tf = f_pair(n) / dt / 1e12
+        out[name] = {"workload": desc, "ms_per_step": dt * 1e3, "steps": steps, "points_per_s": n / dt, "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                     "peak": FP64_MFMA_PEAK_TFLOPS}
+    rng = np.random.default_rng(5)
+    n, m, d = 262144, 4096, 3
+    X = (rng.uniform(0, 1, (n, d)) * 4).astype(np.float32)
+    y = (np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    z = X[rng.permutation(n)[:m]].copy()
+    f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
+    fx = f(agp.RowVecs(X), np.float32(0.1))
+    approx = agp.VFE(f(agp.RowVecs(z), 1e-4))
+    obj = []
+
+    def fit():
+        p = agp.posterior(approx, fx, y)
+        obj.append(float(p.objective))
+        del p
+
+    dt = timed(fit)
+    flops = 2.0 * n * m * m + 2.0 * m**3 / 3
+    out["C5"] = {"workload": "VFE posterior + ELBO, N=262144, M=4096 pseudo-points, D=3, sigma2=0.1, jitter 1e-4, fp32", "ms_per_step": dt * 1e3, "steps": steps,
+                 "points_per_s": n / dt, "tflops": flops / dt / 1e12, "frac_fp32": flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS,
+                 "elbo": obj[-1]}
+    ctx.trim()
+    return out
+
+
+def cached_cpu_baseline(n_full: int):
+    """The oracle's FULL C4 run on an MI355X box's host cores as recorded by tools/fullsize_parity.py (committed under profiles/):
+    what a multi-GPU line carries as its CPU baseline (the bounded live sample is timed by the N = 1 run only)."""
+    for rnd in ("r3", "r2"):
+        rec_path = ROOT / "profiles" / rnd / "fullsize_parity.jsonl"
+        if not rec_path.exists():
+            continue
+        for line in rec_path.read_text().splitlines():
+            r = json.loads(line)
+            if r.get("config") == "C4" and r.get("n") == n_full and "oracle_pair_s" in r:
+                return {"value": r["oracle_points_per_s_fused"], "unit": "points/s", "cores": (r.get("host") or {}).get("cpu_count"), "kind": "port",
+                        "sample": f"cached: the oracle's full in-place fused pair at N={n_full} on an MI355X box's host ({r['oracle_pair_s']:.1f} s), "
+                                  f"profiles/{rnd}/fullsize_parity.jsonl; the live bounded sample is timed by the --gpus 1 run",
+                        "two_factorisations": {"value": r["oracle_points_per_s_two_factorisations"], "unit": "points/s"}}
+    return None
+
+
 def selftest(ngpus: int, virtual: int, grid: str) -> int:
     """Small multi-device fit checked against the single-device engine (same library, same inputs): run in a SUBPROCESS by the
     bench before it trusts a transport (RCCL first, peer copies as the fallback), so that a hanging or failing transport
@@ -178,6 +249,45 @@ def choose_transport(ngpus: int, grid: str) -> str:
     raise SystemExit("[bench] no working multi-GPU transport: " + "; ".join(notes))
 
 
+def dry_launcher(args, rank: int, world: int):
+    """The process-level protocol of an N > 1 run without a device: every launcher rank joins the gloo group and the barriers, rank 0
+    is the driver (here: a stub step that sleeps), the timed region is bracketed by barriers, the maximum over ranks is taken and
+    rank 0 alone prints the JSON line.  tests/test_bench_launcher_cpu.py runs this with world_size 2."""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo")
+    have_pg = dist.is_initialized()
+
+    def barrier():
+        if have_pg:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        if rank == 0:
+            time.sleep(0.002)
+    barrier()
+    t0 = time.perf_counter()
+    if rank == 0:
+        for _ in range(args.steps):
+            time.sleep(0.01)
+    barrier()
+    dt = time.perf_counter() - t0
+    if have_pg:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry launcher (no device)", "value": args.n / (dt / args.steps), "unit": "points/s", "n_gpus": max(args.gpus, world),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "strong", "world": world, "driver_rank": 0}), flush=True)
+    if have_pg:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,9 +301,11 @@ def main():
     ap.add_argument("--vranks", dest="virtual", type=int, default=0, help="V virtual ranks sharing GPU 0 (schedule test / 1-rank overhead measurement)")
     ap.add_argument("--selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C3 / C5 lines (other_configs)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity properties")
-    ap.add_argument("--torch-dist", action="store_true",
-                    help="legacy multi-PROCESS driver (abstractgps.jl_amd/dist.py over torch.distributed) instead of the in-library one")
+    ap.add_argument("--dry-launcher", action="store_true",
+                    help="launcher protocol only (gloo process group, barriers, max over ranks, rank 0 prints the line) with a stub step and no GPU: "
+                         "what the world_size-2 CPU test runs")
     args = ap.parse_args()
 
     if args.selftest:
@@ -204,6 +316,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_launcher:
+        return dry_launcher(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     ngpus = max(args.gpus, world)
@@ -214,17 +328,11 @@ def main():
     torch.cuda.set_device(local_rank if local_rank < torch.cuda.device_count() else 0)
     import torch.distributed as dist
 
-    if world > 1 or args.torch_dist:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # legacy driver: RCCL through torch.distributed.  In-library driver: the library owns the devices and RCCL; the
-        # launcher's other ranks only take part in the barriers, over gloo
-        if args.torch_dist:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        # the library owns the devices and RCCL; the launcher's other ranks only take part in the barriers, over gloo
+        dist.init_process_group("gloo")
     have_pg = dist.is_initialized()
 
     import abstractgps_jl_amd as agp
@@ -243,13 +351,13 @@ def main():
     def max_over_ranks(v: float) -> float:
         if not have_pg:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.torch_dist else "cpu")
+        t = torch.tensor([v], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     extra = {}
-    multi = (ngpus > 1 or args.virtual > 0) and not args.torch_dist
-    if not args.torch_dist:
+    multi = ngpus > 1 or args.virtual > 0
+    if True:
         driver = rank == 0  # in-library driver: one process drives every device; launcher ranks > 0 idle at the barriers
         transport = None
         if driver:
@@ -305,7 +413,9 @@ def main():
             peak = FP64_MFMA_PEAK_TFLOPS * (1 if args.virtual else ngpus)
             # roofline: the SURVEY.md §8(d) number — F_pair / t_pair over the whole job — with the dominant kernel's own rate beside it
             roofline = {"bound": "mfma", "achieved": pair_tf, "peak": peak, "unit": "TFLOP/s",
-                        "frac": pair_tf / peak, **(pmc_traffic(n) if not multi else {"traffic": None}),
+                        "frac": pair_tf / peak,
+                        **(pmc_traffic(n) if not multi else {"traffic": None, "traffic_note": "HBM/fabric bytes come from separate rocprofv3 --pmc passes over the "
+                           "single-GPU command (profiles/r*/pmc_bench_summary.json: same kernel, per launch); PMC cannot be sampled inside a timed multi-GPU run"}),
                         "definition": "achieved = (N^3/3 + 3N^2) / wall time of one pair (SURVEY.md 8(d)), peak = 78.6 TF/s x n_gpus; "
                                       "kernel_* = the dominant kernel alone" + (" (rank 0's launches)" if multi else ""),
                         "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands; launches of <= 4096 tiles run its "
@@ -325,6 +435,9 @@ def main():
                 idx = np.linspace(0, n - 1, 512).astype(int)
                 m_tr = post.mean(agp.RowVecs(x[idx]))
                 extra["check_residual_max"] = float(np.max(np.abs(m_tr - (r[idx] - sigma2 * alpha[idx]))))
+            if not multi and not args.no_other_configs and n == 65536:
+                post.data.C.free()
+                extra["other_configs"] = other_configs(agp, ctx)
             if multi:
                 parallelism = (f"in-library 2D block-cyclic {info['P']}x{info['Q']}, nb={info['nb']}, look-ahead {info['lookahead_depth']}, "
                                f"transport {info['comm']}" + (f" [{args.virtual} virtual ranks on one GPU]" if args.virtual else "")
@@ -334,40 +447,6 @@ def main():
             else:
                 parallelism = "1 GPU"
         scaling = "strong"
-    else:
-        from abstractgps_jl_amd import dist as gdist  # noqa: E402  (module of the package dir)
-
-        eng = gdist.BlockCyclicEngine(local_rank, nb=args.nb or 1024)
-        for _ in range(args.warmup):
-            eng.fit(kernel, x, sigma2, y)
-        eng.be.time_kernels(True)
-        eng.be.gemm_time()
-        barrier()
-        t0 = time.perf_counter()
-        gflops = 0.0
-        for _ in range(args.steps):
-            res = eng.fit(kernel, x, sigma2, y)
-            gflops += res["gemm_flops"]
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        gms, glaunch = eng.be.gemm_time()
-        eng.be.time_kernels(False)
-        logpdf_val = res["logpdf"]
-        ach = gflops / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-        pair_tf = f_pair(n) / (dt / args.steps) / 1e12
-        roofline = {"bound": "mfma", "achieved": pair_tf, "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
-                    "frac": pair_tf / (FP64_MFMA_PEAK_TFLOPS * world), "traffic": None,
-                    "kernel": "gemm_nt_dma_kernel<double> (rank 0's local trailing updates under the block-cyclic predicate)",
-                    "kernel_achieved": ach, "kernel_frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                    "launches_per_step": glaunch / max(args.steps, 1), "avg_launch_ms": gms / max(glaunch, 1)}
-        if not args.no_check:  # (K + σ²I) α = δ on a sample of rows, recomputed on the host from the inputs
-            idx = np.linspace(0, n - 1, 64).astype(int)
-            Krows = se_rows(x[idx], x)
-            resid = Krows @ res["alpha"] + sigma2 * res["alpha"][idx] - y[idx]
-            extra["check_residual_max"] = float(np.max(np.abs(resid)))
-        parallelism = f"multi-process 2D block-cyclic {eng.P}x{eng.Q}, nb={eng.nb} (torch.distributed / RCCL)"
-        scaling = "strong"
-
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n / (dt / args.steps)
@@ -383,8 +462,10 @@ def main():
             "logpdf": logpdf_val,
         }
         line.update(extra)
-        if not multi and not args.torch_dist and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, d)
+        elif multi and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cached_cpu_baseline(n) or cpu_baseline(n, d)
         print(json.dumps(line), flush=True)
     if have_pg:
         dist.destroy_process_group()

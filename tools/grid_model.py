@@ -1,0 +1,151 @@
+"""Cost model of the multi-device schedule (csrc/multi.hip) over process grids P×Q and distribution blocks NB — UNMEASURED ON
+HARDWARE (no multi-GPU box was available to any round); it prices the schedule with the single-GPU per-launch costs of
+tools/perf_model.py (measured in round 2) and a per-link xGMI rate, to pick the default grid by argument that can be checked
+line by line instead of by assertion.
+
+Per block step k of the right-looking factorisation (nblk = N / NB block columns, look-ahead: panel k+1 and its exchange run beside
+the bulk update of step k):
+  panel(k)     diagonal owner: recursive Cholesky of the NB×NB block (perf_model.panel) -> L_kk to its P−1 column peers over P−1
+               links at once (8·NB² B each) -> every owner-column rank: X ← X L_kk⁻ᵀ on ITS rows (MFMA TRSM, rows/P·NB² flops)
+  exchange(k)  rank (p, q) receives  A part: its process row's piece, rows_p·NB·8 B over ONE link (from (p, q_k)) unless q == q_k
+                                     B part: the blocks of its process column, cols_q·NB·8 B from the P owner-column ranks, 1/P each
+               grouped send/recv: all links of a rank run at once -> time = the busiest link's bytes / LINK + per-message latency
+  bulk(k)      rank's local share of the trailing update: 2·NB·(its lower-triangle elements right of the window) flops at the
+               MFMA GEMM rate with the tile fill of ITS local launch (perf_model.gemm)
+  step time    max( max_ranks bulk(k) + look-ahead updates , look-ahead updates + panel(k+1) + exchange(k+1) )
+               (the look-ahead GEMMs run on the same device as the bulk update: their work adds to it; the panel chain overlaps)
+Block-cyclic imbalance (ranks own different numbers of lower blocks), per-rank receive volume and the busiest link are reported.
+
+  python tools/grid_model.py                 # table for N = 65 536 on 2 / 4 / 8 devices, argmin per device count
+"""
+import math
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import perf_model as pm  # noqa: E402
+
+LINK = 64e9         # B/s per xGMI link and direction that a large transfer sustains (MI355X: 153.6 GB/s per link bidirectional peak)
+MSG_LAT = 8e-6      # per point-to-point message (group launch + link latency)
+TRSM_RATE = 45e12   # MFMA TRSM of a tall block against an NB×NB factor (recursion of GEMMs + 64-wide leaves)
+
+
+def local_lower_blocks(nblk, P, Q, p, q, r0, c0):
+    """number of (full, diagonal) lower blocks (i, j), i >= r0, j >= c0, i >= j, owned by rank (p, q)"""
+    full = diag = 0
+    for j in range(c0, nblk):
+        if j % Q != q:
+            continue
+        for i in range(max(j, r0), nblk):
+            if i % P != p:
+                continue
+            if i == j:
+                diag += 1
+            else:
+                full += 1
+    return full, diag
+
+
+def model(N, P, Q, NB, depth=2):
+    nblk = math.ceil(N / NB)
+    lcm = P * Q // math.gcd(P, Q)
+    nblk = math.ceil(nblk / lcm) * lcm
+    R = P * Q
+    ranks = [(p, q) for p in range(P) for q in range(Q)]
+    t_total = 0.0
+    recv = {r: 0.0 for r in ranks}
+    link = {}
+    flops = {r: 0.0 for r in ranks}
+    bulk_t = []
+    crit_t = []
+
+    def panel_time(k):
+        m = nblk - k - 1
+        t = pm.panel(NB, NB)                                   # diagonal block on its owner
+        if P > 1:
+            t += 8.0 * NB * NB / LINK + MSG_LAT                # L_kk to the column peers (P−1 links at once)
+        rows = math.ceil(m / P) * NB
+        t += rows * NB * NB / TRSM_RATE + (30e-6 if rows else 0.0)
+        return t
+
+    def exchange_time(k):
+        m = nblk - k - 1
+        qk = k % Q
+        worst = 0.0
+        for (p, q) in ranks:
+            per_link = {}
+            msgs = 0
+            rows_p = sum(1 for i in range(k + 1, nblk) if i % P == p) * NB
+            cols_q = [j for j in range(k + 1, nblk) if j % Q == q]
+            if q != qk and rows_p:
+                per_link[(p, qk)] = per_link.get((p, qk), 0.0) + rows_p * NB * 8.0
+                msgs += 1
+            for j in cols_q:
+                src = (j % P, qk)
+                if src == (p, q):
+                    continue
+                per_link[src] = per_link.get(src, 0.0) + NB * NB * 8.0
+                msgs += 1
+            for src, b in per_link.items():
+                recv[(p, q)] += b
+                link[(src, (p, q))] = link.get((src, (p, q)), 0.0) + b
+            t = (max(per_link.values()) / LINK if per_link else 0.0) + (MSG_LAT if msgs else 0.0) + 1e-6 * msgs
+            worst = max(worst, t)
+        return worst
+
+    def bulk_time(k):
+        gfirst = k + depth + 1
+        worst = 0.0
+        for (p, q) in ranks:
+            full, diag = local_lower_blocks(nblk, P, Q, p, q, gfirst, gfirst)
+            if full + diag == 0:
+                continue
+            fl = 2.0 * NB * (full * NB * NB + diag * NB * (NB + 1) / 2)
+            flops[(p, q)] += fl
+            tiles = (full + diag) * (NB // 128) ** 2
+            fill = tiles / (math.ceil(tiles / 512) * 512)
+            t = pm.LAUNCH + max(fl / (pm.PEAK * fill), NB / 16 * pm.STEP_ALONE)
+            worst = max(worst, t)
+        return worst
+
+    def la_time(k):  # look-ahead updates of the window columns by panel k (small GEMMs on the panel stream), the critical one first
+        m = nblk - k - 1
+        rows = math.ceil(m / P) * NB
+        return pm.gemm(rows, NB, NB) * min(depth, max(m, 0))
+
+    t_total += panel_time(0) + exchange_time(0)
+    for k in range(nblk):
+        b = bulk_time(k)
+        c = (la_time(k) + panel_time(k + 1) + exchange_time(k + 1)) if k + 1 < nblk else 0.0
+        bulk_t.append(b)
+        crit_t.append(c)
+        t_total += max(b + la_time(k), c)
+    fl = list(flops.values())
+    return {"N": N, "grid": f"{P}x{Q}", "NB": NB, "t_ms": t_total * 1e3, "bulk_ms": sum(bulk_t) * 1e3, "chain_ms": sum(crit_t) * 1e3,
+            "chain_bound_steps": sum(1 for b, c in zip(bulk_t, crit_t) if c > b), "nblk": nblk,
+            "flop_imbalance": max(fl) / (sum(fl) / len(fl)) if sum(fl) else 1.0,
+            "recv_gb_max": max(recv.values()) / 1e9, "link_gb_max": (max(link.values()) / 1e9 if link else 0.0),
+            "tflops": (N**3 / 3) / t_total / 1e12, "frac_of_peak": (N**3 / 3) / t_total / (78.6e12 * R)}
+
+
+def grids(R):
+    return [(P, R // P) for P in range(1, R + 1) if R % P == 0]
+
+
+def best(N, R, nbs=(512, 1024, 2048)):
+    rows = [model(N, P, Q, nb) for (P, Q) in grids(R) for nb in nbs]
+    return min(rows, key=lambda r: r["t_ms"]), rows
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    one = model(N, 1, 1, 2048)
+    print(f"calibration: 1x1, NB = 2048 -> {one['t_ms']:.0f} ms (measured through the in-library driver with one rank: 1451 ms, profiles/r2/multi_virtual_bench.txt)")
+    print(f"N = {N}; single-GPU costs from tools/perf_model.py, link {LINK / 1e9:.0f} GB/s per direction — UNMEASURED ON HARDWARE")
+    print(f"{'devices':>7} {'grid':>5} {'NB':>5} {'t ms':>8} {'bulk':>8} {'chain':>8} {'chain-bound':>11} {'imbalance':>9} {'recv GB':>8} {'link GB':>8} {'% peak':>7}")
+    for R in (1, 2, 4, 8):
+        b, rows = best(N, R)
+        for r in sorted(rows, key=lambda r: r["t_ms"]):
+            mark = " <- argmin" if r is b else ""
+            print(f"{R:>7} {r['grid']:>5} {r['NB']:>5} {r['t_ms']:>8.1f} {r['bulk_ms']:>8.1f} {r['chain_ms']:>8.1f} {r['chain_bound_steps']:>5}/{r['nblk']:<5} "
+                  f"{r['flop_imbalance']:>9.3f} {r['recv_gb_max']:>8.2f} {r['link_gb_max']:>8.2f} {100 * r['frac_of_peak']:>7.1f}{mark}")
