@@ -404,8 +404,7 @@ def _terms(fx: FiniteGP, y, want_logdet: bool, want_sqmahal: bool):
     if not isinstance(f, GP):
         raise TypeError("only GP priors are accelerated here (the shim falls back to the stock methods otherwise)")
     ctx = f.context()
-    ydt = np.float64 if y is None or np.asarray(y).dtype != np.float32 else np.float32
-    dt = np.result_type(_input_dtype(fx.x), ydt).type
+    dt = _input_dtype(fx.x) if y is None else np.result_type(_input_dtype(fx.x), np.float32 if np.asarray(y).dtype == np.float32 else np.float64).type
     m = _Marshal(dt)
     px = m.points(fx.x)
     kk = m.kernel(f.kernel, px.d)

@@ -138,6 +138,10 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
  *   "gemm_ring3"     three-stage operand ring GEMM (1 fp32 launches, 2 all; measured slower)   default 0
  *   "gemm_wide"      256×128-tile one-wave-per-SIMD GEMM (1 large launches, 2 all; measured slower)   default 0
+ *   "cu_split"       CU-partitioned look-ahead: the panel stream owns this many CUs (multiple of 8, spread over all XCDs and
+ *                    shader engines through hipExtStreamCreateWithCUMask), the trailing update the rest, while more than
+ *                    "cu_split_tail" rows remain; panels are "cu_split_nb" wide then; sizes above "cu_split_max_n" keep the
+ *                    unpartitioned schedule                                                default 0 / 8192 / 512 / 40000
  *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Return every cached (free) device block of the ctx to the HIP allocator — e.g. after freeing an N = 65 536 posterior

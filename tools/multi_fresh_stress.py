@@ -33,7 +33,7 @@ t0 = time.time()
 for rep in range(reps):
     for gi, (P, Q) in enumerate(grids):
         rng = np.random.default_rng(1000 * rep + gi)
-        d = int(rng.integers(1, 4))
+        d = int(args["dims"]) if "dims" in args else int(rng.integers(1, 4))
         X = rng.standard_normal((n, d))
         y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
         sig = float(rng.uniform(0.03, 0.3))
@@ -45,6 +45,10 @@ for rep in range(reps):
         ctx.set_param("multi_timeout_s", 120)
         if check:
             ctx.set_param("multi_check", check)
+        if "copy_kernel" in args:
+            ctx.set_param("copy_kernel", int(args["copy_kernel"]))
+        if "dsync" in args:
+            ctx.set_param("multi_debug_sync", int(args["dsync"]))
         tot += 1
         try:
             post = agp.posterior(agp.GP(agp.SqExponentialKernel(), ctx=ctx)(agp.RowVecs(X), sig), y)
@@ -52,13 +56,17 @@ for rep in range(reps):
             arel = float(np.linalg.norm(post.data.alpha - opost.alpha) / np.linalg.norm(opost.alpha))
             if not (rel <= 1e-10 and arel <= 1e-8):
                 bad += 1
-                U = post.data.C.U
+                U = post.data.C.U                               # U[j, i] = L[i, j]
                 err = np.abs(U - opost.U)
-                cols = np.where(err.max(axis=0) > 1e-9)[0]
-                rows = np.where(err.max(axis=1) > 1e-9)[0]
-                print(f"WRONG rep {rep} grid {P}x{Q} depth {depth} d {d}: logpdf rel {rel:.2e} alpha rel {arel:.2e}; factor differs first at "
-                      f"U row {rows.min() if rows.size else -1} (L column block {rows.min() // nb if rows.size else -1}), "
-                      f"U col {cols.min() if cols.size else -1} (L row block {cols.min() // nb if cols.size else -1}), nan {int(np.isnan(U).sum())}", flush=True)
+                err[np.isnan(err)] = np.inf
+                nbk = (n + nb - 1) // nb
+                bad = [(j, i) for j in range(nbk) for i in range(j, nbk) if err[j * nb:(j + 1) * nb, i * nb:(i + 1) * nb].max() > 1e-9]  # (column block, row block), column-major
+                first = bad[0] if bad else (-1, -1)
+                in_first_col = [i for (j, i) in bad if j == first[0]]
+                print(f"WRONG rep {rep} grid {P}x{Q} depth {depth} d {d}: logpdf rel {rel:.2e} alpha rel {arel:.2e} nan {int(np.isnan(U).sum())}; "
+                      f"{len(bad)} bad L blocks of {nbk * (nbk + 1) // 2}; first bad column block {first[0]} (owner column q={first[0] % Q}), bad row blocks in it "
+                      f"{in_first_col[:12]} (owner rows p={[i % P for i in in_first_col[:12]]}); max err there "
+                      f"{max(err[first[0] * nb:(first[0] + 1) * nb, i * nb:(i + 1) * nb].max() for i in in_first_col) if in_first_col else 0:.2e}", flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
             print(f"ERROR rep {rep} grid {P}x{Q} depth {depth} d {d}: {type(e).__name__}: {str(e)[:1500]}", flush=True)
