@@ -605,20 +605,36 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
 }
 
 // Vector solves with the resident factor: R rows hold nrhs right-hand sides of length np.
+// Blocks of trsv_nb (256) columns: a one-workgroup diagonal solve (trsv_diag2: all memory round trips one 64-wide step ahead) and
+// a many-workgroup update of the remaining vector.  Backward sweep with "trsv_pipe" (default): the chain is diag(b) -> diag(b−1)
+// only — diag(b−1) applies the update of ITS 256 columns by block b itself, and the update of everything further left runs on the
+// panel stream beside the chain (it is needed one block later): the chain no longer contains the HBM-bound update kernel.
 template <typename T>
 static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* R, long ldr, int nrhs, bool fwd) {
     const int NBV = (int)c->trsv_nb;
-    const size_t smem = sizeof(T) * (NBV + 64 * 65 + 16 * 64);
+    const bool k2 = NBV <= 256;
+    const size_t smem = k2 ? sizeof(T) * (256 + 64 * 65 + 16 * 64 + 4 * 256 + 256) : sizeof(T) * (NBV + 64 * 65 + 16 * 64);
     const long nblk = (np + NBV - 1) / NBV;
     T* W = nullptr;
     RC(trtri_tiles<T>(c, s, L, ldl, np, &W));  // I − inv(L_jj) for every 64×64 diagonal tile, one batched launch
+    // the pipelined backward sweep needs a second stream: the ctx's panel stream, when the solve runs on the main stream
+    const bool pipe = !fwd && k2 && c->trsv_pipe && s == c->sm && nblk > 2;
+    hipStream_t s2 = c->sp;
+    hipEvent_t ev_a = nullptr, ev_b_prev = nullptr, ev_b = nullptr;
+    if (pipe) {  // the bulk stream starts after everything queued so far (the tiles above, the caller's right-hand sides)
+        RC(ctx_event(c, &ev_a, false));
+        HIPCHK(hipEventRecord(ev_a, s));
+        HIPCHK(hipStreamWaitEvent(s2, ev_a, 0));
+    }
     for (long bb = 0; bb < nblk; ++bb) {
         const long b = fwd ? bb : (nblk - 1 - bb);
         const long b0 = b * NBV;
         const int nbv = (int)std::min<long>(NBV, np - b0);  // multiple of 64 (np is a multiple of 128)
         if (fwd) {
-            hipLaunchKernelGGL((trsv_diag_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr,
-                               nrhs, (const T*)W);
+            if (k2)
+                hipLaunchKernelGGL((trsv_diag2_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W, 0);
+            else
+                hipLaunchKernelGGL((trsv_diag_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
             const long lo = b0 + nbv;
             if (lo < np) {
@@ -626,16 +642,41 @@ static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* 
                                    ldl, b0, nbv, lo, np, R, ldr, nrhs);
                 HIPCHK(hipGetLastError());
             }
-        } else {
-            hipLaunchKernelGGL((trsv_diag_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr,
-                               nrhs, (const T*)W);
+        } else if (!pipe) {
+            if (k2)
+                hipLaunchKernelGGL((trsv_diag2_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W, 0);
+            else
+                hipLaunchKernelGGL((trsv_diag_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
             if (b0 > 0) {
                 hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((b0 + 255) / 256), (unsigned)(nbv / 64)),
-                                   dim3(256), 0, s, L, ldl, b0, nbv, R, ldr, nrhs);
+                                   dim3(256), 0, s, L, ldl, b0, nbv, R, ldr, nrhs, b0);
                 HIPCHK(hipGetLastError());
             }
+        } else {
+            // chain stream: [wait for the bulk update of block b+2 — it wrote this block's columns] diag(b) incl. the update by b+1
+            const int crit = bb == 0 ? 0 : (int)std::min<long>(NBV, np - (b0 + nbv));  // rows of block b+1 (the one solved just before)
+            if (ev_b_prev) HIPCHK(hipStreamWaitEvent(s, ev_b_prev, 0));
+            hipLaunchKernelGGL((trsv_diag2_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W, crit);
+            HIPCHK(hipGetLastError());
+            ev_b_prev = ev_b;  // bulk(b+1) must be complete before diag(b−1)
+            ev_b = nullptr;
+            const long jmax = b0 - NBV;  // columns left of block b−1: block b−1 itself is updated by its own diagonal kernel
+            if (jmax > 0) {
+                RC(ctx_event(c, &ev_a, false));
+                HIPCHK(hipEventRecord(ev_a, s));
+                HIPCHK(hipStreamWaitEvent(s2, ev_a, 0));
+                hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((jmax + 255) / 256), (unsigned)(nbv / 64)),
+                                   dim3(256), 0, s2, L, ldl, b0, nbv, R, ldr, nrhs, jmax);
+                HIPCHK(hipGetLastError());
+                RC(ctx_event(c, &ev_b, false));
+                HIPCHK(hipEventRecord(ev_b, s2));
+            }
         }
+    }
+    if (pipe) {  // (the last bulk updates were waited for by the last diagonal solves; join for the caller's sake)
+        if (ev_b_prev) HIPCHK(hipStreamWaitEvent(s, ev_b_prev, 0));
+        if (ev_b) HIPCHK(hipStreamWaitEvent(s, ev_b, 0));
     }
     return 0;
 }
@@ -1506,6 +1547,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     }
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
+    else if (!strcmp(name, "trsv_pipe")) c->trsv_pipe = v != 0;
     else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;

@@ -2217,6 +2217,120 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
     }
 }
 
+// trsv_diag2: the same block solve for nbv <= 256 with every memory round trip of a 64-wide step issued AHEAD of its use: besides
+// the W tile, the L elements of the in-block update (64 × up to 192, spread over all 1 024 threads: target index j = tid & 255,
+// 16 of the step's 64 source rows per thread quarter) are loaded into registers right after the previous update and are in flight
+// during the GEMV phases of the step, so a step costs its LDS traffic and barriers instead of a global round trip behind them
+// (round 2: 24 µs per 256-wide block, ~6 µs per step, 64 loads per thread on <= 192 active threads).
+// With crit > 0 the kernel first applies the pending update of the block solved just before it (backward sweep only):
+//   r[b0 + j] -= Σ_{i<crit} L[b0 + nbv + i][b0 + j] a[b0 + nbv + i]
+// — the part of trsv_upd_bwd that the chain waits for; the bulk of that update runs beside this kernel on another stream.
+template <typename T, bool FWD>
+__global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
+                                                           T* __restrict__ R, long ldr, int nrhs,
+                                                           const T* __restrict__ W, int crit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* rv = reinterpret_cast<T*>(smem_raw);  // [256] current rhs / solution
+    T* Ws = rv + 256;                        // [64][65] W tile of the current step
+    T* red = Ws + 64 * 65;                   // [16][64] GEMV partial sums
+    T* prt = red + 16 * 64;                  // [4][256] update partial sums
+    T* av = prt + 4 * 256;                   // [256] solution of the previous block (crit)
+    const int tid = threadIdx.x;
+    const int t = tid & 63, part = tid >> 6;
+    const int j = tid & 255, q = tid >> 8;
+    const int ns = nbv / 64;
+    auto load_l = [&](int sb, T (&lr)[16]) {  // L elements of the update that follows step sb
+        const int s0 = sb * 64;
+        if (FWD) {
+            const int i = s0 + 64 + j;       // target row
+            if (i < nbv) {
+                const T* src = L + (b0 + i) * ldl + b0 + s0 + 16 * q;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) lr[c] = src[c];
+            }
+        } else if (j < s0) {                 // target column j
+            const T* src = L + (b0 + s0 + 16 * q) * ldl + b0 + j;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lr[c] = src[(long)c * ldl];
+        }
+    };
+    for (int s = 0; s < nrhs; ++s) {
+        T* r = R + (long)s * ldr + b0;
+        T wreg[4], lreg[16];
+        {
+            const T* W0 = W + ((b0 >> 6) + (FWD ? 0 : ns - 1)) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wreg[i] = W0[tid + 1024 * i];
+        }
+        if (tid < nbv) rv[tid] = r[tid];
+        if (!FWD && crit > 0) {  // pending update from the block below: 4 quarters of its rows per target column
+            if (tid < crit) av[tid] = R[(long)s * ldr + b0 + nbv + tid];
+            __syncthreads();
+            T acc = 0;
+            if (j < nbv) {
+                const int per = crit / 4;
+                const T* src = L + (b0 + nbv + (long)q * per) * ldl + b0 + j;
+#pragma unroll 16
+                for (int i = 0; i < per; ++i) acc = fma(src[(long)i * ldl], av[q * per + i], acc);
+            }
+            prt[q * 256 + j] = acc;
+            __syncthreads();
+            if (tid < nbv) rv[tid] -= prt[tid] + prt[256 + tid] + prt[512 + tid] + prt[768 + tid];
+        }
+        load_l(FWD ? 0 : ns - 1, lreg);  // in flight during the first step's GEMV
+        __syncthreads();
+        for (int ss = 0; ss < ns; ++ss) {
+            const int sb = FWD ? ss : (ns - 1 - ss);
+            const int s0 = sb * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + 1024 * i;
+                Ws[(e >> 6) * 65 + (e & 63)] = wreg[i];
+            }
+            if (ss + 1 < ns) {  // next step's W tile: in flight during this step
+                const T* Wn = W + ((b0 >> 6) + (FWD ? sb + 1 : sb - 1)) * 4096;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wreg[i] = Wn[tid + 1024 * i];
+            }
+            __syncthreads();
+            {
+                T acc = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * part + i;
+                    acc = fma(FWD ? Ws[t * 65 + c] : Ws[c * 65 + t], rv[s0 + c], acc);
+                }
+                red[part * 64 + t] = acc;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                T acc = 0;
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) acc += red[qq * 64 + tid];
+                rv[s0 + tid] -= acc;
+            }
+            __syncthreads();
+            // update the not-yet-solved part of this diagonal block from the registers loaded one step ago
+            const int tgt = FWD ? s0 + 64 + j : j;
+            const bool active = FWD ? (tgt < nbv) : (j < s0);
+            {
+                T acc = 0;
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc = fma(lreg[c], rv[s0 + 16 * q + c], acc);
+                }
+                prt[q * 256 + j] = acc;
+            }
+            if (ss + 1 < ns) load_l(FWD ? sb + 1 : sb - 1, lreg);  // the next update's elements: in flight during the next step's GEMV
+            __syncthreads();
+            if (q == 0 && active) rv[tgt] -= prt[j] + prt[256 + j] + prt[512 + j] + prt[768 + j];
+            __syncthreads();
+        }
+        if (tid < nbv) r[tid] = rv[tid];
+        __syncthreads();
+    }
+}
+
 // rows [row_lo, row_hi): r[s][i] -= Σ_{j<nbv} L[i][b0+j] z[s][b0+j]; one wave per row, 4 rows per block.
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_upd_fwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
@@ -2240,10 +2354,10 @@ __global__ __launch_bounds__(256) void trsv_upd_fwd_kernel(const T* __restrict__
 // takes 64 rows × 256 columns, one column per thread, then one atomicAdd per column.
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_upd_bwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
-                                                            T* __restrict__ R, long ldr, int nrhs) {
+                                                            T* __restrict__ R, long ldr, int nrhs, long jmax) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     const long i0 = b0 + (long)blockIdx.y * 64;
-    if (j >= b0) return;
+    if (j >= jmax) return;  // jmax = b0: every column left of the block; smaller: the part the next diagonal solve does not apply itself
     for (int s = 0; s < nrhs; ++s) {
         const T* a = R + (long)s * ldr;
         T acc = 0;

@@ -340,7 +340,13 @@ struct RankRun {
             tr->line(b);
         }
         if (dry) return 0;
-        if (M->debug_sync & 4) MCHK(hipEventSynchronize(e.ev));
+        // "multi_debug_sync": 4 = every wait on the host; 32 / 64 / 128 = only the waits for arrived / for a peer's events / for the
+        // buffer-reuse events (bulk_done, la_done) on the host — localisation of the first-fit item
+        const int dbg = M->debug_sync;
+        const bool peer = !strcmp(e.tag, "ready") || !strcmp(e.tag, "lkk") || !strcmp(e.tag, "accr") || !strcmp(e.tag, "alr");
+        const bool host = (dbg & 4) || ((dbg & 32) && !strcmp(e.tag, "arrived")) || ((dbg & 64) && peer) ||
+                          ((dbg & 128) && (!strcmp(e.tag, "bulk_done") || !strcmp(e.tag, "la_done")));
+        if (host) MCHK(hipEventSynchronize(e.ev));
         else MCHK(hipStreamWaitEvent(st[s], e.ev, 0));
         if ((check & 1) && e.id < nflags) {
             hipLaunchKernelGGL(mk_check_kernel, dim3(1), dim3(1), 0, st[s], M->ranks[(size_t)e.owner].flags + e.id, (int)seq, me->log, e.owner,

@@ -60,11 +60,11 @@ for rep in range(reps):
                 err = np.abs(U - opost.U)
                 err[np.isnan(err)] = np.inf
                 nbk = (n + nb - 1) // nb
-                bad = [(j, i) for j in range(nbk) for i in range(j, nbk) if err[j * nb:(j + 1) * nb, i * nb:(i + 1) * nb].max() > 1e-9]  # (column block, row block), column-major
-                first = bad[0] if bad else (-1, -1)
-                in_first_col = [i for (j, i) in bad if j == first[0]]
+                badb = [(j, i) for j in range(nbk) for i in range(j, nbk) if err[j * nb:(j + 1) * nb, i * nb:(i + 1) * nb].max() > 1e-9]  # (column block, row block), column-major
+                first = badb[0] if badb else (-1, -1)
+                in_first_col = [i for (j, i) in badb if j == first[0]]
                 print(f"WRONG rep {rep} grid {P}x{Q} depth {depth} d {d}: logpdf rel {rel:.2e} alpha rel {arel:.2e} nan {int(np.isnan(U).sum())}; "
-                      f"{len(bad)} bad L blocks of {nbk * (nbk + 1) // 2}; first bad column block {first[0]} (owner column q={first[0] % Q}), bad row blocks in it "
+                      f"{len(badb)} bad L blocks of {nbk * (nbk + 1) // 2}; first bad column block {first[0]} (owner column q={first[0] % Q}), bad row blocks in it "
                       f"{in_first_col[:12]} (owner rows p={[i % P for i in in_first_col[:12]]}); max err there "
                       f"{max(err[first[0] * nb:(first[0] + 1) * nb, i * nb:(i + 1) * nb].max() for i in in_first_col) if in_first_col else 0:.2e}", flush=True)
         except Exception as e:  # noqa: BLE001
