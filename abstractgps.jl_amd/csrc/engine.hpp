@@ -81,7 +81,6 @@ struct gp_ctx {
     int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
     int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
     int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
-    int trsv_pipe = 1;     // backward vector sweep: diagonal-solve chain on the main stream, bulk updates beside it on the panel stream
     long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)
     long leaf_group = 128; // columns factored left-looking by consecutive leaves (64 = every leaf followed by its own GEMM)
     int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at
@@ -154,6 +153,8 @@ int32_t ctx_alloc(gp_ctx* c, size_t bytes, void** out);
 void ctx_release(gp_ctx* c, void* p, size_t requested);
 int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing);
 int32_t ctx_scal(gp_ctx* c, long n);
+int32_t ctx_prime(gp_ctx* c, long nb_hint);          // lazy workspaces + the hardware queues of sm / sp, created now
+int32_t ctx_prime_stream(gp_ctx* c, hipStream_t s);  // one empty kernel on s (creates its hardware queue), drained
 // Validates a handle (gp_ctx / gp_post / gp_vfe) and locks its ctx without racing a concurrent *_free / gp_ctx_destroy from
 // another thread: the ctx is pinned under the registry mutex, locked, and the handle is checked again under the ctx lock
 // (every *_free removes its handle from the registry BEFORE it takes the ctx lock to release the buffers).

@@ -141,6 +141,45 @@ int32_t ctx_scal(gp_ctx* c, long n) {
     return 0;
 }
 
+__global__ void prime_kernel(int* p) {
+    if (p && threadIdx.x == 0) *p = 0;
+}
+// Everything a ctx creates lazily, created NOW: the workspaces (leaf tickets, info, scalars, trtri tiles for nb_hint columns) and
+// — by launching one empty kernel on each stream — the hardware queues behind its streams.  HIP creates the HSA queue of a stream
+// at its first use, and every queue creation makes the hardware scheduler unmap and remap ALL queues of the process (running waves
+// are context-switched out and back in).  The multi-device driver primes every rank context when it is created, so that no queue
+// appears while kernels of other ranks run (the first-fit item).
+int32_t ctx_prime(gp_ctx* c, long nb_hint) {
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->info_dev) HIPCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    RC(ctx_scal(c, 8 + 128));
+    if (!c->ticket_dev) {
+        HIPCHK(hipMalloc((void**)&c->ticket_dev, sizeof(int) * 64));
+        HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
+    }
+    const size_t need = sizeof(double) * (size_t)(std::max(nb_hint, 256L) / 64 + 2) * 4096;
+    if (c->w_ws_bytes < need) {
+        if (c->w_ws) (void)hipFree(c->w_ws);
+        c->w_ws_bytes = 0;
+        HIPCHK(hipMalloc(&c->w_ws, need));
+        HIPCHK(hipMemset(c->w_ws, 0, need));
+        c->w_ws_bytes = need;
+    }
+    hipLaunchKernelGGL(prime_kernel, dim3(1), dim3(64), 0, c->sm, c->info_dev);
+    hipLaunchKernelGGL(prime_kernel, dim3(1), dim3(64), 0, c->sp, (int*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->sm));
+    HIPCHK(hipStreamSynchronize(c->sp));
+    return 0;
+}
+int32_t ctx_prime_stream(gp_ctx* c, hipStream_t s) {
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(prime_kernel, dim3(1), dim3(64), 0, s, (int*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
@@ -605,34 +644,23 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
 }
 
 // Vector solves with the resident factor: R rows hold nrhs right-hand sides of length np.
-// Blocks of trsv_nb (256) columns: a one-workgroup diagonal solve (trsv_diag2: all memory round trips one 64-wide step ahead) and
-// a many-workgroup update of the remaining vector.  Backward sweep with "trsv_pipe" (default): the chain is diag(b) -> diag(b−1)
-// only — diag(b−1) applies the update of ITS 256 columns by block b itself, and the update of everything further left runs on the
-// panel stream beside the chain (it is needed one block later): the chain no longer contains the HBM-bound update kernel.
+// Blocks of trsv_nb (256) columns: a one-workgroup diagonal solve (trsv_diag2: the memory round trips of every 64-wide step are in
+// flight before they are needed) and a many-workgroup, HBM-bound update of the remaining vector.
 template <typename T>
 static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* R, long ldr, int nrhs, bool fwd) {
     const int NBV = (int)c->trsv_nb;
     const bool k2 = NBV <= 256;
-    const size_t smem = k2 ? sizeof(T) * (256 + 64 * 65 + 16 * 64 + 4 * 256 + 256) : sizeof(T) * (NBV + 64 * 65 + 16 * 64);
+    const size_t smem = k2 ? sizeof(T) * (256 + 64 * 65 + 16 * 64 + 4 * 256) : sizeof(T) * (NBV + 64 * 65 + 16 * 64);
     const long nblk = (np + NBV - 1) / NBV;
     T* W = nullptr;
     RC(trtri_tiles<T>(c, s, L, ldl, np, &W));  // I − inv(L_jj) for every 64×64 diagonal tile, one batched launch
-    // the pipelined backward sweep needs a second stream: the ctx's panel stream, when the solve runs on the main stream
-    const bool pipe = !fwd && k2 && c->trsv_pipe && s == c->sm && nblk > 2;
-    hipStream_t s2 = c->sp;
-    hipEvent_t ev_a = nullptr, ev_b_prev = nullptr, ev_b = nullptr;
-    if (pipe) {  // the bulk stream starts after everything queued so far (the tiles above, the caller's right-hand sides)
-        RC(ctx_event(c, &ev_a, false));
-        HIPCHK(hipEventRecord(ev_a, s));
-        HIPCHK(hipStreamWaitEvent(s2, ev_a, 0));
-    }
     for (long bb = 0; bb < nblk; ++bb) {
         const long b = fwd ? bb : (nblk - 1 - bb);
         const long b0 = b * NBV;
         const int nbv = (int)std::min<long>(NBV, np - b0);  // multiple of 64 (np is a multiple of 128)
         if (fwd) {
             if (k2)
-                hipLaunchKernelGGL((trsv_diag2_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W, 0);
+                hipLaunchKernelGGL((trsv_diag2_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             else
                 hipLaunchKernelGGL((trsv_diag_kernel<T, true>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
@@ -642,41 +670,18 @@ static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* 
                                    ldl, b0, nbv, lo, np, R, ldr, nrhs);
                 HIPCHK(hipGetLastError());
             }
-        } else if (!pipe) {
+        } else {
             if (k2)
-                hipLaunchKernelGGL((trsv_diag2_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W, 0);
+                hipLaunchKernelGGL((trsv_diag2_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             else
                 hipLaunchKernelGGL((trsv_diag_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
             if (b0 > 0) {
                 hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((b0 + 255) / 256), (unsigned)(nbv / 64)),
-                                   dim3(256), 0, s, L, ldl, b0, nbv, R, ldr, nrhs, b0);
+                                   dim3(256), 0, s, L, ldl, b0, nbv, R, ldr, nrhs);
                 HIPCHK(hipGetLastError());
-            }
-        } else {
-            // chain stream: [wait for the bulk update of block b+2 — it wrote this block's columns] diag(b) incl. the update by b+1
-            const int crit = bb == 0 ? 0 : (int)std::min<long>(NBV, np - (b0 + nbv));  // rows of block b+1 (the one solved just before)
-            if (ev_b_prev) HIPCHK(hipStreamWaitEvent(s, ev_b_prev, 0));
-            hipLaunchKernelGGL((trsv_diag2_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W, crit);
-            HIPCHK(hipGetLastError());
-            ev_b_prev = ev_b;  // bulk(b+1) must be complete before diag(b−1)
-            ev_b = nullptr;
-            const long jmax = b0 - NBV;  // columns left of block b−1: block b−1 itself is updated by its own diagonal kernel
-            if (jmax > 0) {
-                RC(ctx_event(c, &ev_a, false));
-                HIPCHK(hipEventRecord(ev_a, s));
-                HIPCHK(hipStreamWaitEvent(s2, ev_a, 0));
-                hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((jmax + 255) / 256), (unsigned)(nbv / 64)),
-                                   dim3(256), 0, s2, L, ldl, b0, nbv, R, ldr, nrhs, jmax);
-                HIPCHK(hipGetLastError());
-                RC(ctx_event(c, &ev_b, false));
-                HIPCHK(hipEventRecord(ev_b, s2));
             }
         }
-    }
-    if (pipe) {  // (the last bulk updates were waited for by the last diagonal solves; join for the caller's sake)
-        if (ev_b_prev) HIPCHK(hipStreamWaitEvent(s, ev_b_prev, 0));
-        if (ev_b) HIPCHK(hipStreamWaitEvent(s, ev_b, 0));
     }
     return 0;
 }
@@ -1547,7 +1552,6 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     }
     else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
     else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
-    else if (!strcmp(name, "trsv_pipe")) c->trsv_pipe = v != 0;
     else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
@@ -1566,7 +1570,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "cu_split_max_n")) c->cu_split_max_n = std::max<int64_t>(0, v);
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
-             !strcmp(name, "multi_check") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
+             !strcmp(name, "multi_check") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }

@@ -2221,20 +2221,19 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
 // the W tile, the L elements of the in-block update (64 × up to 192, spread over all 1 024 threads: target index j = tid & 255,
 // 16 of the step's 64 source rows per thread quarter) are loaded into registers right after the previous update and are in flight
 // during the GEMV phases of the step, so a step costs its LDS traffic and barriers instead of a global round trip behind them
-// (round 2: 24 µs per 256-wide block, ~6 µs per step, 64 loads per thread on <= 192 active threads).
-// With crit > 0 the kernel first applies the pending update of the block solved just before it (backward sweep only):
-//   r[b0 + j] -= Σ_{i<crit} L[b0 + nbv + i][b0 + j] a[b0 + nbv + i]
-// — the part of trsv_upd_bwd that the chain waits for; the bulk of that update runs beside this kernel on another stream.
+// (round 2: 24 µs per 256-wide block, ~6 µs per step, 64 loads per thread on <= 192 active threads; this kernel: ≈11 µs —
+// C4's backward sweep 10.2 -> 6.7 ms, C2's 2.05 -> 1.24 ms, profiles/r3/sweep_trsv.jsonl).  A two-stream variant (this chain on
+// one stream, the bulk of every update beside it on another) was built and measured SLOWER — 3.1 / 14.0 ms: two event records and
+// two stream waits per 256-column block cost more host time than the overlap saves — and removed.
 template <typename T, bool FWD>
 __global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
                                                            T* __restrict__ R, long ldr, int nrhs,
-                                                           const T* __restrict__ W, int crit) {
+                                                           const T* __restrict__ W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* rv = reinterpret_cast<T*>(smem_raw);  // [256] current rhs / solution
     T* Ws = rv + 256;                        // [64][65] W tile of the current step
     T* red = Ws + 64 * 65;                   // [16][64] GEMV partial sums
     T* prt = red + 16 * 64;                  // [4][256] update partial sums
-    T* av = prt + 4 * 256;                   // [256] solution of the previous block (crit)
     const int tid = threadIdx.x;
     const int t = tid & 63, part = tid >> 6;
     const int j = tid & 255, q = tid >> 8;
@@ -2263,20 +2262,6 @@ __global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ 
             for (int i = 0; i < 4; ++i) wreg[i] = W0[tid + 1024 * i];
         }
         if (tid < nbv) rv[tid] = r[tid];
-        if (!FWD && crit > 0) {  // pending update from the block below: 4 quarters of its rows per target column
-            if (tid < crit) av[tid] = R[(long)s * ldr + b0 + nbv + tid];
-            __syncthreads();
-            T acc = 0;
-            if (j < nbv) {
-                const int per = crit / 4;
-                const T* src = L + (b0 + nbv + (long)q * per) * ldl + b0 + j;
-#pragma unroll 16
-                for (int i = 0; i < per; ++i) acc = fma(src[(long)i * ldl], av[q * per + i], acc);
-            }
-            prt[q * 256 + j] = acc;
-            __syncthreads();
-            if (tid < nbv) rv[tid] -= prt[tid] + prt[256 + tid] + prt[512 + tid] + prt[768 + tid];
-        }
         load_l(FWD ? 0 : ns - 1, lreg);  // in flight during the first step's GEMV
         __syncthreads();
         for (int ss = 0; ss < ns; ++ss) {
@@ -2354,10 +2339,10 @@ __global__ __launch_bounds__(256) void trsv_upd_fwd_kernel(const T* __restrict__
 // takes 64 rows × 256 columns, one column per thread, then one atomicAdd per column.
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_upd_bwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
-                                                            T* __restrict__ R, long ldr, int nrhs, long jmax) {
+                                                            T* __restrict__ R, long ldr, int nrhs) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     const long i0 = b0 + (long)blockIdx.y * 64;
-    if (j >= jmax) return;  // jmax = b0: every column left of the block; smaller: the part the next diagonal solve does not apply itself
+    if (j >= b0) return;
     for (int s = 0; s < nrhs; ++s) {
         const T* a = R + (long)s * ldr;
         T acc = 0;

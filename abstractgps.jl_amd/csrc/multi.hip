@@ -243,6 +243,7 @@ struct gp_multi {
     int copy_kernel = 0;  // block copies by copy2d_kernel instead of hipMemcpy2DAsync ("copy_kernel" parameter)
     int debug_sync = 0;   // diagnostic: host-synchronise the rank's streams after every exchange ("multi_debug_sync")
     int check = 0;        // "multi_check" (see the header comment)
+    long window = 16;        // block steps a rank thread may queue ahead of its device ("multi_window")
     double timeout_s = 600;  // a rank thread that waits longer than this for a peer or for its own streams fails the fit
     std::string comm_note;
     Trace* tr = nullptr;  // schedule trace of the running fit
@@ -824,6 +825,9 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
         if (gfirst < nblk) RC(update(SM, "bulk", gfirst, k, gfirst, lcol_from(gfirst) * NB, n_loc));
         RC(rr.own_event(&bulk_done[k], "bulk_done", k));
         RC(rr.rec(SM, bulk_done[k]));
+        // bounded run-ahead of the host: at most `window` block steps are queued beyond what the device has finished (hundreds of
+        // queued steps on 16+ streams of mixed priority stopped making progress in tools/hip_event_repro.hip — profiles/r3)
+        if (!dry && k >= M->window && bulk_done[k - M->window].ev) MCHK(hipEventSynchronize(bulk_done[k - M->window].ev));
         if (!dry && (M->debug_sync & 16)) MCHK(hipStreamSynchronize(sm));
     }
     // join the panel and comm streams into the main stream
@@ -1004,6 +1008,10 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
         m->check = (int)v;
         return 0;
     }
+    if (!strcmp(name, "multi_window")) {
+        m->window = std::max<int64_t>(4, v);
+        return 0;
+    }
     if (!strcmp(name, "multi_timeout_s")) {
         m->timeout_s = (double)std::max<int64_t>(1, v);
         return 0;
@@ -1082,6 +1090,20 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
                 if (hipDeviceCanAccessPeer(&can, devices[r], devices[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[j], 0);
                 (void)hipGetLastError();
             }
+        }
+    }
+    // every lazily created resource of the rank contexts — workspaces and, above all, the hardware queues behind the 3·R streams —
+    // exists before the first fit (GPMI_MULTI_PRIME=0 leaves them lazy: the configuration in which first fits went wrong)
+    {
+        const char* pe = getenv("GPMI_MULTI_PRIME");
+        if (rc == 0 && !(pe && pe[0] == '0')) {
+            for (int r = 0; r < ndev && rc == 0; ++r) {
+                rc = ctx_prime(m->ranks[r].c, nb);
+                if (rc == 0) rc = ctx_prime_stream(m->ranks[r].c, m->ranks[r].sc);
+            }
+            if (rc == 0) rc = ctx_prime(main_ctx, nb);
+            for (int r = 0; r < ndev && rc == 0; ++r)
+                if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = set_err_text(-1997, "device synchronisation after priming failed");
         }
     }
     // transport: RCCL between distinct devices unless told otherwise (GPMI_COMM=rccl|p2p); virtual ranks can only copy — unless a

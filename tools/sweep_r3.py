@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import abstractgps_jl_amd as agp  # noqa: E402
 
-DEFAULTS = {"nb": 2048, "lookahead": 1, "cu_split": 0, "cu_split_nb": 512, "cu_split_tail": 8192, "cu_split_max_n": 40000, "trsv_pipe": 1}
+DEFAULTS = {"nb": 2048, "lookahead": 1, "cu_split": 0, "cu_split_nb": 512, "cu_split_tail": 8192, "cu_split_max_n": 40000}
 
 
 def synth(n, d, seed):
@@ -48,16 +48,8 @@ def exact(tag, n, d, seed, kernel, params, reps=3, ref=None):
 
 
 if __name__ == "__main__":
-    which = [a for a in sys.argv[1:] if a not in ("quick", "trsv")] or ["C2", "C3"]
+    which = [a for a in sys.argv[1:] if a != "quick"] or ["C2", "C3"]
     quick = "quick" in sys.argv
-    if "trsv" in sys.argv:  # backward vector sweep: serial chain (trsv_pipe 0) vs diagonal chain + bulk updates on the second stream
-        cfgs0 = {"C2": (16384, 3, 2, agp.SqExponentialKernel()), "C3": (32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5)),
-                 "C4": (65536, 3, 4, agp.SqExponentialKernel())}
-        for name in which:
-            n, d, seed, kern = cfgs0[name]
-            ref = exact(name, n, d, seed, kern, {"trsv_pipe": 0}, reps=2)
-            exact(name, n, d, seed, kern, {"trsv_pipe": 1}, reps=2, ref=ref)
-        sys.exit(0)
     cfgs = {"C2": (16384, 3, 2, agp.SqExponentialKernel()), "C3": (32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5)),
             "C4": (65536, 3, 4, agp.SqExponentialKernel()), "M8": (8192, 3, 12, agp.SqExponentialKernel())}
     for name in which:
