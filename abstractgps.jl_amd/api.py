@@ -224,6 +224,12 @@ class Context:
         P, Q, nb, comm, depth = (t.value for t in v)
         return {"P": P, "Q": Q, "nb": nb, "comm": {0: "none", 1: "rccl", 2: "copies"}.get(comm, str(comm)), "lookahead_depth": depth}
 
+    def multi_stats(self) -> dict:
+        """fit attempts of the multi-device driver and how many were repetitions after a failed self-check (gp_ctx_multi_stats)"""
+        f, r = C.c_int64(), C.c_int64()
+        check(self.lib.gp_ctx_multi_stats(self.handle, C.byref(f), C.byref(r)))
+        return {"fits": f.value, "retries": r.value}
+
     def set_param(self, name: str, value: int) -> None:
         check(self.lib.gp_ctx_set_param(self.handle, name.encode(), int(value)))
 

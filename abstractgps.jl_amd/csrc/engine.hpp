@@ -95,14 +95,9 @@ struct gp_ctx {
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
     bool gemm_pad_set = false;
     bool gemm_pad_user = false;  // "gemm_pad_lds" was set explicitly (otherwise: 0 for fp64, 20480 for fp32)
-    int gemm_ring3 = 0;    // three-stage operand ring (gemm_nt_dma3_kernel): 0 off, 1 fp32 launches, 2 all
-    bool gemm_ring3_set = false;
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
     int vfe_overlap = 1;   // VFE: kmat / ystats / partial-sum adds on the second stream beside the chunk GEMMs (double buffers)
     int vfe_sk = 0;        // VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))
-    int gemm_wide = 0;     // 256×128-tile, 3-stage, one-workgroup-per-CU GEMM (gemm_nt_wide_kernel): 0 off, 1 large launches, 2 wherever legal
-    long gemm_wide_min = 256;  // gemm_wide = 1: launches of at least this many 256×128 tiles
-    bool gemm_wide_set = false;
     int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;

@@ -237,39 +237,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             grid = dim3((unsigned)total, 1);
         }
         if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
-        // wide tile (256×128, 3-stage ring, one workgroup per CU): large launches only — "gemm_wide" 1 = launches of at least
-        // gemm_wide_min tiles, 2 = wherever the shape allows (tests)
-        bool wide = false;
-        if constexpr (std::is_same<T, CT>::value) {
-            const long bk = 128 / (long)sizeof(T);
-            const long tm2 = (M + 255) / 256;
-            const bool shape_ok = !kmajor && c->gemm_wide > 0 && c->gemm_dma && (M % 128) == 0 && (N % 64) == 0 && (K % bk) == 0 && K >= 2 * bk &&
-                                  (g.ktri != 2 || true) && (!single_lower || ((g.row0 - g.col0) % 128) == 0);
-            if (shape_ok) {
-                long ntile = tm2 * tn;
-                GridMap gw = g;
-                gw.compact = 0;
-                dim3 gridw((unsigned)tn, (unsigned)tm2);
-                if (single_lower) {  // lower trapezoid in 256×128 tiles: row tile i has min(tn, dt + 2i + 2) column tiles
-                    long tri = std::min(tm2, std::max(0L, (tn - dt - 2 + 1) / 2));
-                    ntile = tri * tri + tri * (dt + 1) + (tm2 - tri) * tn;
-                    gw.compact = 4;
-                    gridw = dim3((unsigned)ntile, 1);
-                }
-                if (g.nbatch > 1) gridw.z = (unsigned)g.nbatch;
-                if (c->gemm_wide >= 2 || ntile * std::max(1, g.nbatch) >= c->gemm_wide_min) {
-                    if (!c->gemm_wide_set) {
-                        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
-                        HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
-                        c->gemm_wide_set = true;
-                    }
-                    hipLaunchKernelGGL((gemm_nt_wide_kernel<T>), gridw, dim3(256), 147456, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, gw);
-                    wide = true;
-                }
-            }
-        }
-        if (wide) {
-        } else if (kmajor)
+        if (kmajor)
             hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
                                (int)N, (int)K, g);
         else if ((c->gemm_streamk || c->sk_scope > 0) && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
@@ -286,15 +254,6 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             if (R == 0) G2 = 0;
             hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g, ntiles, (int)G2);
-        } else if ((c->gemm_ring3 == 2 || (c->gemm_ring3 == 1 && sizeof(T) == 4)) && (c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) &&
-                   std::is_same<T, CT>::value) {
-            // three-stage operand ring, one workgroup per CU (96 KiB of dynamic LDS)
-            if (!c->gemm_ring3_set) {
-                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma3_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-                c->gemm_ring3_set = true;
-            }
-            hipLaunchKernelGGL((gemm_nt_dma3_kernel<T>), grid, dim3(256), 98304, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, g);
         } else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
             // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
             // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
@@ -1557,12 +1516,9 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
-    else if (!strcmp(name, "gemm_ring3")) c->gemm_ring3 = (int)v;
     else if (!strcmp(name, "vfe_ks")) c->vfe_ks = std::max<int64_t>(512, round_up(v, 512));
     else if (!strcmp(name, "vfe_sk")) c->vfe_sk = v != 0;
     else if (!strcmp(name, "vfe_overlap")) c->vfe_overlap = v != 0;
-    else if (!strcmp(name, "gemm_wide")) c->gemm_wide = (int)v;
-    else if (!strcmp(name, "gemm_wide_min")) c->gemm_wide_min = std::max<int64_t>(1, v);
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "cu_split")) c->cu_split = (int)std::max<int64_t>(0, v / 8 * 8);
     else if (!strcmp(name, "cu_split_nb")) c->cu_split_nb = std::max<int64_t>(128, round_up(v, 128));
@@ -1570,7 +1526,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "cu_split_max_n")) c->cu_split_max_n = std::max<int64_t>(0, v);
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
-             !strcmp(name, "multi_check") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
+             !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }

@@ -490,348 +490,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     }
 }
 
-// gemm_nt_dma3: gemm_nt_dma with a THREE-stage ring (96 KiB of dynamic LDS, hence one workgroup per CU): the operand DMA of k-step
-// kt+2 is in flight while kt computes, and the only wait in the loop is vmcnt(8) — everything but the youngest stage's eight
-// DMA instructions of this wave has landed.  Used for the fp32 VFE GEMMs ("gemm_ring3").
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_dma3_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
-                                                               int N, int K, GridMap g) {
-    using CT = T;
-    using TR = Tr<T>;
-    using chunk_t = typename TR::chunk_t;
-    using acc_t = typename TR::acc_t;
-    constexpr int VEC = TR::VEC;
-    constexpr int BK = 8 * VEC;
-
-    int bi = blockIdx.y, bj = blockIdx.x;
-    if (g.compact == 1) compact_tile(g, (int)blockIdx.x, bi, bj);
-    else if (g.compact >= 2) {
-        if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
-    } else if (g.ktri == 1) {
-        bi = (int)gridDim.y - 1 - bi;  // triangular k range: the long row tiles are dispatched first
-    }
-    if (g.nbatch > 1) {
-        C += (long)blockIdx.z * g.cstride;
-        A += (long)blockIdx.z * K;
-        B += (long)blockIdx.z * K;
-    }
-    const int m0 = bi * 128, n0 = bj * 128;
-    long gr0 = 0, gc0 = 0;
-    if (g.lower) {
-        gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
-        gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
-        if (gc0 > gr0 + 127) return;  // whole tile above the diagonal (block-uniform)
-    }
-    extern __shared__ __attribute__((aligned(1024))) unsigned char ring3_smem[];  // 3 stages × (A 16 KiB + B 16 KiB)
-    chunk_t (*As)[128 * 8] = reinterpret_cast<chunk_t (*)[128 * 8]>(ring3_smem);
-    chunk_t (*Bs)[128 * 8] = reinterpret_cast<chunk_t (*)[128 * 8]>(ring3_smem + 3 * 16384);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
-    if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
-
-    // DMA map: instruction i of wave w covers rows 8·(4i+w) .. +8; lane -> row 8·(4i+w) + (lane>>3), slot lane&7
-    const int drow = lane >> 3;
-    const T* Ag[4];
-    const T* Bg[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 8 * (4 * i + w) + drow;
-        const int cch = (lane & 7) ^ ((r >> 1) & 7);
-        Ag[i] = A + (long)(m0 + r) * lda + cch * VEC;
-        Bg[i] = B + (long)(n0 + r) * ldb + cch * VEC;
-    }
-    // The DMA is issued from inline asm: hipcc (ROCm 7.2) otherwise drains vmcnt(0) in front of the next ds_read of the
-    // OTHER buffer (it cannot tell the two apart), which serialises the prefetch.  The only consumer-side wait is the
-    // explicit vmcnt(0) in front of the step's barrier below.
-    const unsigned ldsA = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&As[0][0];
-    const unsigned ldsB = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&Bs[0][0];
-    auto dma1 = [&](const T* src, unsigned dst) {
-        unsigned keep;
-        const unsigned d = __builtin_amdgcn_readfirstlane(dst);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(d)
-                     : "memory");
-    };
-    auto dma = [&](int buf, long kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
-            dma1(Bg[i] + kt * BK, ldsB + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
-        }
-    };
-    auto dma_wait_barrier = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    const int li = lane & 15, lg = lane >> 4;
-    acc_t acc[4][4];
-    CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
-    const CT* const Cr = active ? Cw : C + li;
-    const int kt0 = (g.ktri == 2) ? m0 / BK : 0;
-    int nk = K / BK;
-    if (g.ktri == 1) nk = min(nk, (g.ktri_off + m0 + 128) / BK);
-    dma(0, kt0);
-    dma(1, (kt0 + 1 < nk) ? kt0 + 1 : kt0);
-    if (g.beta0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = T(0);
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
-    }
-
-    // fragment slots: row wr·64 + t·16 + li, chunk 4h+lg -> slot (row·8) + ((4h+lg) ^ swz(li))
-    const int sw = (li >> 1) & 7;
-    const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
-    dma_wait_barrier();
-
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) % 3;
-        int nx2 = cur + 2;
-        if (nx2 >= 3) nx2 -= 3;
-        dma(nx2, (kt + 2 < nk) ? kt + 2 : nk - 1);  // the tail re-fetches the last tile into an idle stage (uniform counts)
-        chunk_t a[2][4], b[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int sl = (4 * h + lg) ^ sw;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[h][t] = As[cur][fa + t * 128 + sl];
-                b[h][t] = Bs[cur][fb + t * 128 + sl];
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[h][mt][v], b[h][nt][v], acc[mt][nt]);
-#if GPMI_GEMM_SCHED
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC - 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC + 8, 0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this step in front of the vmcnt(0) + barrier
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-
-    if (active) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = -acc[mt][nt][r];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// gemm_nt_wide: the same contract as gemm_nt_dma (C[M×N] −= A[M×K]·B[N×K]ᵀ, row-major, k contiguous; beta0 / ktri / nbatch /
-//   lower predicates) with a 256×128 block tile, a THREE-stage LDS-DMA ring and ONE workgroup per CU:
-//     4 waves as 2×2, each wave 128×64 = 8×4 MFMA 16×16 tiles (32 accumulators: 256 registers in fp64 — the whole 512-entry
-//     register file of a SIMD serves one wave), BK = 16 (f64) / 32 (f32);
-//     LDS per stage: A 256 rows × 128 B + B 128 rows × 128 B = 48 KiB, 3 stages = 144 of the 160 KiB;
-//     operand bytes fetched per flop drop by 25 % against the 128×128 tile ((256+128)/(256·128) vs (128+128)/(128·128)), LDS
-//     fragment reads per flop by 25 %, barriers per flop by half; the prefetch distance is TWO k-steps (the only wait in the
-//     loop is vmcnt(12): everything but the youngest stage's 12 DMA instructions of this wave has landed).
-//   Same source-side XOR swizzle as gemm_nt_dma.  M multiple of 128, N multiple of 64, K multiple of BK and >= 2·BK.
-//   compact == 4: 1-D grid over the lower trapezoid in 256×128 tiles (row tile i has min(tn, dt + 2i + 2) column tiles).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void compact_tile_wide(const GridMap& g, int b, int& bi, int& bj) {
-    int tri = (g.tn - g.dt - 2 + 1) / 2;  // rows whose count dt + 2i + 2 is below tn
-    if (tri < 0) tri = 0;
-    const long tot_tri = (long)tri * tri + (long)tri * (g.dt + 1);
-    if (b < tot_tri) {
-        const double q = (double)(g.dt + 1);
-        int i = (int)((-q + sqrt(q * q + 4.0 * (double)b)) * 0.5);
-        while ((long)i * i + (long)i * (g.dt + 1) > b) --i;
-        while ((long)(i + 1) * (i + 1) + (long)(i + 1) * (g.dt + 1) <= b) ++i;
-        bi = i;
-        bj = b - (int)((long)i * i + (long)i * (g.dt + 1));
-    } else {
-        const long r = b - tot_tri;
-        bi = tri + (int)(r / g.tn);
-        bj = (int)(r % g.tn);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 1) void gemm_nt_wide_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M, int N,
-                                                               int K, GridMap g) {
-    using TR = Tr<T>;
-    using chunk_t = typename TR::chunk_t;
-    using acc_t = typename TR::acc_t;
-    constexpr int VEC = TR::VEC;
-    constexpr int BK = 8 * VEC;
-    constexpr int NS = 3;
-    constexpr unsigned STAGE = 49152;  // bytes per stage: A 32 KiB then B 16 KiB
-    extern __shared__ __attribute__((aligned(1024))) unsigned char wide_smem[];
-
-    int bi = blockIdx.y, bj = blockIdx.x;
-    if (g.compact == 4) compact_tile_wide(g, (int)blockIdx.x, bi, bj);
-    else if (g.ktri == 1) bi = (int)gridDim.y - 1 - bi;  // triangular k range: the long row tiles are dispatched first
-    if (g.nbatch > 1) {
-        C += (long)blockIdx.z * g.cstride;
-        A += (long)blockIdx.z * K;
-        B += (long)blockIdx.z * K;
-    }
-    const int m0 = bi * 256, n0 = bj * 128;
-    long gr0 = 0, gc0 = 0;
-    if (g.lower) {
-        gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
-        gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
-        if (g.P == 1) {
-            if (gc0 > gr0 + 255) return;  // whole tile above the diagonal (block-uniform)
-        } else {  // block-cyclic rows: the tile's two 128-row halves are different global row blocks when nb == 128
-            const long gr1 = glob_idx(g.row0 + m0 + 128, g.nb, g.P, g.p);
-            if (gc0 > gr0 + 127 && gc0 > gr1 + 127) return;
-        }
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    // store predicates per 64-row half of the wave's 128×64 tile (rows past M / columns past N / above the diagonal)
-    const bool in_n = wc * 64 < N - n0;
-    bool act[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int rloc = wr * 128 + hh * 64;
-        act[hh] = in_n && (rloc < M - m0);
-        if (g.lower) {
-            const long grh = glob_idx(g.row0 + m0 + rloc, g.nb, g.P, g.p);
-            if (gc0 + wc * 64 > grh + 63) act[hh] = false;
-        }
-    }
-
-    // DMA map: A: instruction i (0..7) of wave w covers row block rb = 4i + w (8 rows each, 32 blocks); B: i (0..3), rb = 4i + w
-    const int drow = lane >> 3;
-    const T* Ag[8];
-    const T* Bg[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = 8 * (4 * i + w) + drow;
-        const int cch = (lane & 7) ^ ((r >> 1) & 7);
-        Ag[i] = A + (long)(m0 + r) * lda + cch * VEC;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 8 * (4 * i + w) + drow;
-        const int cch = (lane & 7) ^ ((r >> 1) & 7);
-        Bg[i] = B + (long)(n0 + r) * ldb + cch * VEC;
-    }
-    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&wide_smem[0];
-    auto dma1 = [&](const T* src, unsigned dst) {
-        unsigned keep;
-        const unsigned d = __builtin_amdgcn_readfirstlane(dst);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(d)
-                     : "memory");
-    };
-    auto dma = [&](int stage, long kt) {
-        const unsigned base = lds0 + (unsigned)stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dma1(Ag[i] + kt * BK, base + (unsigned)((4 * i + w) * 1024));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma1(Bg[i] + kt * BK, base + 32768u + (unsigned)((4 * i + w) * 1024));
-    };
-
-    const int li = lane & 15, lg = lane >> 4;
-    const int kt0 = (g.ktri == 2) ? m0 / BK : 0;
-    int nk = K / BK;
-    if (g.ktri == 1) nk = min(nk, (g.ktri_off + m0 + 256) / BK);
-    dma(0, kt0);
-    dma(1, (kt0 + 1 < nk) ? kt0 + 1 : kt0);
-
-    acc_t acc[8][4];
-    T* const Cw = C + (long)(m0 + wr * 128) * ldc + n0 + wc * 64 + li;
-    if (g.beta0) {
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = T(0);
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const T* const Cr = act[mt >> 2] ? Cw : C + li - (long)(mt >> 2) * 64 * ldc;  // halves that store nothing preload a valid tile
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
-        }
-    }
-    // fragment slots: A row wr·128 + t·16 + li, B row wc·64 + t·16 + li; chunk 4h+lg -> slot (row·8) + ((4h+lg) ^ swz(li))
-    const int sw = (li >> 1) & 7;
-    const int fa = (wr * 128 + li) * 8, fb = (wc * 64 + li) * 8;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) % NS;
-        int nxt2 = cur + 2;
-        if (nxt2 >= NS) nxt2 -= NS;
-        dma(nxt2, (kt + 2 < nk) ? kt + 2 : nk - 1);  // the tail re-fetches the last tile into an idle stage (uniform counts)
-        const chunk_t* As = reinterpret_cast<const chunk_t*>(wide_smem + (size_t)cur * STAGE);
-        const chunk_t* Bs = reinterpret_cast<const chunk_t*>(wide_smem + (size_t)cur * STAGE + 32768);
-        chunk_t a[2][8], b[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int sl = (4 * h + lg) ^ sw;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) a[h][t] = As[fa + t * 128 + sl];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[h][t] = Bs[fb + t * 128 + sl];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[h][mt][v], b[h][nt][v], acc[mt][nt]);
-#if GPMI_GEMM_SCHED
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 32 * VEC - 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 32 * VEC + 8, 0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this step in front of the wait + barrier
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        if (!act[mt >> 2]) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = -acc[mt][nt][r];
-    }
-}
+// (Two measured-slower variants of this kernel were removed in round 3 — a three-stage operand ring with one workgroup per CU,
+//  gemm_nt_dma3, and a 256×128 tile with one wave per SIMD, gemm_nt_wide: 55 vs 70 TF/s fp64, C5 94 vs 90 ms,
+//  profiles/r2/gemm_wide.txt, profiles/r2/c5_ablation.txt; they live in the history at dbd752d.)
 
 // ------------------------------------------------------------------------------------------------
 // gemm_nt_sk: gemm_nt_dma with a persistent grid and a stream-K tail (single-GPU maps only: plain rectangle or the

@@ -243,6 +243,9 @@ struct gp_multi {
     int copy_kernel = 0;  // block copies by copy2d_kernel instead of hipMemcpy2DAsync ("copy_kernel" parameter)
     int debug_sync = 0;   // diagnostic: host-synchronise the rank's streams after every exchange ("multi_debug_sync")
     int check = 0;        // "multi_check" (see the header comment)
+    int verify = 1;          // host-side self-check of every fit + one repetition on failure ("multi_verify")
+    int inject_fault = 0;    // diagnostic: the next fit hands the self-check a spoiled alpha once ("multi_inject_fault")
+    long fits = 0, retries = 0;  // fit attempts / repetitions after a failed self-check (gp_ctx_multi_stats)
     long window = 16;        // block steps a rank thread may queue ahead of its device ("multi_window")
     double timeout_s = 600;  // a rank thread that waits longer than this for a peer or for its own streams fails the fit
     std::string comm_note;
@@ -1008,6 +1011,14 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
         m->check = (int)v;
         return 0;
     }
+    if (!strcmp(name, "multi_inject_fault")) {
+        m->inject_fault = v != 0;
+        return 0;
+    }
+    if (!strcmp(name, "multi_verify")) {
+        m->verify = v != 0;
+        return 0;
+    }
     if (!strcmp(name, "multi_window")) {
         m->window = std::max<int64_t>(4, v);
         return 0;
@@ -1155,6 +1166,15 @@ extern "C" int32_t gp_ctx_multi_info(gp_ctx* c, int32_t* P, int32_t* Q, int32_t*
     return 0;
 }
 
+extern "C" int32_t gp_ctx_multi_stats(gp_ctx* c, int64_t* fits, int64_t* retries) {
+    Guard gd(c);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_ctx");
+    gp_multi* m = c->multi;
+    if (fits) *fits = m ? m->fits : 0;
+    if (retries) *retries = m ? m->retries : 0;
+    return 0;
+}
+
 static long lcm_of(long a0, long b0) {
     long a = a0, b = b0;
     while (b) {
@@ -1286,8 +1306,6 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         }
     }
     (void)hipSetDevice(c->device);
-    const long seq = ++M->seq;
-    M->abort.store(0);
     const bool keep = post != nullptr;
 
     Trace tr;
@@ -1304,55 +1322,149 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     std::vector<std::vector<double>> scal((size_t)R, std::vector<double>(8 + RHS_ROWS, 0.0));
     std::vector<int> infos((size_t)R, 0);
     std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
-    for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
-    auto t0 = std::chrono::steady_clock::now();
-    {
-        std::vector<std::thread> th;
-        for (int r = 0; r < R; ++r)
-            th.emplace_back([&, r]() {
-                MRank& rk = M->ranks[r];
-                std::lock_guard<std::mutex> l(rk.c->mu);
-                rk.rc = fit_rank(M, &rk, dm, false, k->kind, k->variance, xs_h.data(), noise_h.data(), rhs_h.data(), ncols, keep, keep, alpha_pin,
-                                 scal[r].data(), &infos[r], bufs[r].get(), seq);
-                if (rk.rc != 0) {
-                    rk.err = gp_last_error();
-                    M->abort.store(1);
-                    if (rk.rc != -1992) {  // (a stream that never drains would block these as well)
-                        (void)hipStreamSynchronize(rk.c->sm);
-                        (void)hipStreamSynchronize(rk.c->sp);
-                        (void)hipStreamSynchronize(rk.sc);
+    auto release_bufs = [&]() {  // everything of the attempt goes back to the rank caches — the factor pieces a successful rank thread
+        for (int r = 0; r < R; ++r) {  // had already taken out of its DevBufs for the posterior handle included
+            MRank& rk = M->ranks[r];
+            std::lock_guard<std::mutex> l(rk.c->mu);
+            (void)hipSetDevice(rk.device);
+            if (keep && rk.rc == 0 && rk.A) ctx_release(rk.c, rk.A, 0);
+            rk.A = nullptr;
+            bufs[r].reset();
+        }
+        (void)hipSetDevice(c->device);
+    };
+    // "multi_verify" (default on): the result is checked on the host before it is handed out — δᵀα against ‖L⁻¹δ‖² (two independent
+    // paths through the factor) and (K + Σy)α = δ on a few rows recomputed from the inputs — and the fit is repeated ONCE when the
+    // check (or the factorisation: a spurious non-positive pivot) fails.  Why: with 18+ streams of several rank threads on ONE
+    // device, kernels occasionally ran with stale arguments on this ROCm stack (profiles/r3/first_fit.md; 20 % of
+    // the first fits of fresh 8-rank contexts, 2.5 % with HIP_FORCE_DEV_KERNARG=0, ~1 % once every queue exists before the fit).
+    const bool verify = M->verify != 0;
+    const bool want_alpha = keep || verify;
+    auto kappa_host = [&](long i, long j) -> double {
+        double d2 = 0;
+        for (int dd = 0; dd < d; ++dd) {
+            const double t = xs_h[(size_t)dd * npad + i] - xs_h[(size_t)dd * npad + j];
+            d2 += t * t;
+        }
+        const double r = std::sqrt(d2);
+        switch (k->kind) {
+            case 0: return k->variance * std::exp(-0.5 * d2);
+            case 1: return k->variance * std::exp(-r);
+            case 2: return k->variance * (1.0 + 1.7320508075688772935 * r) * std::exp(-1.7320508075688772935 * r);
+            default: return k->variance * (1.0 + 2.2360679774997896964 * r + 5.0 / 3.0 * d2) * std::exp(-2.2360679774997896964 * r);
+        }
+    };
+    auto verify_result = [&](double zz, std::string& why) -> bool {
+        double da = 0, dn = 0;
+        for (long i = 0; i < n; ++i) {
+            da += rhs_h[i] * alpha_pin[i];
+            dn += std::fabs(rhs_h[i] * alpha_pin[i]);
+        }
+        if (!(std::fabs(da - zz) <= 1e-7 * (dn + std::fabs(zz)))) {
+            char b[160];
+            snprintf(b, sizeof b, "delta'alpha = %.15g but ||L^-1 delta||^2 = %.15g", da, zz);
+            why = b;
+            return false;
+        }
+        const int S = 8;
+        for (int t = 0; t < S; ++t) {
+            const long i = (long)((double)(2 * t + 1) / (2 * S) * (double)n);  // rows spread over the matrix
+            double acc = 0, mag = 0;
+            for (long j = 0; j < n; ++j) {
+                const double v = kappa_host(i, j) * alpha_pin[j];
+                acc += v;
+                mag += std::fabs(v);
+            }
+            acc += noise_h[i] * alpha_pin[i];
+            mag += std::fabs(noise_h[i] * alpha_pin[i]) + std::fabs(rhs_h[i]);
+            if (!(std::fabs(acc - rhs_h[i]) <= 1e-7 * mag)) {
+                char b[160];
+                snprintf(b, sizeof b, "row %ld of (K + Sigma_y) alpha = delta is off by %.3e (scale %.3e)", i, acc - rhs_h[i], mag);
+                why = b;
+                return false;
+            }
+        }
+        return true;
+    };
+    long seq = 0;
+    double wall_ms = 0;
+    int32_t rc = 0;
+    for (int attempt = 0;; ++attempt) {
+        seq = ++M->seq;
+        M->abort.store(0);
+        M->fits++;
+        for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
+        auto t0 = std::chrono::steady_clock::now();
+        {
+            std::vector<std::thread> th;
+            for (int r = 0; r < R; ++r)
+                th.emplace_back([&, r]() {
+                    MRank& rk = M->ranks[r];
+                    std::lock_guard<std::mutex> l(rk.c->mu);
+                    rk.rc = fit_rank(M, &rk, dm, false, k->kind, k->variance, xs_h.data(), noise_h.data(), rhs_h.data(), ncols, want_alpha, keep,
+                                     alpha_pin, scal[r].data(), &infos[r], bufs[r].get(), seq);
+                    if (rk.rc != 0) {
+                        rk.err = gp_last_error();
+                        M->abort.store(1);
+                        if (rk.rc != -1992) {  // (a stream that never drains would block these as well)
+                            (void)hipStreamSynchronize(rk.c->sm);
+                            (void)hipStreamSynchronize(rk.c->sp);
+                            (void)hipStreamSynchronize(rk.sc);
+                        }
                     }
-                }
-            });
-        for (auto& t : th) t.join();
+                });
+            for (auto& t : th) t.join();
+        }
+        wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        (void)hipSetDevice(c->device);
+        rc = 0;
+        for (int r = 0; r < R; ++r)
+            if (M->ranks[r].rc != 0 && M->ranks[r].rc != -1999) {
+                rc = set_err_text(M->ranks[r].rc, "rank " + std::to_string(r) + ": " + M->ranks[r].err);
+                break;
+            }
+        if (rc == 0)
+            for (int r = 0; r < R; ++r)
+                if (M->ranks[r].rc != 0) rc = set_err_text(M->ranks[r].rc, M->ranks[r].err);
+        if (rc != 0) break;  // hard error: no second attempt
+        int info = 0;  // the FIRST failing leading minor (LAPACK dpotrf info; PosDefException(info) in the reference)
+        for (int r = 0; r < R; ++r)
+            if (infos[r] > 0 && (info == 0 || infos[r] < info)) info = infos[r];
+        std::string why;
+        bool ok = info == 0;
+        if (ok && M->inject_fault) {  // diagnostic ("multi_inject_fault"): spoil one entry of alpha once, as a kernel run on stale arguments would
+            alpha_pin[n / 3] += 1.0;
+            M->inject_fault = 0;
+        }
+        if (ok && verify) {
+            double zz = 0;
+            for (int r = 0; r < R; ++r) zz += scal[r][8];
+            ok = verify_result(zz, why);
+        } else if (!ok) {
+            why = "leading minor of order " + std::to_string(info) + " not positive definite";
+        }
+        if (ok) break;
+        if (verify && attempt == 0) {  // once more, from the inputs
+            M->retries++;
+            if (getenv("GPMI_VERBOSE")) fprintf(stderr, "[gpmi355] multi-device fit repeated: %s\n", why.c_str());
+            release_bufs();
+            for (int r = 0; r < R; ++r) {
+                std::fill(scal[r].begin(), scal[r].end(), 0.0);
+                infos[r] = 0;
+            }
+            memset(alpha_pin, 0, sizeof(double) * (size_t)npad);
+            continue;
+        }
+        rc = info != 0 ? info : set_err_text(-1991, "multi-device fit failed its self-check twice: " + why);
+        break;
     }
-    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     M->tr = nullptr;
     if (tr.f) {
         fclose(tr.f);
         tr.f = nullptr;
     }
-    (void)hipSetDevice(c->device);
-    int32_t rc = 0;
-    for (int r = 0; r < R; ++r)
-        if (M->ranks[r].rc != 0 && M->ranks[r].rc != -1999) {
-            rc = set_err_text(M->ranks[r].rc, "rank " + std::to_string(r) + ": " + M->ranks[r].err);
-            break;
-        }
-    if (rc == 0)
-        for (int r = 0; r < R; ++r)
-            if (M->ranks[r].rc != 0) rc = set_err_text(M->ranks[r].rc, M->ranks[r].err);
-    int info = 0;  // the FIRST failing leading minor (LAPACK dpotrf info; PosDefException(info) in the reference)
-    for (int r = 0; r < R; ++r)
-        if (infos[r] > 0 && (info == 0 || infos[r] < info)) info = infos[r];
-    if (rc == 0 && info != 0) rc = info;
     if (rc != 0) {
-        for (int r = 0; r < R; ++r) {
-            std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
-            (void)hipSetDevice(M->ranks[r].device);
-            bufs[r].reset();
-        }
-        (void)hipSetDevice(c->device);
+        release_bufs();
         (void)hipHostFree(alpha_pin);
         return rc;
     }
@@ -1393,12 +1505,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
                 rc2 = set_err_text(-1994, "upload of the posterior vectors failed");
         }
         if (rc2 != 0) {
-            for (int r = 0; r < R; ++r) {
-                std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
-                (void)hipSetDevice(M->ranks[r].device);
-                bufs[r].reset();
-            }
-            (void)hipSetDevice(c->device);
+            release_bufs();
             (void)hipHostFree(alpha_pin);
             return rc2;
         }

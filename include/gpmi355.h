@@ -108,6 +108,10 @@ int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null);
 int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int32_t ndev, int32_t P, int32_t Q, int32_t nb);
 /* Grid / transport of a ctx (1×1, nb 0, comm 0 for a single-device ctx).  comm: 1 RCCL, 2 peer / same-device copies. */
 int32_t gp_ctx_multi_info(gp_ctx* ctx, int32_t* P, int32_t* Q, int32_t* nb, int32_t* comm, int32_t* depth);
+/* Multi-device fits check their result on the host ("multi_verify", default 1: δᵀα against ‖L⁻¹δ‖², and (K + Σy)α = δ on a few
+ * rows recomputed from the inputs) and are repeated once when the check or the factorisation fails; a second failure is the
+ * error (-1991, or the LAPACK info).  fits = fit attempts so far, retries = repetitions (0 on a healthy stack). */
+int32_t gp_ctx_multi_stats(gp_ctx* ctx, int64_t* fits, int64_t* retries);
 /* The schedule the multi-device driver issues for a P×Q grid over nblk block columns (look-ahead depth 1..3; comm 1 =
  * send/recv transport, 2 = copies), written as JSON lines to `path`: every stream operation with its block footprint, every
  * event record / wait, every transfer — produced by the SAME rank-thread code that drives the devices, run without a device
@@ -136,8 +140,6 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
- *   "gemm_ring3"     three-stage operand ring GEMM (1 fp32 launches, 2 all; measured slower)   default 0
- *   "gemm_wide"      256×128-tile one-wave-per-SIMD GEMM (1 large launches, 2 all; measured slower)   default 0
  *   "cu_split"       CU-partitioned look-ahead: the panel stream owns this many CUs (multiple of 8, spread over all XCDs and
  *                    shader engines through hipExtStreamCreateWithCUMask), the trailing update the rest, while more than
  *                    "cu_split_tail" rows remain; panels are "cu_split_nb" wide then; sizes above "cu_split_max_n" keep the

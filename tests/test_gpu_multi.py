@@ -139,6 +139,32 @@ def test_multi_fp32_and_wide_Y_and_other_entry_points_run_on_device0(agp):
         ctx.close()
 
 
+def test_self_check_repeats_a_spoiled_fit_once(agp):
+    """multi_verify (default on): a fit whose alpha does not satisfy delta'alpha = ||L^-1 delta||^2 / (K + Sigma_y) alpha = delta is repeated
+    once from the inputs — exercised by spoiling alpha on the host ("multi_inject_fault"); with the check off the spoiled value
+    comes through, which is what the check exists to prevent (stale kernel arguments on this stack: DESIGN.md §5)."""
+    x, y = o.synth_inputs(900, 2, 21)
+    of = o.GP(o.Kernel(o.MATERN32))
+    lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, x, 0.05), y)
+    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128)
+    try:
+        f = agp.GP(agp.Matern32Kernel(), ctx=ctx)
+        post = agp.posterior(f(agp.RowVecs(x), 0.05), y)
+        assert ctx.multi_stats() == {"fits": 1, "retries": 0} and _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+        ctx.set_param("multi_inject_fault", 1)
+        post = agp.posterior(f(agp.RowVecs(x), 0.05), y)
+        assert ctx.multi_stats() == {"fits": 3, "retries": 1}
+        assert float(post.logpdf_value) == pytest.approx(lp_ref, rel=1e-10) and _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+        np.testing.assert_allclose(post.data.C.U, opost.U, atol=1e-10)          # the kept factor is the repeated fit's
+        assert agp.logpdf(f(agp.RowVecs(x), 0.05), y) == pytest.approx(lp_ref, rel=1e-10)   # logpdf alone is checked too
+        ctx.set_param("multi_verify", 0)
+        ctx.set_param("multi_inject_fault", 1)
+        bad = agp.posterior(f(agp.RowVecs(x), 0.05), y)
+        assert _relnorm(bad.data.alpha, opost.alpha) > 1e-3 and ctx.multi_stats()["retries"] == 1
+    finally:
+        ctx.close()
+
+
 def test_more_devices_than_visible_is_an_error(agp):
     import torch
 

@@ -386,3 +386,22 @@ def test_multi_panel_parity_8192(agp):
     mo, vo = opost.mean_and_var(xs)
     np.testing.assert_allclose(m, mo, atol=1e-8)
     np.testing.assert_allclose(v, vo, atol=1e-9)
+
+
+def test_cu_partitioned_lookahead_parity(agp):
+    """"cu_split": panel stream on 32 CUs and trailing update on the other 224 (hipExtStreamCreateWithCUMask) for the first part of the
+    factorisation, the chain-bound tail on the whole machine — same numbers as the unpartitioned schedule and as the oracle."""
+    n = 10240
+    x, y = o.synth_inputs(n, 3, 77)
+    lp, opost = o.logpdf_and_posterior(o.FiniteGP(o.GP(o.Kernel(o.MATERN52, 1.2, 0.9)), x, 0.02), y)
+    ctx = agp.Context(0)
+    try:
+        for k, v in {"cu_split": 32, "cu_split_nb": 512, "cu_split_tail": 4096}.items():
+            ctx.set_param(k, v)
+        f = agp.GP(1.2 * agp.Matern52Kernel() @ agp.ScaleTransform(0.9), ctx=ctx)
+        for _ in range(2):
+            post = agp.posterior(f(agp.RowVecs(x), 0.02), y)
+            assert float(post.logpdf_value) == pytest.approx(lp, rel=1e-10)
+            assert _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+    finally:
+        ctx.close()

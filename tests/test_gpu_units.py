@@ -206,58 +206,6 @@ def test_gemm_tn_kmajor(lib, h, m, n, k, lower):
         assert (Cm - ref).abs().max().item() < 1e-10
 
 
-@pytest.fixture
-def wide(lib, h):
-    from abstractgps_jl_amd._lib import check
-
-    check(lib.gp_ctx_set_param(h, b"gemm_wide", 2))
-    yield
-    check(lib.gp_ctx_set_param(h, b"gemm_wide", 0))
-
-
-@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (256, 128, 64), (384, 64, 64), (1024, 1024, 1024), (2176, 2304, 48),
-                                    (4224, 1152, 32), (640, 448, 272)])
-def test_gemm_wide_rect(lib, h, wide, m, n, k):
-    """gemm_nt_wide_kernel (256×128 tile, 3-stage LDS-DMA ring) against torch, incl. partial row tiles (m ≡ 128 mod 256) and
-    pipelines shorter than the ring."""
-    test_gemm_nt_rect(lib, h, m, n, k)
-
-
-@pytest.mark.parametrize("m,n,off,coff", [(256, 256, 0, 0), (512, 128, 128, 128), (2304, 2304, 0, 0), (2432, 2176, 384, 128),
-                                          (3200, 2560, 1152, 0), (2048, 2048, 128, 128), (1280, 1536, 0, 0)])
-def test_gemm_wide_lower(lib, h, wide, m, n, off, coff):
-    """lower mode through the 256×128 trapezoid enumeration: every element on/below the diagonal updated, 64×64 sub-tiles
-    strictly above it untouched."""
-    test_gemm_nt_lower_skips_upper(lib, h, m, n, off, coff)
-
-
-def test_gemm_wide_fp32_and_full_paths(agp):
-    """the wide kernel inside the real paths: fp64 factorisation (lower trapezoids), fp32/fp64 VFE (triangular-k and split-K
-    batched modes), block-cyclic predicate (virtual ranks) — all against the oracle."""
-    from oracle import gp_oracle as o
-
-    x, y = o.synth_inputs(3000, 3, 9)
-    ref = float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y))
-    ctx = agp.Context(0)
-    ctx.set_param("gemm_wide", 2)
-    ctx.set_param("nb", 512)
-    f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
-    assert float(agp.logpdf(f(agp.RowVecs(x), 0.01), y)) == pytest.approx(ref, rel=1e-10)
-    z = x[::10]
-    of = o.GP(o.Kernel(o.SE))
-    e64 = o.elbo(of, z, 1e-4, o.FiniteGP(of, x, 0.1), y)
-    assert float(agp.elbo(agp.VFE(f(agp.RowVecs(z), 1e-4)), f(agp.RowVecs(x), 0.1), y)) == pytest.approx(e64, rel=1e-8)
-    e32 = agp.elbo(agp.VFE(f(agp.RowVecs(z.astype(np.float32)), 1e-4)), f(agp.RowVecs(x.astype(np.float32)), np.float32(0.1)), y.astype(np.float32))
-    assert float(e32) == pytest.approx(e64, rel=2e-4)
-    ctx.close()
-    mctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=256)
-    mctx.set_param("gemm_wide", 2)
-    fm = agp.GP(agp.SqExponentialKernel(), ctx=mctx)
-    post = agp.posterior(fm(agp.RowVecs(x), 0.01), y)
-    assert float(post.logpdf_value) == pytest.approx(ref, rel=1e-10)
-    mctx.close()
-
-
 @pytest.mark.parametrize("group", [64, 128, 256, 512])
 def test_potrf_leaf_groups(lib, h, group):
     """left-looking leaf groups: a leaf applies the kpre = 0..group/64−1 tiles to its left itself before factoring (64 = every

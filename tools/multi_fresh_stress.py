@@ -28,7 +28,7 @@ from oracle import gp_oracle as o  # noqa: E402
 check = int(args.get("check", "0"))
 grids = [tuple(int(v) for v in g.split("x")) for g in args.get("grids", "4x2,8x1,2x4,2x3").split(",")]
 n, nb = int(args.get("n", "2049")), int(args.get("nb", "128"))
-bad = tot = 0
+bad = tot = retries = 0
 t0 = time.time()
 for rep in range(reps):
     for gi, (P, Q) in enumerate(grids):
@@ -43,6 +43,7 @@ for rep in range(reps):
         ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
         ctx.set_param("lookahead_depth", depth)
         ctx.set_param("multi_timeout_s", 120)
+        ctx.set_param("multi_verify", int(args.get("verify", "0")))   # raw failure rate by default; verify=1: the shipped self-check + one repetition
         if check:
             ctx.set_param("multi_check", check)
         if "copy_kernel" in args:
@@ -70,7 +71,9 @@ for rep in range(reps):
         except Exception as e:  # noqa: BLE001
             bad += 1
             print(f"ERROR rep {rep} grid {P}x{Q} depth {depth} d {d}: {type(e).__name__}: {str(e)[:1500]}", flush=True)
+        retries += ctx.multi_stats()["retries"]
         ctx.close()
+print(f"[self-check repetitions: {retries}] " if int(args.get("verify", "0")) else "", end="")
 print(f"fresh-context first fits: {bad} bad of {tot} (sk={os.environ['GPMI_MULTI_SK']} prio={os.environ['GPMI_COMM_PRIO']} check={check} "
       f"comm={args.get('comm', 'copies')} hwq={os.environ['GPU_MAX_HW_QUEUES']} n={n} nb={nb}) in {time.time() - t0:.0f}s", flush=True)
 sys.exit(1 if bad else 0)
