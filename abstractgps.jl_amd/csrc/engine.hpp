@@ -235,6 +235,9 @@ int32_t eng_trsv(gp_ctx* c, hipStream_t s, const double* l, long ldl, long np, d
 int32_t eng_gemv_t(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nrows, long ncols, const double* a, double* r);
 int32_t eng_rowsumsq(gp_ctx* c, hipStream_t s, const double* x, long ldx, long nrows, long ncols, double* out_dev);
 int32_t eng_add_vec(gp_ctx* c, hipStream_t s, double* dst, const double* src, long n);  // dst += src
+// out[r] = Σ_j variance·κ(‖xs_r − x_j‖) alpha_j for nrows points xs (dimension-major, stride ldxs): rows of K·alpha without K
+int32_t eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const double* x, long ldx, int d, int kind, double variance,
+                 long n, const double* alpha, double* out, long nrows);
 // 2-D block copy by a kernel (16-B aligned rows, even cols): source may live on a peer device with peer access enabled
 int32_t eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols);
 }  // namespace gpmi

@@ -694,6 +694,14 @@ int32_t gpmi::eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const 
     HIPCHK(hipGetLastError());
     return 0;
 }
+int32_t gpmi::eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const double* x, long ldx, int d, int kind, double variance,
+                       long n, const double* alpha, double* out, long nrows) {
+    (void)c;
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(kvec_kernel<double>, dim3((unsigned)nrows), dim3(256), 0, s, xs, ldxs, x, ldx, d, kind, variance, n, alpha, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int32_t gpmi::eng_add_vec(gp_ctx* c, hipStream_t s, double* dst, const double* src, long n) {
     (void)c;
     if (n <= 0) return 0;

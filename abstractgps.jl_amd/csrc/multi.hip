@@ -222,6 +222,8 @@ struct MRank {
     double* stage[4] = {nullptr, nullptr, nullptr, nullptr};
     double* acc = nullptr;       // backward sweep: per local column partial sums
     double* alpha_blk = nullptr; // backward sweep: α blocks computed by this rank (diagonal owner), indexed by global block
+    double* xs = nullptr;        // scaled inputs [d][npad] (kept until the fit's buffers are released: the self-check reads them)
+    double* ver = nullptr;       // self-check: this rank's rows of K·α
     int* flags = nullptr;        // "multi_check": marker flags of this rank's events
     int* log = nullptr;          // "multi_check": findings
     int32_t rc = 0;
@@ -475,7 +477,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     const int check = rr.check;
 
     // ---- buffers
-    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0;
+    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0, *ver_v = 0;
     void* Ab_v[4] = {0, 0, 0, 0};
     void* Bb_v[4] = {0, 0, 0, 0};
     void* St_v[4] = {0, 0, 0, 0};
@@ -490,6 +492,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
         RC(bufs->get(sizeof(double) * (size_t)(n_loc + 128), &acc_v));
         RC(bufs->get(sizeof(double) * (size_t)npad, &ab_v));
         RC(bufs->get(sizeof(double) * (size_t)NB * (P + 1), &tmp_v));
+        RC(bufs->get(sizeof(double) * (size_t)npad, &ver_v));
         for (int s = 0; s < NBUF; ++s) {
             if (Q > 1) RC(bufs->get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &Ab_v[s]));
             RC(bufs->get(sizeof(double) * (size_t)(n_loc + 128) * LDP, &Bb_v[s]));
@@ -502,6 +505,8 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     me->Lkk = (double*)Lkk_v;
     me->acc = (double*)acc_v;
     me->alpha_blk = (double*)ab_v;
+    me->xs = (double*)xs_v;
+    me->ver = (double*)ver_v;
     me->flags = (int*)chk_v;
     me->log = chk_v ? (int*)chk_v + rr.nflags : nullptr;
     for (int s = 0; s < 4; ++s) me->stage[s] = (double*)St_v[s];
@@ -1333,27 +1338,13 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         }
         (void)hipSetDevice(c->device);
     };
-    // "multi_verify" (default on): the result is checked on the host before it is handed out — δᵀα against ‖L⁻¹δ‖² (two independent
-    // paths through the factor) and (K + Σy)α = δ on a few rows recomputed from the inputs — and the fit is repeated ONCE when the
+    // "multi_verify" (default on): the result is checked before it is handed out — δᵀα against ‖L⁻¹δ‖² (forward against backward
+    // solve) and (K + Σy)α = δ on every row, K·α recomputed from the inputs on the devices — and the fit is repeated ONCE when the
     // check (or the factorisation: a spurious non-positive pivot) fails.  Why: with 18+ streams of several rank threads on ONE
     // device, kernels occasionally ran with stale arguments on this ROCm stack (profiles/r3/first_fit.md; 20 % of
     // the first fits of fresh 8-rank contexts, 2.5 % with HIP_FORCE_DEV_KERNARG=0, ~1 % once every queue exists before the fit).
     const bool verify = M->verify != 0;
     const bool want_alpha = keep || verify;
-    auto kappa_host = [&](long i, long j) -> double {
-        double d2 = 0;
-        for (int dd = 0; dd < d; ++dd) {
-            const double t = xs_h[(size_t)dd * npad + i] - xs_h[(size_t)dd * npad + j];
-            d2 += t * t;
-        }
-        const double r = std::sqrt(d2);
-        switch (k->kind) {
-            case 0: return k->variance * std::exp(-0.5 * d2);
-            case 1: return k->variance * std::exp(-r);
-            case 2: return k->variance * (1.0 + 1.7320508075688772935 * r) * std::exp(-1.7320508075688772935 * r);
-            default: return k->variance * (1.0 + 2.2360679774997896964 * r + 5.0 / 3.0 * d2) * std::exp(-2.2360679774997896964 * r);
-        }
-    };
     auto verify_result = [&](double zz, std::string& why) -> bool {
         double da = 0, dn = 0;
         for (long i = 0; i < n; ++i) {
@@ -1366,20 +1357,46 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
             why = b;
             return false;
         }
-        const int S = 8;
-        for (int t = 0; t < S; ++t) {
-            const long i = (long)((double)(2 * t + 1) / (2 * S) * (double)n);  // rows spread over the matrix
-            double acc = 0, mag = 0;
-            for (long j = 0; j < n; ++j) {
-                const double v = kappa_host(i, j) * alpha_pin[j];
-                acc += v;
-                mag += std::fabs(v);
+        // (K + Σy) α = δ on EVERY row: a wrong tile perturbs the factored matrix in one block only, and the residual is then confined
+        // to that block's rows and columns (a sample of rows missed 3 of 27 corrupted fits, profiles/r3/first_fit.md) — so every rank
+        // evaluates its share of the rows of K·α on its device straight from the inputs (kvec: no matrix involved)
+        std::vector<double> Ka((size_t)n, 0.0);
+        std::vector<int32_t> vrc((size_t)R, 0);
+        {
+            std::vector<std::thread> th;
+            for (int r = 0; r < R; ++r)
+                th.emplace_back([&, r]() {
+                    MRank& rk = M->ranks[r];
+                    std::lock_guard<std::mutex> l(rk.c->mu);
+                    vrc[r] = [&]() -> int32_t {
+                        MCHK(hipSetDevice(rk.device));
+                        const long i0 = n * r / R, i1 = n * (r + 1) / R;
+                        MCHK(hipMemcpyAsync(rk.alpha_blk, alpha_pin, sizeof(double) * (size_t)npad, hipMemcpyHostToDevice, rk.c->sm));
+                        RC(eng_kvec(rk.c, rk.c->sm, rk.xs + i0, npad, rk.xs, npad, d, k->kind, k->variance, n, rk.alpha_blk, rk.ver + i0, i1 - i0));
+                        MCHK(hipMemcpyAsync(Ka.data() + i0, rk.ver + i0, sizeof(double) * (size_t)(i1 - i0), hipMemcpyDeviceToHost, rk.c->sm));
+                        MCHK(hipStreamSynchronize(rk.c->sm));
+                        return 0;
+                    }();
+                });
+            for (auto& t : th) t.join();
+        }
+        (void)hipSetDevice(c->device);
+        for (int r = 0; r < R; ++r)
+            if (vrc[r] != 0) {
+                why = "the residual pass failed on rank " + std::to_string(r);
+                return false;
             }
-            acc += noise_h[i] * alpha_pin[i];
-            mag += std::fabs(noise_h[i] * alpha_pin[i]) + std::fabs(rhs_h[i]);
-            if (!(std::fabs(acc - rhs_h[i]) <= 1e-7 * mag)) {
-                char b[160];
-                snprintf(b, sizeof b, "row %ld of (K + Sigma_y) alpha = delta is off by %.3e (scale %.3e)", i, acc - rhs_h[i], mag);
+        double amax = 0, dmax = 0;
+        for (long i = 0; i < n; ++i) {
+            amax = std::max(amax, std::fabs(alpha_pin[i]));
+            dmax = std::max(dmax, std::fabs(rhs_h[i]));
+        }
+        const double tol = 1e-9 * ((double)n * k->variance * amax + dmax);  // ≥ 1e5 × the rounding of a backward-stable solve, ≤ 1e-3 × the damage seen
+        for (long i = 0; i < n; ++i) {
+            const double res = Ka[i] + noise_h[i] * alpha_pin[i] - rhs_h[i];
+            if (!(std::fabs(res) <= tol)) {
+                char b[200];
+                snprintf(b, sizeof b, "row %ld of (K + Sigma_y) alpha = delta is off by %.3e (tolerance %.3e)", i, res, tol);
                 why = b;
                 return false;
             }

@@ -108,8 +108,8 @@ int32_t gp_ctx_create(gp_ctx** out, int32_t device, void* stream_or_null);
 int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int32_t ndev, int32_t P, int32_t Q, int32_t nb);
 /* Grid / transport of a ctx (1×1, nb 0, comm 0 for a single-device ctx).  comm: 1 RCCL, 2 peer / same-device copies. */
 int32_t gp_ctx_multi_info(gp_ctx* ctx, int32_t* P, int32_t* Q, int32_t* nb, int32_t* comm, int32_t* depth);
-/* Multi-device fits check their result on the host ("multi_verify", default 1: δᵀα against ‖L⁻¹δ‖², and (K + Σy)α = δ on a few
- * rows recomputed from the inputs) and are repeated once when the check or the factorisation fails; a second failure is the
+/* Multi-device fits check their result before handing it out ("multi_verify", default 1: δᵀα against ‖L⁻¹δ‖², and (K + Σy)α = δ on
+ * every row with K·α recomputed from the inputs on the devices) and are repeated once when the check or the factorisation fails; a second failure is the
  * error (-1991, or the LAPACK info).  fits = fit attempts so far, retries = repetitions (0 on a healthy stack). */
 int32_t gp_ctx_multi_stats(gp_ctx* ctx, int64_t* fits, int64_t* retries);
 /* The schedule the multi-device driver issues for a P×Q grid over nblk block columns (look-ahead depth 1..3; comm 1 =

@@ -179,7 +179,7 @@ def test_vfe_append_pseudo_points(agp, dtype, m1, m2):
     # on the new diagonal block C22 = cov(prior, z_new) (src/sparse_approximations.jl:138) while a batch fit has it on all of K_zz,
     # and the Schur complement C22 − U12ᵀU12 of nearby pseudo-points is small (measured on MI355X: 1e-6 of jitter moves these
     # predictions by 1.4e-2).  The reference's own test compares α at atol = rtol = 1e-2 (test/sparse_approximations.jl:79).
-    tol_b = 5e-2
+    tol_b = 5e-2 if dtype == np.float64 else 0.15   # fp32 case: jitter 1e-3 on the batch side only
     np.testing.assert_allclose(m3, ob.mean(xs), atol=tol_b)
     elbo_b = o.elbo(of, np.concatenate([z1, z2]), jitter, o.FiniteGP(of, x, s2), y)
     assert float(p3.objective) == pytest.approx(elbo_b, rel=5e-2)

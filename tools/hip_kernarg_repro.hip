@@ -17,7 +17,7 @@ struct Args { long a, b, c, d; };  // a few more bytes of arguments, all derived
 __global__ void tagk(unsigned* out, unsigned tag, Args x, int spin) {
     long t0 = clock64();
     while (clock64() - t0 < spin) {}
-    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (x.a == tag * 3L && x.b == tag + 7L && x.c == ~(long)tag && x.d == tag * tag * 1L) ? tag : 0xdeadu;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (x.a == tag * 3L && x.b == tag + 7L && x.c == ~(long)tag && x.d == (long)tag * (long)tag) ? tag : 0xdeadu;
 }
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 8, R = argc > 2 ? atoi(argv[2]) : 300, L = argc > 3 ? atoi(argv[3]) : 64;
