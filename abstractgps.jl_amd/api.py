@@ -226,9 +226,9 @@ class Context:
 
     def multi_stats(self) -> dict:
         """fit attempts of the multi-device driver and how many were repetitions after a failed self-check (gp_ctx_multi_stats)"""
-        f, r = C.c_int64(), C.c_int64()
-        check(self.lib.gp_ctx_multi_stats(self.handle, C.byref(f), C.byref(r)))
-        return {"fits": f.value, "retries": r.value}
+        f, r, sv = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.gp_ctx_multi_stats(self.handle, C.byref(f), C.byref(r), C.byref(sv)))
+        return {"fits": f.value, "retries": r.value, "solves": sv.value}
 
     def set_param(self, name: str, value: int) -> None:
         check(self.lib.gp_ctx_set_param(self.handle, name.encode(), int(value)))

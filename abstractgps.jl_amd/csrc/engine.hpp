@@ -235,6 +235,9 @@ int32_t eng_trsv(gp_ctx* c, hipStream_t s, const double* l, long ldl, long np, d
 int32_t eng_gemv_t(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nrows, long ncols, const double* a, double* r);
 int32_t eng_rowsumsq(gp_ctx* c, hipStream_t s, const double* x, long ldx, long nrows, long ncols, double* out_dev);
 int32_t eng_add_vec(gp_ctx* c, hipStream_t s, double* dst, const double* src, long n);  // dst += src
+// out (nr_pad × nc_pad, row-major) = variance·κ(‖xr_i − xc_j‖), zero where i >= nr_valid or j >= nc_valid (cross-Gram block)
+int32_t eng_kcross(gp_ctx* c, hipStream_t s, int kind, double variance, const double* xr, long ldxr, long nr_valid, long nr_pad,
+                   const double* xc, long ldxc, long nc_valid, long nc_pad, int d, double* out, long ld);
 // out[r] = Σ_j variance·κ(‖xs_r − x_j‖) alpha_j for nrows points xs (dimension-major, stride ldxs): rows of K·alpha without K
 int32_t eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const double* x, long ldx, int d, int kind, double variance,
                  long n, const double* alpha, double* out, long nrows);
@@ -249,5 +252,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
                   gp_post* post, void* alpha_out);
 void multi_trim(gp_ctx* c);  // gp_ctx_trim of every rank context
 int32_t multi_gather(gp_post* post);  // block-cyclic pieces -> one row-major factor on the ctx's first device
+bool multi_can_solve(gp_post* post);  // predictive variances on the distributed factor possible (pieces not gathered, same grid alive)
+int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub);  // Σ_c (K_*x L⁻ᵀ)[s][c]²
 void multi_post_release(gp_post* post);
 int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v);  // 1 = not a multi parameter

@@ -694,6 +694,16 @@ int32_t gpmi::eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const 
     HIPCHK(hipGetLastError());
     return 0;
 }
+int32_t gpmi::eng_kcross(gp_ctx* c, hipStream_t s, int kind, double variance, const double* xr, long ldxr, long nr_valid, long nr_pad,
+                         const double* xc, long ldxc, long nc_valid, long nc_pad, int d, double* out, long ld) {
+    (void)c;
+    dim3 grid((unsigned)(nc_pad / 128), (unsigned)(nr_pad / 128));
+    if (grid.x == 0 || grid.y == 0) return 0;
+    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, out, ld, xr, ldxr, xc, ldxc, d, kind, variance, (const double*)nullptr, nr_valid,
+                       nc_valid, 0, plain_map(0, 0, 0), (const double*)nullptr, (const double*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int32_t gpmi::eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const double* x, long ldx, int d, int kind, double variance,
                        long n, const double* alpha, double* out, long nrows) {
     (void)c;
@@ -1534,7 +1544,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "cu_split_max_n")) c->cu_split_max_n = std::max<int64_t>(0, v);
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
-             !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
+             !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_dist_predict") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }
@@ -1731,6 +1741,21 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
     if ((what & 4) && !cov_out) return set_arg_err(7, "cov_out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    if ((what & 2) && !(what & 4) && multi_can_solve(post)) {
+        // multi-device fit whose factor still lives as block-cyclic pieces: the variances come from a forward solve ON the pieces
+        // (multi.hip: multi_predict_var) — no gather; the mean needs α only
+        if (what & 1) RC(predict_impl<double>(post, xs, pm, 1, mean_out, nullptr, nullptr));
+        gp_kernel k{};
+        k.kind = post->kind; k.dtype = 0; k.variance = post->variance; k.nscale = post->nscale;
+        k.scale = post->scale.empty() ? nullptr : post->scale.data();
+        const long ns = xs->n;
+        std::vector<double> xs_h;
+        scale_points<double>(&k, xs, ns, xs_h);
+        std::vector<double> sub((size_t)ns, 0.0);
+        RC(multi_predict_var(post, xs_h.data(), ns, ns, sub.data()));
+        for (long i = 0; i < ns; ++i) ((double*)var_out)[i] = post->variance - sub[i];  // k** = σ² for the stationary kernels of the path
+        return 0;
+    }
     if (what & 6) RC(multi_gather(post));  // multi-device fit: the factor is assembled on this device on first need
     return post->dtype == 0 ? predict_impl<double>(post, xs, pm, what, mean_out, var_out, cov_out)
                             : predict_impl<float>(post, xs, pm, what, mean_out, var_out, cov_out);

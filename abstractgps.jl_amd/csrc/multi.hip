@@ -86,6 +86,15 @@ __global__ void mk_cmp_kernel(const double* a, long lda, const double* b, long l
     if (threadIdx.x == 0 && bad) mk_log(log, code, k, blk, bad);
 }
 
+// dst[r][c] += src[r][c] for a rows×cols block (row-major, own leading dimensions)
+__global__ void mk_addmat_kernel(double* dst, long ldd, const double* src, long lds, long rows, long cols) {
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] += src[r * lds + c];
+    }
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -167,7 +176,7 @@ struct XEvent : Ev {
 constexpr long RHS_ROWS = 128;
 enum { SM = 0, SP = 1, SC = 2 };
 const char* const SNAME[3] = {"sm", "sp", "sc"};
-const char* const XTAG[4] = {"ready", "lkk", "accr", "alr"};
+const char* const XTAG[6] = {"ready", "lkk", "accr", "alr", "sx", "sa"};
 
 // block footprint of an operation (block units; the checker expands it):
 //   A   : rank, local block rows [a0, a1) (fl & 2: plus the RHS block row; fl & 4: the RHS block row only), local block columns
@@ -214,6 +223,7 @@ struct MRank {
     hipStream_t sc = nullptr;  // comm stream
     ncclComm_t_ comm = nullptr;
     std::vector<XEvent> ready, lkk, accr, alr;  // per block column k (see fit_rank)
+    std::vector<XEvent> sx, sa;                  // forward solve on the distributed factor: X_k published / accumulators after step k
     std::vector<hipEvent_t> own;                 // own-thread events (arrived / bulk_done / la_done), pooled
     // per-fit state (device pointers owned through DevBufs of the rank thread; shared with peers for the pulls)
     double* A = nullptr;
@@ -224,6 +234,9 @@ struct MRank {
     double* alpha_blk = nullptr; // backward sweep: α blocks computed by this rank (diagonal owner), indexed by global block
     double* xs = nullptr;        // scaled inputs [d][npad] (kept until the fit's buffers are released: the self-check reads them)
     double* ver = nullptr;       // self-check: this rank's rows of K·α
+    double* sacc = nullptr;      // forward solve: accumulators −Σ_j X_j L_ijᵀ of this rank's block rows  [nsp][nlb_r·NB + 32]
+    double* sxown = nullptr;     // forward solve: the solution blocks X_k this rank owns (diagonal owner)  [nsp][n_own·NB + 32]
+    long sacc_ld = 0, sxown_ld = 0;
     int* flags = nullptr;        // "multi_check": marker flags of this rank's events
     int* log = nullptr;          // "multi_check": findings
     int32_t rc = 0;
@@ -246,6 +259,8 @@ struct gp_multi {
     int debug_sync = 0;   // diagnostic: host-synchronise the rank's streams after every exchange ("multi_debug_sync")
     int check = 0;        // "multi_check" (see the header comment)
     int verify = 1;          // host-side self-check of every fit + one repetition on failure ("multi_verify")
+    int dist_predict = 1;    // predictive variances of a multi-device posterior on the distributed factor ("multi_dist_predict"; 0: gather first)
+    long solves = 0;         // forward solves on the distributed factor so far
     int inject_fault = 0;    // diagnostic: the next fit hands the self-check a spoiled alpha once ("multi_inject_fault")
     long fits = 0, retries = 0;  // fit attempts / repetitions after a failed self-check (gp_ctx_multi_stats)
     long window = 16;        // block steps a rank thread may queue ahead of its device ("multi_window")
@@ -299,7 +314,7 @@ struct RankRun {
         out->owner = me->r;
         out->tag = tag;
         out->k = k;
-        out->id = (int)(4 * dm.nblk + (long)own_used);
+        out->id = (int)(6 * dm.nblk + (long)own_used);
         if (dry) {
             ++own_used;
             out->ev = nullptr;
@@ -483,7 +498,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     void* St_v[4] = {0, 0, 0, 0};
     const size_t A_b = sizeof(double) * (size_t)(m_loc + 128) * ld;
     const long own_cap = 10 * nblk + 64;
-    rr.nflags = 4 * nblk + own_cap;
+    rr.nflags = 6 * nblk + own_cap;
     if (!dry) {
         RC(bufs->get(A_b, &A_v));
         RC(bufs->get(sizeof(double) * (size_t)dm.d * npad, &xs_v));
@@ -977,6 +992,179 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     return 0;
 }
 
+
+// cross-thread events of every rank sized for nblk block columns (ids: kind · nblk + k — the layout of the marker flags and of the
+// trace names); dry: no HIP events behind them
+int32_t size_xevents(gp_multi* M, long nblk, bool dry) {
+    for (auto& rk : M->ranks) {
+        if (!dry) (void)hipSetDevice(rk.device);
+        int kind = 0;
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa}) {
+            if ((long)v->size() < nblk) {
+                std::vector<XEvent> nv((size_t)nblk);
+                for (size_t i = 0; i < v->size(); ++i) {
+                    nv[i].ev = (*v)[i].ev;
+                    nv[i].gen.store((*v)[i].gen.load());
+                }
+                if (!dry)
+                    for (size_t i = v->size(); i < (size_t)nblk; ++i)
+                        if (hipEventCreateWithFlags(&nv[i].ev, hipEventDisableTiming) != hipSuccess) return set_err_text(-1995, "hipEventCreate failed");
+                v->swap(nv);
+            }
+            for (size_t i = 0; i < v->size(); ++i) {
+                (*v)[i].owner = rk.r;
+                (*v)[i].id = (long)i < nblk ? (int)(kind * nblk + (long)i) : -1;
+                (*v)[i].tag = XTAG[kind];
+                (*v)[i].k = (long)i;
+            }
+            ++kind;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward solve on the distributed factor: X = K_*x L⁻ᵀ for a chunk of test points, and Σ_c X[s][c]² per test point — the predictive
+// variance var* = k** − colsumsq(U⁻ᵀ K_x*) (src/exact_gpr_posterior.jl:68-70, src/util/common_covmat_ops.jl:90) WITHOUT gathering
+// the factor onto one device.  L stays where the factorisation left it (block (i, j) on rank (i mod P, j mod Q)); what travels are
+// N*×NB blocks of the solution:
+//   step k   diagonal owner (k mod P, k mod Q):  X_k = (K(x*, x_k) + Σ_q ACC_q[k]) L_kk⁻ᵀ     (its own accumulator + the Q−1 partial
+//                                                sums of its process row), colsumsq(X_k) into its variance partial, X_k published
+//            every rank of process column k mod Q: fetch X_k, ACC[rows i > k] −= X_k L_ikᵀ     (ONE MFMA GEMM over its local rows)
+// One stream per rank (the main stream); cross-rank dependencies are the generation-numbered events sx[k] (X_k final) and sa[k]
+// (accumulators after step k).  First version: no look-ahead — the chain X_k → update of row k+1 → X_k+1 is serial.
+// ------------------------------------------------------------------------------------------------
+struct SolveDims {
+    long n, npad, nblk, NB, ns, nsp;
+    int d;
+};
+
+int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const gp_multi_post::Piece* piece, int kind, double variance,
+                   const double* x_h /* [d][npad] scaled training inputs */, const double* xs_h /* [d][nsp] scaled test inputs */,
+                   double* vsum_host /* nsp: this rank's partial Σ_c X² */, DevBufs* bufs, long seq) {
+    const int P = M->P, Q = M->Q, p = me->p, q = me->q, R_ = me->r;
+    const long NB = sd.NB, nblk = sd.nblk, npad = sd.npad, nsp = sd.nsp, n = sd.n;
+    const long nlb_r = nblk / P;
+    const long lcm = (long)P * Q / std::__gcd((long)P, (long)Q);
+    const long n_own = nblk / lcm;  // diagonal blocks of this rank (one per lcm block columns; 0 when (p, q) never meets the diagonal)
+    const bool on_diag = [&]() {
+        for (long k = 0; k < lcm; ++k)
+            if (k % P == p && k % Q == q) return true;
+        return false;
+    }();
+    Dims dm{n, npad, nblk, NB, nlb_r, nblk / Q, NB + 32, sd.d};
+    RankRun rr{M, me, dm, seq, dry, 0, M->tr};
+    gp_ctx* c = me->c;
+    hipStream_t sm = nullptr;
+    if (!dry) {
+        rr.st[SM] = sm = c->sm;
+        MCHK(hipSetDevice(me->device));
+        c->ev_used = 0;
+        c->gemm_recs.clear();
+    }
+    const long ldacc = nlb_r * NB + 32, ldx = std::max(1L, n_own) * NB + 32, ldb = NB + 32;
+    void *x_v = 0, *xs_v = 0, *acc_v = 0, *xown_v = 0, *xb_v = 0, *t_v = 0, *vs_v = 0, *vt_v = 0;
+    if (!dry) {
+        RC(bufs->get(sizeof(double) * (size_t)sd.d * npad, &x_v));
+        RC(bufs->get(sizeof(double) * (size_t)sd.d * nsp, &xs_v));
+        RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldacc, &acc_v));
+        RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldx, &xown_v));
+        RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldb, &xb_v));
+        RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldb, &t_v));
+        RC(bufs->get(sizeof(double) * (size_t)nsp, &vs_v));
+        RC(bufs->get(sizeof(double) * (size_t)nsp, &vt_v));
+    }
+    me->sacc = (double*)acc_v; me->sacc_ld = ldacc;
+    me->sxown = (double*)xown_v; me->sxown_ld = ldx;
+    const double* A = piece ? (const double*)piece->A : nullptr;
+    const long ld = piece ? piece->ld : 0;
+    auto rank_of = [&](int pp, int qq) -> MRank& { return M->ranks[(size_t)pp * Q + qq]; };
+    auto addmat = [&](double* dst, long ldd, const double* src, long lds, long rows, long cols) -> int32_t {
+        hipLaunchKernelGGL(mk_addmat_kernel, dim3((unsigned)std::min<long>(1024, (rows * cols + 255) / 256)), dim3(256), 0, sm, dst, ldd, src, lds, rows, cols);
+        MCHK(hipGetLastError());
+        return 0;
+    };
+
+    RC(rr.op(SM, "solve_init", 0, 0, {}, {Fp{"ACC", R_, 0, 0, 0, nlb_r, 0}, Fp{"Vs", R_, 0, 0, 0, 1, 0}}, [&]() -> int32_t {
+        MCHK(hipMemcpyAsync(x_v, x_h, sizeof(double) * (size_t)sd.d * npad, hipMemcpyHostToDevice, sm));
+        MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)sd.d * nsp, hipMemcpyHostToDevice, sm));
+        MCHK(hipMemsetAsync(acc_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldacc, sm));
+        MCHK(hipMemsetAsync(xown_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldx, sm));
+        MCHK(hipMemsetAsync(xb_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldb, sm));
+        MCHK(hipMemsetAsync(t_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldb, sm));
+        MCHK(hipMemsetAsync(vs_v, 0, sizeof(double) * (size_t)nsp, sm));
+        return 0;
+    }));
+    (void)on_diag;
+    for (long k = 0; k < nblk; ++k) {
+        const int pk = (int)(k % P), qk = (int)(k % Q);
+        if (q != qk) continue;  // only the process column of block column k takes part in step k
+        const long li = k / P, lc = k / Q, ko = k / lcm;
+        const double* xk = nullptr;
+        long xk_ld = 0;
+        Fp f_xk;
+        if (p == pk) {  // diagonal owner
+            double* Xk = me->sxown ? me->sxown + ko * NB : nullptr;
+            const Fp fX = Fp{"X", R_, 0, 0, k, k + 1, 0};
+            const Fp fAcc = Fp{"ACC", R_, 0, 0, li, li + 1, 0};
+            RC(rr.op(SM, "kstar", k, 0, {}, {fX}, [&]() {
+                return eng_kcross(c, sm, kind, variance, (const double*)xs_v, nsp, sd.ns, nsp, (const double*)x_v + k * NB, npad,
+                                  std::max(0L, std::min(NB, n - k * NB)), NB, sd.d, Xk, ldx);
+            }));
+            RC(rr.op(SM, "add_own", k, 0, {fAcc, fX}, {fX}, [&]() { return addmat(Xk, ldx, me->sacc + li * NB, ldacc, nsp, NB); }));
+            for (int qq = 0; qq < Q; ++qq) {  // + the partial sums of the other ranks of my process row (their columns j < k, j ≡ qq mod Q)
+                if (qq == qk) continue;
+                long jl = -1;
+                for (long j = k - 1; j >= 0; --j)
+                    if ((int)(j % Q) == qq) {
+                        jl = j;
+                        break;
+                    }
+                if (jl < 0) continue;  // that rank holds no column left of k: its accumulator is still zero
+                MRank& src = rank_of(pk, qq);
+                const Fp fT = Fp{"T", R_, 0, 0, 0, 1, 0};
+                RC(rr.await(src.sa[jl], SM));
+                RC(rr.op(SM, "pull_acc", k, qq, {Fp{"ACC", src.r, 0, 0, li, li + 1, 0}}, {fT},
+                         [&]() { return rr.pull(SM, (double*)t_v, ldb, src.sacc + li * NB, src.sacc_ld, nsp, NB); }));
+                RC(rr.op(SM, "add_t", k, qq, {fT, fX}, {fX}, [&]() { return addmat(Xk, ldx, (const double*)t_v, ldb, nsp, NB); }));
+            }
+            RC(rr.op(SM, "trsm", k, 0, {Fp{"A", R_, li, li + 1, lc, lc + 1, 0}, fX}, {fX},
+                     [&]() { return eng_trsm(c, sm, Xk, ldx, nsp, A + li * NB * ld + lc * NB, ld, NB); }));
+            RC(rr.op(SM, "colsq", k, 0, {fX, Fp{"Vs", R_, 0, 0, 0, 1, 0}}, {Fp{"Vs", R_, 0, 0, 0, 1, 0}}, [&]() -> int32_t {
+                RC(eng_rowsumsq(c, sm, Xk, ldx, nsp, NB, (double*)vt_v));
+                return eng_add_vec(c, sm, (double*)vs_v, (const double*)vt_v, nsp);
+            }));
+            RC(rr.publish(me->sx[k], SM));
+            xk = Xk;
+            xk_ld = ldx;
+            f_xk = fX;
+        } else {
+            MRank& own = rank_of(pk, qk);
+            const Fp fB = Fp{"Xb", R_, 0, 0, 0, 1, 0};
+            RC(rr.await(own.sx[k], SM));
+            RC(rr.op(SM, "pull_x", k, 0, {Fp{"X", own.r, 0, 0, k, k + 1, 0}}, {fB},
+                     [&]() { return rr.pull(SM, (double*)xb_v, ldb, own.sxown + ko * NB, own.sxown_ld, nsp, NB); }));
+            xk = (const double*)xb_v;
+            xk_ld = ldb;
+            f_xk = fB;
+        }
+        // accumulators of my block rows below k:  ACC[:, rows i > k] −= X_k · L[rows i > k, block column k]ᵀ
+        const long lr0 = nlb_before(k, p, P);  // first local block row with global block > k
+        if (lr0 < nlb_r) {
+            const Fp fAcc = Fp{"ACC", R_, 0, 0, lr0, nlb_r, 0};
+            RC(rr.op(SM, "gemm", k, 0, {f_xk, Fp{"A", R_, lr0, nlb_r, lc, lc + 1, 0}, fAcc}, {fAcc}, [&]() {
+                return eng_gemm_nt(c, sm, me->sacc + lr0 * NB, ldacc, xk, xk_ld, A + lr0 * NB * ld + lc * NB, ld, nsp, (nlb_r - lr0) * NB, NB,
+                                   plain_map(0, 0, 0));
+            }));
+        }
+        RC(rr.publish(me->sa[k], SM));
+    }
+    if (dry) return 0;
+    MCHK(hipMemcpyAsync(vsum_host, vs_v, sizeof(double) * (size_t)nsp, hipMemcpyDeviceToHost, sm));
+    RC(rr.drain(SM));
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -987,7 +1175,7 @@ void multi_destroy(gp_multi* m) {
     for (auto& rk : m->ranks) {
         (void)hipSetDevice(rk.device);
         if (rk.comm && g_rccl.ok) (void)g_rccl.CommDestroy(rk.comm);
-        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr})
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa})
             for (auto& x : *v)
                 if (x.ev) (void)hipEventDestroy(x.ev);
         for (auto e : rk.own) (void)hipEventDestroy(e);
@@ -1014,6 +1202,10 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
     }
     if (!strcmp(name, "multi_check")) {
         m->check = (int)v;
+        return 0;
+    }
+    if (!strcmp(name, "multi_dist_predict")) {
+        m->dist_predict = v != 0;
         return 0;
     }
     if (!strcmp(name, "multi_inject_fault")) {
@@ -1171,12 +1363,13 @@ extern "C" int32_t gp_ctx_multi_info(gp_ctx* c, int32_t* P, int32_t* Q, int32_t*
     return 0;
 }
 
-extern "C" int32_t gp_ctx_multi_stats(gp_ctx* c, int64_t* fits, int64_t* retries) {
+extern "C" int32_t gp_ctx_multi_stats(gp_ctx* c, int64_t* fits, int64_t* retries, int64_t* solves) {
     Guard gd(c);
     if (!gd.ok) return set_arg_err(1, "not a live gp_ctx");
     gp_multi* m = c->multi;
     if (fits) *fits = m ? m->fits : 0;
     if (retries) *retries = m ? m->retries : 0;
+    if (solves) *solves = m ? m->solves : 0;
     return 0;
 }
 
@@ -1211,19 +1404,8 @@ extern "C" int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk_in
     for (int r = 0; r < M.R; ++r) {
         MRank& rk = M.ranks[r];
         rk.r = r; rk.p = r / Q; rk.q = r % Q;
-        int kind = 0;
-        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr}) {
-            std::vector<XEvent> nv((size_t)nblk);
-            for (long i = 0; i < nblk; ++i) {
-                nv[i].owner = r;
-                nv[i].id = (int)(kind * nblk + i);
-                nv[i].tag = XTAG[kind];
-                nv[i].k = i;
-            }
-            v->swap(nv);
-            ++kind;
-        }
     }
+    RC(size_xevents(&M, nblk, true));
     {
         char b[160];
         snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"dry\":1}", P, Q, nblk, depth, comm);
@@ -1283,31 +1465,11 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     MCHK(hipHostMalloc((void**)&alpha_pin, sizeof(double) * (size_t)npad, hipHostMallocPortable));
     memset(alpha_pin, 0, sizeof(double) * (size_t)npad);
 
-    // ---- events sized for this nblk (ids: kind · nblk + k — the layout of the marker flags and of the trace names)
-    for (auto& rk : M->ranks) {
-        (void)hipSetDevice(rk.device);
-        int kind = 0;
-        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr}) {
-            if ((long)v->size() < nblk) {
-                std::vector<XEvent> nv((size_t)nblk);
-                for (size_t i = 0; i < v->size(); ++i) {
-                    nv[i].ev = (*v)[i].ev;
-                    nv[i].gen.store((*v)[i].gen.load());
-                }
-                for (size_t i = v->size(); i < (size_t)nblk; ++i)
-                    if (hipEventCreateWithFlags(&nv[i].ev, hipEventDisableTiming) != hipSuccess) {
-                        (void)hipHostFree(alpha_pin);
-                        return set_err_text(-1995, "hipEventCreate failed");
-                    }
-                v->swap(nv);
-            }
-            for (size_t i = 0; i < v->size(); ++i) {
-                (*v)[i].owner = rk.r;
-                (*v)[i].id = (long)i < nblk ? (int)(kind * nblk + (long)i) : -1;
-                (*v)[i].tag = XTAG[kind];
-                (*v)[i].k = (long)i;
-            }
-            ++kind;
+    {
+        const int32_t erc = size_xevents(M, nblk, false);
+        if (erc != 0) {
+            (void)hipHostFree(alpha_pin);
+            return erc;
         }
     }
     (void)hipSetDevice(c->device);
@@ -1552,6 +1714,129 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     }
     (void)hipSetDevice(c->device);
     (void)hipHostFree(alpha_pin);
+    return 0;
+}
+
+// The forward-solve schedule for a P×Q grid over nblk block columns, traced without a device (see gp_multi_schedule_trace).
+extern "C" int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk_in, const char* path) {
+    if (P < 1 || Q < 1 || P * Q > 64) return set_arg_err(1, "P, Q");
+    if (nblk_in < 1 || nblk_in > 4096) return set_arg_err(3, "nblk");
+    if (!path) return set_arg_err(4, "path is NULL");
+    Trace tr;
+    tr.f = fopen(path, "w");
+    if (!tr.f) return set_arg_err(4, "cannot open the trace file");
+    gp_multi M;
+    M.P = P; M.Q = Q; M.R = P * Q; M.nb = 128; M.comm = 2; M.tr = &tr; M.timeout_s = 60;
+    const long lcm = lcm_of(P, Q);
+    const long nblk = (nblk_in + lcm - 1) / lcm * lcm;
+    M.ranks.resize((size_t)M.R);
+    for (int r = 0; r < M.R; ++r) {
+        MRank& rk = M.ranks[r];
+        rk.r = r; rk.p = r / Q; rk.q = r % Q;
+    }
+    RC(size_xevents(&M, nblk, true));
+    {
+        char b[160];
+        snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":0,\"comm\":2,\"dry\":1,\"mode\":\"solve\"}", P, Q, nblk);
+        tr.line(b);
+    }
+    SolveDims sd{nblk * 128, nblk * 128, nblk, 128, 128, 128, 1};
+    std::vector<std::thread> th;
+    for (int r = 0; r < M.R; ++r)
+        th.emplace_back([&, r]() {
+            MRank& rk = M.ranks[r];
+            rk.rc = solve_rank(&M, &rk, sd, true, nullptr, 0, 1.0, nullptr, nullptr, nullptr, nullptr, 1);
+            if (rk.rc != 0) {
+                rk.err = gp_last_error();
+                M.abort.store(1);
+            }
+        });
+    for (auto& t : th) t.join();
+    fclose(tr.f);
+    tr.f = nullptr;
+    for (int r = 0; r < M.R; ++r)
+        if (M.ranks[r].rc != 0 && M.ranks[r].rc != -1999) return set_err_text(M.ranks[r].rc, "rank " + std::to_string(r) + ": " + M.ranks[r].err);
+    return 0;
+}
+
+// can the predictive variance of this posterior be computed on the distributed factor?
+bool multi_can_solve(gp_post* post) {
+    gp_multi_post* mp = post->pieces;
+    gp_multi* M = post->ctx ? post->ctx->multi : nullptr;
+    return mp && M && M->dist_predict && M->P == mp->P && M->Q == mp->Q && (int)mp->pieces.size() == M->R && post->dtype == 0;
+}
+
+// var_sub[s] = Σ_c (K_*x L⁻ᵀ)[s][c]² for the ns test points xs_h (scaled, dimension-major [d][ns_ld]) — the amount the posterior
+// variance lies below the prior variance — on the block-cyclic pieces of the factor.  Called with the main ctx locked.
+int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub) {
+    gp_multi_post* mp = post->pieces;
+    gp_ctx* c = post->ctx;
+    gp_multi* M = c->multi;
+    const int R = M->R, d = post->d;
+    const long n = mp->n, npad = mp->npad, nblk = mp->nblk, NB = mp->nb, np = post->np;
+    // scaled training inputs: device 0 holds them as [d][np]; every rank gets [d][npad]
+    std::vector<double> x1((size_t)d * np), x_h((size_t)d * npad, 0.0);
+    MCHK(hipSetDevice(c->device));
+    MCHK(hipMemcpy(x1.data(), post->xs, sizeof(double) * x1.size(), hipMemcpyDeviceToHost));
+    for (int dd = 0; dd < d; ++dd) memcpy(&x_h[(size_t)dd * npad], &x1[(size_t)dd * np], sizeof(double) * (size_t)n);
+    RC(size_xevents(M, nblk, false));
+    (void)hipSetDevice(c->device);
+    const long CH = 4096;
+    for (long s0 = 0; s0 < ns; s0 += CH) {
+        const long nsc = std::min(CH, ns - s0), nsp = (nsc + 127) / 128 * 128;
+        std::vector<double> xs_h((size_t)d * nsp, 0.0);
+        for (int dd = 0; dd < d; ++dd) memcpy(&xs_h[(size_t)dd * nsp], xs_scaled + (size_t)dd * ns_ld + s0, sizeof(double) * (size_t)nsc);
+        SolveDims sd{n, npad, nblk, NB, nsc, nsp, d};
+        const long seq = ++M->seq;
+        M->abort.store(0);
+        Trace tr;
+        if (const char* tp = getenv("GPMI_TRACE_SCHEDULE")) {
+            tr.f = fopen(tp, "w");
+            if (tr.f) {
+                char b[160];
+                snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":0,\"comm\":2,\"dry\":0,\"mode\":\"solve\"}", M->P, M->Q, nblk);
+                tr.line(b);
+            }
+        }
+        M->tr = tr.f ? &tr : nullptr;
+        std::vector<std::vector<double>> part((size_t)R, std::vector<double>((size_t)nsp, 0.0));
+        std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
+        for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
+        {
+            std::vector<std::thread> th;
+            for (int r = 0; r < R; ++r)
+                th.emplace_back([&, r]() {
+                    MRank& rk = M->ranks[r];
+                    std::lock_guard<std::mutex> l(rk.c->mu);
+                    rk.rc = solve_rank(M, &rk, sd, false, &mp->pieces[r], post->kind, post->variance, x_h.data(), xs_h.data(), part[r].data(),
+                                       bufs[r].get(), seq);
+                    if (rk.rc != 0) {
+                        rk.err = gp_last_error();
+                        M->abort.store(1);
+                        if (rk.rc != -1992) (void)hipStreamSynchronize(rk.c->sm);
+                    }
+                });
+            for (auto& t : th) t.join();
+        }
+        M->tr = nullptr;
+        if (tr.f) fclose(tr.f);
+        for (int r = 0; r < R; ++r) {
+            std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
+            (void)hipSetDevice(M->ranks[r].device);
+            bufs[r].reset();
+        }
+        (void)hipSetDevice(c->device);
+        for (int r = 0; r < R; ++r)
+            if (M->ranks[r].rc != 0 && M->ranks[r].rc != -1999) return set_err_text(M->ranks[r].rc, "rank " + std::to_string(r) + ": " + M->ranks[r].err);
+        for (int r = 0; r < R; ++r)
+            if (M->ranks[r].rc != 0) return set_err_text(M->ranks[r].rc, M->ranks[r].err);
+        for (long i = 0; i < nsc; ++i) {
+            double acc = 0;
+            for (int r = 0; r < R; ++r) acc += part[r][i];
+            var_sub[s0 + i] = acc;
+        }
+        M->solves++;
+    }
     return 0;
 }
 

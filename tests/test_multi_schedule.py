@@ -52,6 +52,22 @@ def test_trace_covers_the_backward_sweep_transfers():
     assert any("sends but" in p for p in problems)
 
 
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_forward_solve_on_the_distributed_factor_is_ordered(grid):
+    """the schedule of the predictive-variance solve (csrc/multi.hip: solve_rank — X_k published by the diagonal owner, fetched by its
+    process column, partial sums gathered along its process row), traced from the real rank threads without a device"""
+    P, Q = grid
+    for nblk in (1, 2, 3, 5, 9, 17):
+        problems, rs = M.check_config(P, Q, nblk, 0, COPIES, solve=True)
+        assert not problems and not rs, (grid, nblk, problems[:3], rs[:3])
+
+
+def test_checker_finds_unwaited_solution_blocks_and_partial_sums():
+    for tag in ("sx", "sa"):   # X_k fetched before it is final / a partial sum fetched before the peer's last update
+        edit = lambda lines, tag=tag: [ln for ln in lines if not (ln["t"] == "wait" and ln.get("tag") == tag)]  # noqa: E731
+        assert M.check_config(2, 3, 6, 0, COPIES, mutate=edit, solve=True)[1]
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):

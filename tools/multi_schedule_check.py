@@ -33,13 +33,17 @@ def nlb_before(k, p, P):  # number of global blocks i <= k with i ≡ p (mod P)
     return (k - p) // P + 1 if k >= p else 0
 
 
-def emit_trace(P, Q, nblk, depth, comm, path):
-    """run the library's rank threads without a device (no GPU needed; the .so must be built)"""
+def emit_trace(P, Q, nblk, depth, comm, path, solve=False):
+    """run the library's rank threads without a device (no GPU needed; the .so must be built); solve: the forward solve on the
+    distributed factor (predictive variances) instead of the fit"""
     sys.path.insert(0, str(ROOT))
     import abstractgps_jl_amd as agp
 
     lib = agp._lib.load()
-    agp._lib.check(lib.gp_multi_schedule_trace(P, Q, nblk, depth, comm, str(path).encode()))
+    if solve:
+        agp._lib.check(lib.gp_multi_solve_trace(P, Q, nblk, str(path).encode()))
+    else:
+        agp._lib.check(lib.gp_multi_schedule_trace(P, Q, nblk, depth, comm, str(path).encode()))
 
 
 def load(path):
@@ -76,7 +80,7 @@ def expand(fp, hdr):
                 out.add(("Bb", r, s, lj))
     elif name == "Lkk":
         out.add(("Lkk", r))
-    elif name in ("acc", "alb", "tmp"):
+    elif name in ("acc", "alb", "tmp", "ACC", "X", "Xb", "T", "Vs"):  # (the last five: buffers of the forward solve on the distributed factor)
         for i in range(b0, b1):
             out.add((name, r, i))
     else:
@@ -211,11 +215,11 @@ def check_trace(path):
     return hdr, problems, races(g)
 
 
-def check_config(P, Q, nblk, depth, comm, mutate=None):
+def check_config(P, Q, nblk, depth, comm, mutate=None, solve=False):
     """trace the library's schedule for one configuration and check it; mutate(lines) -> lines edits the trace first (tests)"""
     with tempfile.TemporaryDirectory() as td:
         path = Path(td) / "trace.jsonl"
-        emit_trace(P, Q, nblk, depth, comm, path)
+        emit_trace(P, Q, nblk, depth, comm, path, solve=solve)
         hdr, lines = load(path)
     if mutate:
         lines = mutate(lines)
@@ -244,5 +248,13 @@ if __name__ == "__main__":
                           f"{len(rs)} unordered conflicting pairs, e.g.")
                     for x in (problems + rs)[:6]:
                         print("   ", x)
+    for (P, Q) in GRIDS:   # the forward solve on the distributed factor (predictive variances without the gather)
+        for nblk in (1, 2, 3, 5, 9, 17):
+            problems, rs = check_config(P, Q, nblk, 0, 2, solve=True)
+            if problems or rs:
+                bad += 1
+                print(f"solve grid {P}x{Q} nblk {nblk}: {len(problems)} protocol findings, {len(rs)} unordered conflicting pairs, e.g.")
+                for x in (problems + rs)[:6]:
+                    print("   ", x)
     print("configurations with findings:", bad)
     sys.exit(1 if bad else 0)
