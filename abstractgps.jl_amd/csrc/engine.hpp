@@ -253,6 +253,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
 void multi_trim(gp_ctx* c);  // gp_ctx_trim of every rank context
 int32_t multi_gather(gp_post* post);  // block-cyclic pieces -> one row-major factor on the ctx's first device
 bool multi_can_solve(gp_post* post);  // predictive variances on the distributed factor possible (pieces not gathered, same grid alive)
-int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub);  // Σ_c (K_*x L⁻ᵀ)[s][c]²
+// var_sub[s] = Σ_c X[s][c]², cov_sub (nullable, ns×ns) = X Xᵀ with X = K_*x L⁻ᵀ solved on the block-cyclic pieces
+int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub, double* cov_sub);
 void multi_post_release(gp_post* post);
 int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v);  // 1 = not a multi parameter

@@ -1741,9 +1741,9 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
     if ((what & 4) && !cov_out) return set_arg_err(7, "cov_out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
-    if ((what & 2) && !(what & 4) && multi_can_solve(post)) {
-        // multi-device fit whose factor still lives as block-cyclic pieces: the variances come from a forward solve ON the pieces
-        // (multi.hip: multi_predict_var) — no gather; the mean needs α only
+    if ((what & 6) && multi_can_solve(post) && (!(what & 4) || xs->n <= 4096)) {
+        // multi-device fit whose factor still lives as block-cyclic pieces: variances and (up to 4 096 test points) the full
+        // covariance come from a forward solve ON the pieces (multi.hip: multi_predict_var) — no gather; the mean needs α only
         if (what & 1) RC(predict_impl<double>(post, xs, pm, 1, mean_out, nullptr, nullptr));
         gp_kernel k{};
         k.kind = post->kind; k.dtype = 0; k.variance = post->variance; k.nscale = post->nscale;
@@ -1751,9 +1751,26 @@ int32_t gp_posterior_predict(gp_post* post, const gp_points* xs, const void* pm,
         const long ns = xs->n;
         std::vector<double> xs_h;
         scale_points<double>(&k, xs, ns, xs_h);
-        std::vector<double> sub((size_t)ns, 0.0);
-        RC(multi_predict_var(post, xs_h.data(), ns, ns, sub.data()));
-        for (long i = 0; i < ns; ++i) ((double*)var_out)[i] = post->variance - sub[i];  // k** = σ² for the stationary kernels of the path
+        std::vector<double> sub((size_t)ns, 0.0), csub((what & 4) ? (size_t)ns * ns : 0, 0.0);
+        RC(multi_predict_var(post, xs_h.data(), ns, ns, sub.data(), (what & 4) ? csub.data() : nullptr));
+        if (what & 2)
+            for (long i = 0; i < ns; ++i) ((double*)var_out)[i] = post->variance - sub[i];  // k** = σ² for the stationary kernels of the path
+        if (what & 4) {  // K** on the device (the ctx's own stream), minus X Xᵀ
+            const long nsp = round_up(ns, 128), ldc = nsp + c->ldpad;
+            std::vector<double> xsp((size_t)post->d * nsp, 0.0);
+            for (int dd = 0; dd < post->d; ++dd) memcpy(&xsp[(size_t)dd * nsp], &xs_h[(size_t)dd * ns], sizeof(double) * (size_t)ns);
+            DevBufs bufs(c);
+            void *x_v = nullptr, *C_v = nullptr;
+            RC(bufs.get(sizeof(double) * xsp.size(), &x_v));
+            RC(bufs.get(sizeof(double) * (size_t)nsp * ldc, &C_v));
+            HIPCHK(hipMemcpyAsync(x_v, xsp.data(), sizeof(double) * xsp.size(), hipMemcpyHostToDevice, c->sm));
+            RC(gpmi::eng_kcross(c, c->sm, post->kind, post->variance, (const double*)x_v, nsp, ns, nsp, (const double*)x_v, nsp, ns, nsp, post->d,
+                                (double*)C_v, ldc));
+            double* co = (double*)cov_out;
+            HIPCHK(hipMemcpy2DAsync(co, sizeof(double) * ns, C_v, sizeof(double) * ldc, sizeof(double) * ns, ns, hipMemcpyDeviceToHost, c->sm));
+            HIPCHK(hipStreamSynchronize(c->sm));
+            for (size_t i = 0; i < (size_t)ns * ns; ++i) co[i] -= csub[i];
+        }
         return 0;
     }
     if (what & 6) RC(multi_gather(post));  // multi-device fit: the factor is assembled on this device on first need

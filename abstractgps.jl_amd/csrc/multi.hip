@@ -1041,7 +1041,8 @@ struct SolveDims {
 
 int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const gp_multi_post::Piece* piece, int kind, double variance,
                    const double* x_h /* [d][npad] scaled training inputs */, const double* xs_h /* [d][nsp] scaled test inputs */,
-                   double* vsum_host /* nsp: this rank's partial Σ_c X² */, DevBufs* bufs, long seq) {
+                   double* vsum_host /* nsp: this rank's partial Σ_c X² */, double* cov_host /* nullable: nsp×nsp partial X Xᵀ (lower) */,
+                   DevBufs* bufs, long seq) {
     const int P = M->P, Q = M->Q, p = me->p, q = me->q, R_ = me->r;
     const long NB = sd.NB, nblk = sd.nblk, npad = sd.npad, nsp = sd.nsp, n = sd.n;
     const long nlb_r = nblk / P;
@@ -1063,7 +1064,9 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         c->gemm_recs.clear();
     }
     const long ldacc = nlb_r * NB + 32, ldx = std::max(1L, n_own) * NB + 32, ldb = NB + 32;
-    void *x_v = 0, *xs_v = 0, *acc_v = 0, *xown_v = 0, *xb_v = 0, *t_v = 0, *vs_v = 0, *vt_v = 0;
+    void *x_v = 0, *xs_v = 0, *acc_v = 0, *xown_v = 0, *xb_v = 0, *t_v = 0, *vs_v = 0, *vt_v = 0, *cv_v = 0;
+    const bool want_cov = dry ? true : cov_host != nullptr;
+    const long ldcv = nsp + 32;
     if (!dry) {
         RC(bufs->get(sizeof(double) * (size_t)sd.d * npad, &x_v));
         RC(bufs->get(sizeof(double) * (size_t)sd.d * nsp, &xs_v));
@@ -1073,6 +1076,7 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldb, &t_v));
         RC(bufs->get(sizeof(double) * (size_t)nsp, &vs_v));
         RC(bufs->get(sizeof(double) * (size_t)nsp, &vt_v));
+        if (want_cov) RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldcv, &cv_v));
     }
     me->sacc = (double*)acc_v; me->sacc_ld = ldacc;
     me->sxown = (double*)xown_v; me->sxown_ld = ldx;
@@ -1095,7 +1099,6 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         MCHK(hipMemsetAsync(vs_v, 0, sizeof(double) * (size_t)nsp, sm));
         return 0;
     }));
-    (void)on_diag;
     for (long k = 0; k < nblk; ++k) {
         const int pk = (int)(k % P), qk = (int)(k % Q);
         if (q != qk) continue;  // only the process column of block column k takes part in step k
@@ -1159,8 +1162,19 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         }
         RC(rr.publish(me->sa[k], SM));
     }
+    // full covariance: cov* = K** − X Xᵀ, and X Xᵀ = Σ_k X_k X_kᵀ is a sum over the diagonal owners' blocks — ONE MFMA SYRK per rank
+    // over the solution blocks it owns (lower triangle), summed on the host
+    if (want_cov && on_diag)
+        RC(rr.op(SM, "syrk", 0, 0, {Fp{"X", R_, 0, 0, 0, nblk, 0}}, {Fp{"Cv", R_, 0, 0, 0, 1, 0}}, [&]() -> int32_t {
+            MCHK(hipMemsetAsync(cv_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldcv, sm));
+            return eng_gemm_nt(c, sm, (double*)cv_v, ldcv, me->sxown, ldx, me->sxown, ldx, nsp, nsp, n_own * NB, plain_map(1, 0, 0));
+        }));
     if (dry) return 0;
     MCHK(hipMemcpyAsync(vsum_host, vs_v, sizeof(double) * (size_t)nsp, hipMemcpyDeviceToHost, sm));
+    if (want_cov) {
+        if (on_diag) MCHK(hipMemcpy2DAsync(cov_host, sizeof(double) * nsp, cv_v, sizeof(double) * ldcv, sizeof(double) * nsp, nsp, hipMemcpyDeviceToHost, sm));
+        else memset(cov_host, 0, sizeof(double) * (size_t)nsp * nsp);
+    }
     RC(rr.drain(SM));
     return 0;
 }
@@ -1745,7 +1759,7 @@ extern "C" int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk_in, c
     for (int r = 0; r < M.R; ++r)
         th.emplace_back([&, r]() {
             MRank& rk = M.ranks[r];
-            rk.rc = solve_rank(&M, &rk, sd, true, nullptr, 0, 1.0, nullptr, nullptr, nullptr, nullptr, 1);
+            rk.rc = solve_rank(&M, &rk, sd, true, nullptr, 0, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
             if (rk.rc != 0) {
                 rk.err = gp_last_error();
                 M.abort.store(1);
@@ -1768,7 +1782,7 @@ bool multi_can_solve(gp_post* post) {
 
 // var_sub[s] = Σ_c (K_*x L⁻ᵀ)[s][c]² for the ns test points xs_h (scaled, dimension-major [d][ns_ld]) — the amount the posterior
 // variance lies below the prior variance — on the block-cyclic pieces of the factor.  Called with the main ctx locked.
-int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub) {
+int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub, double* cov_sub) {
     gp_multi_post* mp = post->pieces;
     gp_ctx* c = post->ctx;
     gp_multi* M = c->multi;
@@ -1781,7 +1795,8 @@ int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, lo
     for (int dd = 0; dd < d; ++dd) memcpy(&x_h[(size_t)dd * npad], &x1[(size_t)dd * np], sizeof(double) * (size_t)n);
     RC(size_xevents(M, nblk, false));
     (void)hipSetDevice(c->device);
-    const long CH = 4096;
+    // cov_sub (nullable): ns×ns, (X Xᵀ)[s][t] — all test points in ONE chunk then (the caller bounds ns)
+    const long CH = cov_sub ? std::max(ns, 1L) : 4096;
     for (long s0 = 0; s0 < ns; s0 += CH) {
         const long nsc = std::min(CH, ns - s0), nsp = (nsc + 127) / 128 * 128;
         std::vector<double> xs_h((size_t)d * nsp, 0.0);
@@ -1800,6 +1815,7 @@ int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, lo
         }
         M->tr = tr.f ? &tr : nullptr;
         std::vector<std::vector<double>> part((size_t)R, std::vector<double>((size_t)nsp, 0.0));
+        std::vector<std::vector<double>> cpart((size_t)(cov_sub ? R : 0), std::vector<double>((size_t)nsp * nsp, 0.0));
         std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
         for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
         {
@@ -1809,7 +1825,7 @@ int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, lo
                     MRank& rk = M->ranks[r];
                     std::lock_guard<std::mutex> l(rk.c->mu);
                     rk.rc = solve_rank(M, &rk, sd, false, &mp->pieces[r], post->kind, post->variance, x_h.data(), xs_h.data(), part[r].data(),
-                                       bufs[r].get(), seq);
+                                       cov_sub ? cpart[r].data() : nullptr, bufs[r].get(), seq);
                     if (rk.rc != 0) {
                         rk.err = gp_last_error();
                         M->abort.store(1);
@@ -1835,6 +1851,13 @@ int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, lo
             for (int r = 0; r < R; ++r) acc += part[r][i];
             var_sub[s0 + i] = acc;
         }
+        if (cov_sub)  // lower triangles of the partial products (row-major, row stride nsp) -> the full symmetric ns×ns sum
+            for (long i = 0; i < nsc; ++i)
+                for (long j = 0; j <= i; ++j) {
+                    double acc = 0;
+                    for (int r = 0; r < R; ++r) acc -= cpart[r][(size_t)i * nsp + j];  // (the SYRK kernel computes C −= X Xᵀ from zero)
+                    cov_sub[(size_t)i * ns + j] = cov_sub[(size_t)j * ns + i] = acc;
+                }
         M->solves++;
     }
     return 0;

@@ -182,10 +182,15 @@ def test_predictive_variance_on_the_distributed_factor(agp, P, Q, tmp_path):
         assert ctx.multi_stats()["solves"] == 3
         mm, sd = agp.marginals(post(agp.RowVecs(xs), 0.02))
         np.testing.assert_allclose(sd, np.sqrt(vo + 0.02), atol=1e-9)
-        # the factor is still in pieces; what needs it whole gathers it now, and the variances agree with the gathered path
-        np.testing.assert_allclose(post.cov(agp.RowVecs(xs[:40])), opost.cov(xs[:40]), atol=1e-9)
+        # full covariance and joint mean_and_cov on the pieces as well (one SYRK per rank over the solution blocks it owns)
+        np.testing.assert_allclose(post.cov(agp.RowVecs(xs[:257])), opost.cov(xs[:257]), atol=1e-9)
+        mc, cc = post.mean_and_cov(agp.RowVecs(xs[:40]))
+        np.testing.assert_allclose(cc, opost.cov(xs[:40]), atol=1e-9)
+        assert ctx.multi_stats()["solves"] == 6
+        # what needs the whole factor gathers it now (C.U); the variances of the gathered, single-device path agree
+        assert np.max(np.abs(post.data.C.U - opost.U)) <= 1e-10
         np.testing.assert_allclose(post.var(agp.RowVecs(xs)), vo, atol=1e-9)
-        assert ctx.multi_stats()["solves"] == 4                               # gathered now: single-device path, counter unchanged
+        assert ctx.multi_stats()["solves"] == 6
     finally:
         ctx.close()
 

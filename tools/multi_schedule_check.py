@@ -80,7 +80,7 @@ def expand(fp, hdr):
                 out.add(("Bb", r, s, lj))
     elif name == "Lkk":
         out.add(("Lkk", r))
-    elif name in ("acc", "alb", "tmp", "ACC", "X", "Xb", "T", "Vs"):  # (the last five: buffers of the forward solve on the distributed factor)
+    elif name in ("acc", "alb", "tmp", "ACC", "X", "Xb", "T", "Vs", "Cv"):  # (the last six: buffers of the forward solve on the distributed factor)
         for i in range(b0, b1):
             out.add((name, r, i))
     else:
