@@ -1350,6 +1350,53 @@ static int32_t post_joint(gp_post* post, const gp_points* xs, const void* pm, co
     return 0;
 }
 
+// The same joint for a multi-device posterior whose factor still lives as block-cyclic pieces (fp64): mean from α, V ᵀV from the
+// forward solve ON the pieces (multi.hip: multi_predict_var) — the factor is not gathered.
+static int32_t post_joint_dist(gp_post* post, const gp_points* xs, const void* pm, const gp_noise* noise, long R, DevBufs& bufs,
+                               Joint<double>& J) {
+    gp_ctx* c = post->ctx;
+    const long ns = xs->n, nsp = round_up(ns, 128);
+    const int d = post->d;
+    gp_kernel k{};
+    k.kind = post->kind; k.dtype = 0; k.variance = post->variance; k.nscale = post->nscale;
+    k.scale = post->scale.empty() ? nullptr : post->scale.data();
+    std::vector<double> m_h((size_t)ns), xs_n, xs_p, nz_h;
+    RC(predict_impl<double>(post, xs, pm, 1, m_h.data(), nullptr, nullptr));   // m(x*) + K_*x α (no factor involved)
+    scale_points<double>(&k, xs, ns, xs_n);
+    scale_points<double>(&k, xs, nsp, xs_p);
+    noise_to<double, double>(noise, ns, nsp, nz_h);
+    std::vector<double> sub((size_t)ns), csub((size_t)ns * ns);
+    RC(multi_predict_var(post, xs_n.data(), ns, ns, sub.data(), csub.data()));
+    const long ldc = nsp + c->ldpad;
+    void *xs_v = 0, *nz_v = 0, *W_v = 0;
+    RC(bufs.get(sizeof(double) * (size_t)d * nsp, &xs_v));
+    RC(bufs.get(sizeof(double) * (size_t)nsp, &nz_v));
+    RC(bufs.get(sizeof(double) * (size_t)nsp * ldc, &W_v));
+    RC(bufs.get(sizeof(double) * (size_t)(nsp + R + 128) * ldc, &J.C));
+    J.ns = ns; J.nsp = nsp; J.ld = ldc; J.R = R;
+    double* Cm = (double*)J.C;
+    std::vector<double> W((size_t)nsp * ldc, 0.0);
+    for (long i = 0; i < ns; ++i)
+        for (long j = 0; j < ns; ++j) W[(size_t)i * ldc + j] = -csub[(size_t)i * ns + j];
+    hipStream_t s = c->sm;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(xs_v, xs_p.data(), sizeof(double) * xs_p.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(nz_v, nz_h.data(), sizeof(double) * (size_t)nsp, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(W_v, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice, s));
+    {
+        GridMap g = plain_map(1, 0, 0);
+        dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
+        hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Cm, ldc, (const double*)xs_v, nsp, (const double*)xs_v, nsp, d, post->kind,
+                           post->variance, (const double*)nz_v, ns, ns, 1, g, (const double*)nullptr, (const double*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemsetAsync(Cm + nsp * ldc, 0, sizeof(double) * (size_t)(R + 128) * ldc, s));
+    RC(gpmi::eng_add_vec(c, s, Cm, (const double*)W_v, nsp * ldc));                                           // K** + Σy* − VᵀV
+    HIPCHK(hipStreamSynchronize(s));
+    J.mean.assign(m_h.begin(), m_h.end());
+    return 0;
+}
+
 // logpdf of Y (ns × ncols column-major host, leading dimension ldy) under N(J.mean, J.C): factor J.C in place with δ rows riding along
 template <typename TC, typename TIO>
 static int32_t joint_logpdf(gp_ctx* c, Joint<TC>& J, const void* Yv, long ldy, int ncols, void* outv) {
@@ -2100,13 +2147,14 @@ int32_t gp_posterior_logpdf(gp_post* post, const gp_points* xs, const void* pm, 
     if (!out) return set_arg_err(8, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
-    RC(multi_gather(post));
+    const bool dist = multi_can_solve(post) && xs->n <= 4096;  // held-out logpdf on the block-cyclic pieces: no gather
+    if (!dist) RC(multi_gather(post));
     DevBufs bufs(c);
     const long R = round_up(ncols, 128);
     int32_t rc;
     if (post->dtype == 0) {
         Joint<double> J;
-        rc = post_joint<double>(post, xs, pm, noise, R, bufs, J);
+        rc = dist ? post_joint_dist(post, xs, pm, noise, R, bufs, J) : post_joint<double>(post, xs, pm, noise, R, bufs, J);
         if (rc == 0) rc = joint_logpdf<double, double>(c, J, Y, ldy, ncols, out);
     } else {
         Joint<float> J;
@@ -2127,12 +2175,13 @@ int32_t gp_posterior_rand(gp_post* post, const gp_points* xs, const void* pm, co
     if (!out) return set_arg_err(7, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
-    RC(multi_gather(post));
+    const bool dist = multi_can_solve(post) && xs->n <= 4096;  // posterior sampling on the block-cyclic pieces: no gather
+    if (!dist) RC(multi_gather(post));
     DevBufs bufs(c);
     int32_t rc;
     if (post->dtype == 0) {
         Joint<double> J;
-        rc = post_joint<double>(post, xs, pm, noise, 0, bufs, J);
+        rc = dist ? post_joint_dist(post, xs, pm, noise, 0, bufs, J) : post_joint<double>(post, xs, pm, noise, 0, bufs, J);
         if (rc == 0) rc = joint_rand<double, double>(c, J, bufs, xi, ncols, out);
     } else {
         Joint<float> J;

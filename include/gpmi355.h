@@ -114,8 +114,9 @@ int32_t gp_ctx_multi_info(gp_ctx* ctx, int32_t* P, int32_t* Q, int32_t* nb, int3
 int32_t gp_ctx_multi_stats(gp_ctx* ctx, int64_t* fits, int64_t* retries, int64_t* solves);
 /* Predictive variances — and full covariances for up to 4 096 test points — of a multi-device posterior (gp_posterior_predict) are
  * computed on the distributed factor: a block forward solve with the factor left where the fit put it, N*×nb blocks of the solution
- * travelling, one SYRK per rank for the covariance ("multi_dist_predict", default 1; `solves` above counts them; sequential updates,
- * sampling, held-out logpdf and C.U still gather the factor onto devices[0] first).
+ * travelling, one SYRK per rank for the covariance — and with them gp_posterior_logpdf / gp_posterior_rand for up to 4 096 test points
+ * ("multi_dist_predict", default 1; `solves` above counts them; sequential updates, gp_posterior_factor_mul / _solve and C.U still
+ * gather the factor onto devices[0] first).
  * gp_multi_solve_trace writes that solve's schedule for a P×Q grid (dry run of the real rank threads, like gp_multi_schedule_trace). */
 int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk, const char* path);
 /* The schedule the multi-device driver issues for a P×Q grid over nblk block columns (look-ahead depth 1..3; comm 1 =

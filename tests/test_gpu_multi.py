@@ -187,10 +187,16 @@ def test_predictive_variance_on_the_distributed_factor(agp, P, Q, tmp_path):
         mc, cc = post.mean_and_cov(agp.RowVecs(xs[:40]))
         np.testing.assert_allclose(cc, opost.cov(xs[:40]), atol=1e-9)
         assert ctx.multi_stats()["solves"] == 6
+        # held-out logpdf and posterior sampling (src/finite_gp_projection.jl:306-311, 233-237 over a posterior) on the pieces too
+        ys = rng.standard_normal((60, 2))
+        np.testing.assert_allclose(agp.logpdf(post(agp.RowVecs(xs[:60]), 0.1), ys), o.logpdf(o.FiniteGP(opost, xs[:60], 0.1), ys), rtol=1e-9)
+        xi = rng.standard_normal((60, 3))
+        np.testing.assert_allclose(agp.rand(post(agp.RowVecs(xs[:60]), 0.05), 3, xi=xi), o.rand_from(o.FiniteGP(opost, xs[:60], 0.05), xi), atol=1e-8)
+        assert ctx.multi_stats()["solves"] == 8
         # what needs the whole factor gathers it now (C.U); the variances of the gathered, single-device path agree
         assert np.max(np.abs(post.data.C.U - opost.U)) <= 1e-10
         np.testing.assert_allclose(post.var(agp.RowVecs(xs)), vo, atol=1e-9)
-        assert ctx.multi_stats()["solves"] == 6
+        assert ctx.multi_stats()["solves"] == 8
     finally:
         ctx.close()
 
