@@ -138,7 +138,11 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "trsm_mfma"      all-MFMA blocked TRSM through I − inv(L_jj) tiles                    default 0
  *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
  *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail on launches of <= sk_max_tiles tiles   default 1
- *                    (0 in the rank contexts of a multi-device ctx)
+ *                    (0 in the rank contexts of a multi-device ctx: "multi_gemm_streamk").  The tail adds its k-slices into C with
+ *                    hardware floating-point atomics, so the order of summation depends on scheduling: results agree with the
+ *                    oracle at the stated tolerances but are NOT bitwise reproducible from run to run; 0 removes this source of
+ *                    variation from the factorisation (hardware-dispatched GEMMs only, 1-5 % slower at N <= 32 768; the backward
+ *                    vector sweep still adds four partial products per column with atomics)
  *   "leaf_group"     columns factored left-looking by consecutive fused leaves (64/128/256/512)   default 128
  *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one
