@@ -1046,7 +1046,13 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
     const int P = M->P, Q = M->Q, p = me->p, q = me->q, R_ = me->r;
     const long NB = sd.NB, nblk = sd.nblk, npad = sd.npad, nsp = sd.nsp, n = sd.n;
     const long nlb_r = nblk / P;
-    const long lcm = (long)P * Q / std::__gcd((long)P, (long)Q);
+    long g_ = P, h_ = Q;
+    while (h_) {
+        const long t_ = g_ % h_;
+        g_ = h_;
+        h_ = t_;
+    }
+    const long lcm = (long)P * Q / g_;
     const long n_own = nblk / lcm;  // diagonal blocks of this rank (one per lcm block columns; 0 when (p, q) never meets the diagonal)
     const bool on_diag = [&]() {
         for (long k = 0; k < lcm; ++k)
