@@ -92,6 +92,12 @@ default_context() = something(_default_ctx[], (_default_ctx[] = HipContext(0)))
 set_param!(c::HipContext, name::AbstractString, v::Integer) =
     check(ccall((:gp_ctx_set_param, libgpmi355), Int32, (Ptr{Cvoid}, Cstring, Int64), c.handle, name, v))
 trim!(c::HipContext) = check(ccall((:gp_ctx_trim, libgpmi355), Int32, (Ptr{Cvoid},), c.handle))
+# multi-device contexts: fit attempts, repetitions after a failed self-check, forward solves on the distributed factor
+function multi_stats(c::HipContext)
+    f = Ref{Int64}(0); r = Ref{Int64}(0); s = Ref{Int64}(0)
+    check(ccall((:gp_ctx_multi_stats, libgpmi355), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), c.handle, f, r, s))
+    return (fits=f[], retries=r[], solves=s[])
+end
 
 # ---- the GP wrapper -------------------------------------------------------------------------------
 struct HipGP{Tg<:GP} <: AbstractGP
