@@ -48,6 +48,7 @@ PROTOTYPES = {
     "gp_multi_schedule_trace": (i32, [i32, i32, i32, i32, i32, C.c_char_p]),
     "gp_ctx_multi_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "gp_multi_solve_trace": (i32, [i32, i32, i32, C.c_char_p]),
+    "gp_multi_solve_trace_ex": (i32, [i32, i32, i32, i32, C.c_char_p]),
     "gp_ctx_destroy": (i32, [vp]),
     "gp_ctx_set_param": (i32, [vp, C.c_char_p, i64]),
     "gp_get_timings": (i32, [vp, C.POINTER(gp_timings)]),

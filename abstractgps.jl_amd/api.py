@@ -519,6 +519,15 @@ class _Factor:
         check(self.ctx.lib.gp_posterior_get_factor(self.handle, out.ctypes.data))
         return out
 
+    def solve(self, B) -> np.ndarray:
+        """`C \\ B` by forward + backward sweeps over the resident factor (gp_posterior_solve) — on the block-cyclic pieces when the
+        factor comes from a multi-device fit."""
+        B = np.asarray(B, dtype=self.dtype)
+        D = np.asfortranarray(B.reshape(self.n, -1))
+        out = np.empty_like(D, order="F")
+        check(self.ctx.lib.gp_posterior_solve(self.handle, D.ctypes.data, D.shape[1], out.ctypes.data))
+        return np.ascontiguousarray(out).reshape(B.shape)
+
     def free(self):
         self._fin()
 

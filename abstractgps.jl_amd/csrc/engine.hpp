@@ -255,5 +255,10 @@ int32_t multi_gather(gp_post* post);  // block-cyclic pieces -> one row-major fa
 bool multi_can_solve(gp_post* post);  // predictive variances on the distributed factor possible (pieces not gathered, same grid alive)
 // var_sub[s] = Σ_c X[s][c]², cov_sub (nullable, ns×ns) = X Xᵀ with X = K_*x L⁻ᵀ solved on the block-cyclic pieces
 int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub, double* cov_sub);
+// out = C \ B (n×ncols column-major host arrays) by a forward pass and ncols backward sweeps on the pieces
+int32_t multi_solve(gp_post* post, const double* B, int ncols, double* out);
+// sequential conditioning on the pieces: the factor of `old` extended by new block rows into `post` (-1991: self-check failed)
+int32_t multi_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post* post, void* alpha_out,
+                     double* logpdf_out);
 void multi_post_release(gp_post* post);
 int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v);  // 1 = not a multi parameter

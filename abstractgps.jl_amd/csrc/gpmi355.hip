@@ -1849,6 +1849,23 @@ int32_t gp_posterior_update(gp_post* old, const gp_points* x2, const gp_noise* n
     *out = nullptr;
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    if (old->dtype == 0 && multi_can_solve(old) && x2->n <= 4096) {
+        // multi-device posterior whose factor still lives as block-cyclic pieces: the factor is extended where it lives (multi.hip:
+        // multi_update) — no gather; a failed forward / backward consistency check (-1991) falls back to the gathered path below
+        gp_post* p = new gp_post();
+        double lp = 0;
+        const int32_t rc = multi_update(old, x2, noise2, delta_all, p, alpha_out, &lp);
+        if (rc == 0) {
+            if (logpdf_out) *(double*)logpdf_out = lp;
+            c->refs++;
+            reg_add(p);
+            *out = p;
+            return 0;
+        }
+        delete p;
+        (void)hipSetDevice(c->device);
+        if (rc != -1991) return rc;
+    }
     RC(multi_gather(old));
     gp_post* p = new gp_post();
     double lp = 0;
@@ -1888,6 +1905,7 @@ int32_t gp_posterior_solve(gp_post* post, const void* B, int32_t ncols, void* ou
     if (!out) return set_arg_err(4, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    if (post->dtype == 0 && multi_can_solve(post) && ncols <= 128) return multi_solve(post, (const double*)B, ncols, (double*)out);  // on the pieces
     RC(multi_gather(post));
     return post->dtype == 0 ? solve_impl<double>(post, B, ncols, out) : solve_impl<float>(post, B, ncols, out);
 }

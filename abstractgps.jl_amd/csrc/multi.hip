@@ -176,7 +176,8 @@ struct XEvent : Ev {
 constexpr long RHS_ROWS = 128;
 enum { SM = 0, SP = 1, SC = 2 };
 const char* const SNAME[3] = {"sm", "sp", "sc"};
-const char* const XTAG[6] = {"ready", "lkk", "accr", "alr", "sx", "sa"};
+constexpr int NXKIND = 7;
+const char* const XTAG[NXKIND] = {"ready", "lkk", "accr", "alr", "sx", "sa", "bar"};
 
 // block footprint of an operation (block units; the checker expands it):
 //   A   : rank, local block rows [a0, a1) (fl & 2: plus the RHS block row; fl & 4: the RHS block row only), local block columns
@@ -224,6 +225,7 @@ struct MRank {
     ncclComm_t_ comm = nullptr;
     std::vector<XEvent> ready, lkk, accr, alr;  // per block column k (see fit_rank)
     std::vector<XEvent> sx, sa;                  // forward solve on the distributed factor: X_k published / accumulators after step k
+    std::vector<XEvent> bar;                     // [0]: "everything this rank issued so far" — the barrier between the sweeps of a distributed solve
     std::vector<hipEvent_t> own;                 // own-thread events (arrived / bulk_done / la_done), pooled
     // per-fit state (device pointers owned through DevBufs of the rank thread; shared with peers for the pulls)
     double* A = nullptr;
@@ -237,6 +239,8 @@ struct MRank {
     double* sacc = nullptr;      // forward solve: accumulators −Σ_j X_j L_ijᵀ of this rank's block rows  [nsp][nlb_r·NB + 32]
     double* sxown = nullptr;     // forward solve: the solution blocks X_k this rank owns (diagonal owner)  [nsp][n_own·NB + 32]
     long sacc_ld = 0, sxown_ld = 0;
+    double* A2 = nullptr;        // sequential update: this rank's piece of the EXTENDED factor (new block rows are filled by the forward solve)
+    long ld2 = 0;
     int* flags = nullptr;        // "multi_check": marker flags of this rank's events
     int* log = nullptr;          // "multi_check": findings
     int32_t rc = 0;
@@ -272,6 +276,9 @@ struct gp_multi {
 struct gp_multi_post {
     int P = 1, Q = 1;  // (copied: the posterior may outlive the ctx's gp_multi)
     long n = 0, npad = 0, nblk = 0, nb = 0;
+    // real points per block (a prefix of the block; the rest is identity padding): after a fit only the tail of the LAST blocks is
+    // padding, after a sequential update on the pieces every batch of observations ends in its own padded blocks
+    std::vector<long> valid;
     struct Piece {
         gp_ctx* c;
         void* A;
@@ -314,7 +321,7 @@ struct RankRun {
         out->owner = me->r;
         out->tag = tag;
         out->k = k;
-        out->id = (int)(6 * dm.nblk + (long)own_used);
+        out->id = (int)(NXKIND * dm.nblk + (long)own_used);
         if (dry) {
             ++own_used;
             out->ev = nullptr;
@@ -498,7 +505,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     void* St_v[4] = {0, 0, 0, 0};
     const size_t A_b = sizeof(double) * (size_t)(m_loc + 128) * ld;
     const long own_cap = 10 * nblk + 64;
-    rr.nflags = 6 * nblk + own_cap;
+    rr.nflags = NXKIND * nblk + own_cap;
     if (!dry) {
         RC(bufs->get(A_b, &A_v));
         RC(bufs->get(sizeof(double) * (size_t)dm.d * npad, &xs_v));
@@ -999,7 +1006,7 @@ int32_t size_xevents(gp_multi* M, long nblk, bool dry) {
     for (auto& rk : M->ranks) {
         if (!dry) (void)hipSetDevice(rk.device);
         int kind = 0;
-        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa}) {
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa, &rk.bar}) {
             if ((long)v->size() < nblk) {
                 std::vector<XEvent> nv((size_t)nblk);
                 for (size_t i = 0; i < v->size(); ++i) {
@@ -1037,15 +1044,22 @@ int32_t size_xevents(gp_multi* M, long nblk, bool dry) {
 struct SolveDims {
     long n, npad, nblk, NB, ns, nsp;
     int d;
+    const long* valid = nullptr;  // real points per block (nullptr: the first n points are real)
+    bool rhs = false;             // the right-hand sides are GIVEN (rhs_h: nsp × npad, row-major, padded column layout) instead of K(x*, x)
+    long sink_nb2 = 0;            // > 0: rows [t·NB, (t+1)·NB) of every X_k also go to block row nblk + t of the rank's NEW piece (MRank::A2)
+    int nbwd = 0;                 // > 0: backward sweeps Z_s = X_s L⁻¹ for the first nbwd rows (one vector sweep each) after the forward pass
+    long seq_bwd0 = 0;            // generations of the backward sweeps: seq_bwd0 + 2 s for the barrier before sweep s, + 1 for its events
 };
 
+// Rows of X = B L⁻ᵀ on the block-cyclic pieces (B = K(x*, x) or given rows), optionally followed by Z = X L⁻¹ row by row.
 int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const gp_multi_post::Piece* piece, int kind, double variance,
                    const double* x_h /* [d][npad] scaled training inputs */, const double* xs_h /* [d][nsp] scaled test inputs */,
-                   double* vsum_host /* nsp: this rank's partial Σ_c X² */, double* cov_host /* nullable: nsp×nsp partial X Xᵀ (lower) */,
+                   const double* rhs_h /* sd.rhs: nsp × npad */, double* vsum_host /* nsp: this rank's partial Σ_c X² */,
+                   double* cov_host /* nullable: nsp×nsp partial X Xᵀ (lower) */, double* z_host /* sd.nbwd × npad: Z rows (diagonal owners write their blocks) */,
                    DevBufs* bufs, long seq) {
     const int P = M->P, Q = M->Q, p = me->p, q = me->q, R_ = me->r;
     const long NB = sd.NB, nblk = sd.nblk, npad = sd.npad, nsp = sd.nsp, n = sd.n;
-    const long nlb_r = nblk / P;
+    const long nlb_r = nblk / P, nlb_c = nblk / Q;
     long g_ = P, h_ = Q;
     while (h_) {
         const long t_ = g_ % h_;
@@ -1059,7 +1073,7 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
             if (k % P == p && k % Q == q) return true;
         return false;
     }();
-    Dims dm{n, npad, nblk, NB, nlb_r, nblk / Q, NB + 32, sd.d};
+    Dims dm{n, npad, nblk, NB, nlb_r, nlb_c, NB + 32, sd.d};
     RankRun rr{M, me, dm, seq, dry, 0, M->tr};
     gp_ctx* c = me->c;
     hipStream_t sm = nullptr;
@@ -1070,12 +1084,16 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         c->gemm_recs.clear();
     }
     const long ldacc = nlb_r * NB + 32, ldx = std::max(1L, n_own) * NB + 32, ldb = NB + 32;
-    void *x_v = 0, *xs_v = 0, *acc_v = 0, *xown_v = 0, *xb_v = 0, *t_v = 0, *vs_v = 0, *vt_v = 0, *cv_v = 0;
-    const bool want_cov = dry ? true : cov_host != nullptr;
+    void *x_v = 0, *xs_v = 0, *acc_v = 0, *xown_v = 0, *xb_v = 0, *t_v = 0, *vs_v = 0, *vt_v = 0, *cv_v = 0, *rhs_v = 0, *bacc_v = 0, *alb_v = 0, *tmp_v = 0;
+    const bool want_cov = dry ? !sd.rhs : cov_host != nullptr;
     const long ldcv = nsp + 32;
     if (!dry) {
-        RC(bufs->get(sizeof(double) * (size_t)sd.d * npad, &x_v));
-        RC(bufs->get(sizeof(double) * (size_t)sd.d * nsp, &xs_v));
+        if (!sd.rhs) {
+            RC(bufs->get(sizeof(double) * (size_t)sd.d * npad, &x_v));
+            RC(bufs->get(sizeof(double) * (size_t)sd.d * nsp, &xs_v));
+        } else if (on_diag) {
+            RC(bufs->get(sizeof(double) * (size_t)nsp * npad, &rhs_v));
+        }
         RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldacc, &acc_v));
         RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldx, &xown_v));
         RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldb, &xb_v));
@@ -1083,9 +1101,16 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         RC(bufs->get(sizeof(double) * (size_t)nsp, &vs_v));
         RC(bufs->get(sizeof(double) * (size_t)nsp, &vt_v));
         if (want_cov) RC(bufs->get(sizeof(double) * (size_t)(nsp + 128) * ldcv, &cv_v));
+        if (sd.nbwd > 0) {
+            RC(bufs->get(sizeof(double) * (size_t)(nlb_c * NB + 128), &bacc_v));
+            RC(bufs->get(sizeof(double) * (size_t)npad, &alb_v));
+            RC(bufs->get(sizeof(double) * (size_t)NB * (P + 1), &tmp_v));
+        }
     }
     me->sacc = (double*)acc_v; me->sacc_ld = ldacc;
     me->sxown = (double*)xown_v; me->sxown_ld = ldx;
+    me->acc = (double*)bacc_v;
+    me->alpha_blk = (double*)alb_v;
     const double* A = piece ? (const double*)piece->A : nullptr;
     const long ld = piece ? piece->ld : 0;
     auto rank_of = [&](int pp, int qq) -> MRank& { return M->ranks[(size_t)pp * Q + qq]; };
@@ -1094,10 +1119,12 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
         MCHK(hipGetLastError());
         return 0;
     };
+    auto valid_of = [&](long k) -> long { return sd.valid ? sd.valid[k] : std::max(0L, std::min(NB, n - k * NB)); };
 
     RC(rr.op(SM, "solve_init", 0, 0, {}, {Fp{"ACC", R_, 0, 0, 0, nlb_r, 0}, Fp{"Vs", R_, 0, 0, 0, 1, 0}}, [&]() -> int32_t {
-        MCHK(hipMemcpyAsync(x_v, x_h, sizeof(double) * (size_t)sd.d * npad, hipMemcpyHostToDevice, sm));
-        MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)sd.d * nsp, hipMemcpyHostToDevice, sm));
+        if (x_v) MCHK(hipMemcpyAsync(x_v, x_h, sizeof(double) * (size_t)sd.d * npad, hipMemcpyHostToDevice, sm));
+        if (xs_v) MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)sd.d * nsp, hipMemcpyHostToDevice, sm));
+        if (rhs_v) MCHK(hipMemcpyAsync(rhs_v, rhs_h, sizeof(double) * (size_t)nsp * npad, hipMemcpyHostToDevice, sm));
         MCHK(hipMemsetAsync(acc_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldacc, sm));
         MCHK(hipMemsetAsync(xown_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldx, sm));
         MCHK(hipMemsetAsync(xb_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldb, sm));
@@ -1116,10 +1143,17 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
             double* Xk = me->sxown ? me->sxown + ko * NB : nullptr;
             const Fp fX = Fp{"X", R_, 0, 0, k, k + 1, 0};
             const Fp fAcc = Fp{"ACC", R_, 0, 0, li, li + 1, 0};
-            RC(rr.op(SM, "kstar", k, 0, {}, {fX}, [&]() {
-                return eng_kcross(c, sm, kind, variance, (const double*)xs_v, nsp, sd.ns, nsp, (const double*)x_v + k * NB, npad,
-                                  std::max(0L, std::min(NB, n - k * NB)), NB, sd.d, Xk, ldx);
-            }));
+            if (sd.rhs)
+                RC(rr.op(SM, "rhs", k, 0, {}, {fX}, [&]() -> int32_t {
+                    MCHK(hipMemcpy2DAsync(Xk, sizeof(double) * ldx, (const double*)rhs_v + k * NB, sizeof(double) * npad, sizeof(double) * NB, nsp,
+                                          hipMemcpyDeviceToDevice, sm));
+                    return 0;
+                }));
+            else
+                RC(rr.op(SM, "kstar", k, 0, {}, {fX}, [&]() {
+                    return eng_kcross(c, sm, kind, variance, (const double*)xs_v, nsp, sd.ns, nsp, (const double*)x_v + k * NB, npad, valid_of(k), NB, sd.d, Xk,
+                                      ldx);
+                }));
             RC(rr.op(SM, "add_own", k, 0, {fAcc, fX}, {fX}, [&]() { return addmat(Xk, ldx, me->sacc + li * NB, ldacc, nsp, NB); }));
             for (int qq = 0; qq < Q; ++qq) {  // + the partial sums of the other ranks of my process row (their columns j < k, j ≡ qq mod Q)
                 if (qq == qk) continue;
@@ -1157,6 +1191,18 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
             xk_ld = ldb;
             f_xk = fB;
         }
+        // sequential update: the rows of X_k that form block (nblk + t, k) of the extended factor stay on this rank's new piece
+        for (long t = 0; t < sd.sink_nb2; ++t) {
+            const long I = nblk + t;
+            if ((int)(I % P) != p) continue;
+            const long rows = std::min(NB, nsp - t * NB);
+            if (rows <= 0) continue;
+            RC(rr.op(SM, "sink", k, t, {f_xk}, {Fp{"A2", R_, I / P, I / P + 1, lc, lc + 1, 0}}, [&]() -> int32_t {
+                MCHK(hipMemcpy2DAsync(me->A2 + (I / P) * NB * me->ld2 + lc * NB, sizeof(double) * me->ld2, xk + t * NB * xk_ld, sizeof(double) * xk_ld,
+                                      sizeof(double) * NB, rows, hipMemcpyDeviceToDevice, sm));
+                return 0;
+            }));
+        }
         // accumulators of my block rows below k:  ACC[:, rows i > k] −= X_k · L[rows i > k, block column k]ᵀ
         const long lr0 = nlb_before(k, p, P);  // first local block row with global block > k
         if (lr0 < nlb_r) {
@@ -1175,13 +1221,83 @@ int32_t solve_rank(gp_multi* M, MRank* me, const SolveDims& sd, bool dry, const 
             MCHK(hipMemsetAsync(cv_v, 0, sizeof(double) * (size_t)(nsp + 128) * ldcv, sm));
             return eng_gemm_nt(c, sm, (double*)cv_v, ldcv, me->sxown, ldx, me->sxown, ldx, nsp, nsp, n_own * NB, plain_map(1, 0, 0));
         }));
+
+    // ---- backward sweeps  Z_s = X_s L⁻¹  (row s of the forward result as the right-hand side; one vector sweep per row, the block
+    // sweep of fit_rank: partial sums per local column, reduced over the process rows by the diagonal owner).  Between two sweeps
+    // every rank waits for every other rank's stream ("bar"): the partial sums and solution blocks of sweep s are pulled by peers.
+    for (int s = 0; s < sd.nbwd; ++s) {
+        double* acc = me->acc;
+        double* tmp = (double*)tmp_v;
+        if (s > 0 && M->R > 1) {  // (two events in turn: a rank may reach the next barrier before a slow peer has issued its wait for this one)
+            rr.seq = sd.seq_bwd0 + 2 * s;
+            RC(rr.publish(me->bar[s & 1], SM));
+            for (int r2 = 0; r2 < M->R; ++r2)
+                if (r2 != R_) RC(rr.await(M->ranks[(size_t)r2].bar[s & 1], SM));
+        }
+        rr.seq = sd.seq_bwd0 + 2 * s + 1;
+        RC(rr.op(SM, "bwd_init", s, 0, {}, {Fp{"acc", R_, 0, 0, 0, nlb_c, 0}}, [&]() -> int32_t {
+            MCHK(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)(nlb_c * NB + 128), sm));
+            return 0;
+        }));
+        for (long k = nblk - 1; k >= 0; --k) {
+            const int pk = (int)(k % P), qk = (int)(k % Q);
+            const long c0 = (k / Q) * NB, lc = k / Q, ko = k / lcm;
+            const Fp f_acc = Fp{"acc", R_, 0, 0, lc, lc + 1, 0};
+            const Fp f_alb = Fp{"alb", R_, 0, 0, k, k + 1, 0};
+            if (q == qk) {
+                if (p == pk) {
+                    double* ak = me->alpha_blk ? me->alpha_blk + k * NB : nullptr;
+                    RC(rr.op(SM, "ak", k, s, {f_acc, Fp{"X", R_, 0, 0, k, k + 1, 0}}, {f_alb}, [&]() -> int32_t {
+                        MCHK(hipMemcpyAsync(ak, acc + c0, sizeof(double) * NB, hipMemcpyDeviceToDevice, sm));
+                        return eng_add_vec(c, sm, ak, me->sxown + ko * NB + (long)s * ldx, NB);  // + row s of X_k
+                    }));
+                    for (int pp = 0; pp < P; ++pp) {  // + the partial sums of the other process rows
+                        if (pp == pk) continue;
+                        MRank& src = rank_of(pp, qk);
+                        const Fp f_tmp = Fp{"tmp", R_, 0, 0, pp, pp + 1, 0};
+                        RC(rr.await(src.accr[k], SM));
+                        RC(rr.op(SM, "pull_acc", k, pp, {Fp{"acc", src.r, 0, 0, lc, lc + 1, 0}}, {f_tmp}, [&]() { return rr.pull(SM, tmp + (size_t)pp * NB, NB, src.acc + c0, NB, 1, NB); }));
+                        RC(rr.op(SM, "add_acc", k, pp, {f_tmp, f_alb}, {f_alb}, [&]() { return eng_add_vec(c, sm, ak, tmp + (size_t)pp * NB, NB); }));
+                    }
+                    RC(rr.op(SM, "trsv", k, s, {Fp{"A", R_, k / P, k / P + 1, lc, lc + 1, 0}, f_alb}, {f_alb}, [&]() -> int32_t {
+                        RC(eng_trsv(c, sm, A + (k / P) * NB * ld + c0, ld, NB, ak, NB, 1, false));
+                        MCHK(hipMemcpyAsync(z_host + (size_t)s * npad + k * NB, ak, sizeof(double) * NB, hipMemcpyDeviceToHost, sm));
+                        return 0;
+                    }));
+                    RC(rr.publish(me->alr[k], SM));
+                } else {
+                    RC(rr.publish(me->accr[k], SM));
+                }
+            }
+            if (p == pk && k > 0) {  // my block row k: acc_j −= L[k][j]ᵀ z_k for my local columns j < k
+                const long ncb = nlb_before(k - 1, q, Q);
+                if (ncb > 0) {
+                    const double* ak;
+                    Fp f_ak = f_alb;
+                    if (q == qk) {
+                        ak = me->alpha_blk ? me->alpha_blk + k * NB : nullptr;
+                    } else {
+                        MRank& own = rank_of(pk, qk);
+                        double* dst = tmp + (size_t)P * NB;
+                        f_ak = Fp{"tmp", R_, 0, 0, P, P + 1, 0};
+                        RC(rr.await(own.alr[k], SM));
+                        RC(rr.op(SM, "pull_alpha", k, 0, {Fp{"alb", own.r, 0, 0, k, k + 1, 0}}, {f_ak}, [&]() { return rr.pull(SM, dst, NB, own.alpha_blk + k * NB, NB, 1, NB); }));
+                        ak = dst;
+                    }
+                    const Fp f_accs = Fp{"acc", R_, 0, 0, 0, ncb, 0};
+                    RC(rr.op(SM, "gemv", k, s, {Fp{"A", R_, k / P, k / P + 1, 0, ncb, 0}, f_ak, f_accs}, {f_accs},
+                             [&]() { return eng_gemv_t(c, sm, A + (k / P) * NB * ld, ld, NB, ncb * NB, ak, acc); }));
+                }
+            }
+        }
+    }
     if (dry) return 0;
     MCHK(hipMemcpyAsync(vsum_host, vs_v, sizeof(double) * (size_t)nsp, hipMemcpyDeviceToHost, sm));
-    if (want_cov) {
+    if (cov_host) {
         if (on_diag) MCHK(hipMemcpy2DAsync(cov_host, sizeof(double) * nsp, cv_v, sizeof(double) * ldcv, sizeof(double) * nsp, nsp, hipMemcpyDeviceToHost, sm));
         else memset(cov_host, 0, sizeof(double) * (size_t)nsp * nsp);
     }
-    RC(rr.drain(SM));
+    RC(rr.drain(SM));  // (the caller releases the buffers after EVERY rank thread has drained its stream: peers' pulls included)
     return 0;
 }
 
@@ -1195,7 +1311,7 @@ void multi_destroy(gp_multi* m) {
     for (auto& rk : m->ranks) {
         (void)hipSetDevice(rk.device);
         if (rk.comm && g_rccl.ok) (void)g_rccl.CommDestroy(rk.comm);
-        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa})
+        for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa, &rk.bar})
             for (auto& x : *v)
                 if (x.ev) (void)hipEventDestroy(x.ev);
         for (auto e : rk.own) (void)hipEventDestroy(e);
@@ -1425,7 +1541,10 @@ extern "C" int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk_in
         MRank& rk = M.ranks[r];
         rk.r = r; rk.p = r / Q; rk.q = r % Q;
     }
-    RC(size_xevents(&M, nblk, true));
+    if (const int32_t erc = size_xevents(&M, nblk, true)) {
+        fclose(tr.f);
+        return erc;
+    }
     {
         char b[160];
         snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"dry\":1}", P, Q, nblk, depth, comm);
@@ -1710,6 +1829,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         }
         gp_multi_post* mp = new gp_multi_post();
         mp->P = P; mp->Q = Q; mp->n = n; mp->npad = npad; mp->nblk = nblk; mp->nb = NB;
+        for (long kb = 0; kb < nblk; ++kb) mp->valid.push_back(std::max(0L, std::min(NB, n - kb * NB)));
         for (int r = 0; r < R; ++r) {
             MRank& rk = M->ranks[r];
             mp->pieces.push_back({rk.c, rk.A, rk.ld, rk.m_loc, rk.n_loc});
@@ -1737,14 +1857,16 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
     return 0;
 }
 
-// The forward-solve schedule for a P×Q grid over nblk block columns, traced without a device (see gp_multi_schedule_trace).
-extern "C" int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk_in, const char* path) {
+// The schedule of a solve on the distributed factor for a P×Q grid over nblk block columns, traced without a device (see
+// gp_multi_schedule_trace).  flags: 1 = given right-hand sides (instead of K(x*, x)), 2 = the rows also go to the new block rows of an
+// extended factor (sequential update; lcm(P, Q) new block rows), 4 = two backward sweeps after the forward pass (gp_posterior_solve).
+extern "C" int32_t gp_multi_solve_trace_ex(int32_t P, int32_t Q, int32_t nblk_in, int32_t flags, const char* path) {
     if (P < 1 || Q < 1 || P * Q > 64) return set_arg_err(1, "P, Q");
     if (nblk_in < 1 || nblk_in > 4096) return set_arg_err(3, "nblk");
-    if (!path) return set_arg_err(4, "path is NULL");
+    if (!path) return set_arg_err(5, "path is NULL");
     Trace tr;
     tr.f = fopen(path, "w");
-    if (!tr.f) return set_arg_err(4, "cannot open the trace file");
+    if (!tr.f) return set_arg_err(5, "cannot open the trace file");
     gp_multi M;
     M.P = P; M.Q = Q; M.R = P * Q; M.nb = 128; M.comm = 2; M.tr = &tr; M.timeout_s = 60;
     const long lcm = lcm_of(P, Q);
@@ -1754,37 +1876,139 @@ extern "C" int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk_in, c
         MRank& rk = M.ranks[r];
         rk.r = r; rk.p = r / Q; rk.q = r % Q;
     }
-    RC(size_xevents(&M, nblk, true));
-    {
-        char b[160];
-        snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":0,\"comm\":2,\"dry\":1,\"mode\":\"solve\"}", P, Q, nblk);
+    int32_t rc = size_xevents(&M, nblk, true);
+    if (rc == 0) {
+        char b[200];
+        snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":0,\"comm\":2,\"dry\":1,\"mode\":\"solve\",\"flags\":%d}", P, Q, nblk, flags);
         tr.line(b);
+        SolveDims sd{nblk * 128, nblk * 128, nblk, 128, 128, (flags & 2) ? lcm * 128 : 128, 1};
+        sd.rhs = (flags & 1) != 0;
+        sd.sink_nb2 = (flags & 2) ? lcm : 0;
+        sd.nbwd = (flags & 4) ? 2 : 0;
+        sd.seq_bwd0 = 2;
+        std::vector<std::thread> th;
+        for (int r = 0; r < M.R; ++r)
+            th.emplace_back([&, r]() {
+                MRank& rk = M.ranks[r];
+                rk.rc = solve_rank(&M, &rk, sd, true, nullptr, 0, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
+                if (rk.rc != 0) {
+                    rk.err = gp_last_error();
+                    M.abort.store(1);
+                }
+            });
+        for (auto& t : th) t.join();
     }
-    SolveDims sd{nblk * 128, nblk * 128, nblk, 128, 128, 128, 1};
-    std::vector<std::thread> th;
-    for (int r = 0; r < M.R; ++r)
-        th.emplace_back([&, r]() {
-            MRank& rk = M.ranks[r];
-            rk.rc = solve_rank(&M, &rk, sd, true, nullptr, 0, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
-            if (rk.rc != 0) {
-                rk.err = gp_last_error();
-                M.abort.store(1);
-            }
-        });
-    for (auto& t : th) t.join();
     fclose(tr.f);
     tr.f = nullptr;
+    if (rc != 0) return rc;
     for (int r = 0; r < M.R; ++r)
         if (M.ranks[r].rc != 0 && M.ranks[r].rc != -1999) return set_err_text(M.ranks[r].rc, "rank " + std::to_string(r) + ": " + M.ranks[r].err);
     return 0;
 }
+extern "C" int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk_in, const char* path) { return gp_multi_solve_trace_ex(P, Q, nblk_in, 0, path); }
 
-// can the predictive variance of this posterior be computed on the distributed factor?
+// can this posterior be worked on where the fit left it (block-cyclic pieces, same grid still alive)?
 bool multi_can_solve(gp_post* post) {
     gp_multi_post* mp = post->pieces;
     gp_multi* M = post->ctx ? post->ctx->multi : nullptr;
     return mp && M && M->dist_predict && M->P == mp->P && M->Q == mp->Q && (int)mp->pieces.size() == M->R && post->dtype == 0;
 }
+
+namespace {
+// compact index of the first real point of every block (off[nblk] = number of real points)
+std::vector<long> block_offsets(const std::vector<long>& valid) {
+    std::vector<long> off(valid.size() + 1, 0);
+    for (size_t k = 0; k < valid.size(); ++k) off[k + 1] = off[k] + valid[k];
+    return off;
+}
+// compact [rows][ldc] (real points only) -> padded block layout [rows][npad]
+void to_padded(const double* comp, long ldc, long rows, const std::vector<long>& valid, long NB, double* pad, long npad) {
+    const std::vector<long> off = block_offsets(valid);
+    for (long r = 0; r < rows; ++r)
+        for (size_t k = 0; k < valid.size(); ++k)
+            if (valid[k] > 0) memcpy(pad + (size_t)r * npad + k * NB, comp + (size_t)r * ldc + off[k], sizeof(double) * (size_t)valid[k]);
+}
+void to_compact(const double* pad, long npad, long rows, const std::vector<long>& valid, long NB, double* comp, long ldc) {
+    const std::vector<long> off = block_offsets(valid);
+    for (long r = 0; r < rows; ++r)
+        for (size_t k = 0; k < valid.size(); ++k)
+            if (valid[k] > 0) memcpy(comp + (size_t)r * ldc + off[k], pad + (size_t)r * npad + k * NB, sizeof(double) * (size_t)valid[k]);
+}
+
+// One solve_rank pass over all ranks (one host thread each): generations, trace file, error collection, buffers back to the caches.
+// part[r]: rank r's partial Σ_c X² per row; cpart[r] (want_cov): its partial X Xᵀ; z_host (sd.nbwd rows of npad): backward results.
+int32_t run_solve(gp_ctx* c, SolveDims sd, const std::vector<gp_multi_post::Piece>& pieces, int kind, double variance, const double* x_h,
+                  const double* xs_h, const double* rhs_h, bool want_cov, double* z_host, std::vector<std::vector<double>>& part,
+                  std::vector<std::vector<double>>& cpart) {
+    gp_multi* M = c->multi;
+    const int R = M->R;
+    RC(size_xevents(M, sd.nblk, false));
+    (void)hipSetDevice(c->device);
+    const long seq = ++M->seq;
+    sd.seq_bwd0 = M->seq + 1;
+    M->seq += 2 * (long)sd.nbwd + 2;
+    M->abort.store(0);
+    Trace tr;
+    if (const char* tp = getenv("GPMI_TRACE_SCHEDULE")) {
+        tr.f = fopen(tp, "w");
+        if (tr.f) {
+            char b[200];
+            snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":0,\"comm\":2,\"dry\":0,\"mode\":\"solve\",\"flags\":%d}", M->P, M->Q, sd.nblk,
+                     (sd.rhs ? 1 : 0) | (sd.sink_nb2 ? 2 : 0) | (sd.nbwd ? 4 : 0));
+            tr.line(b);
+        }
+    }
+    M->tr = tr.f ? &tr : nullptr;
+    part.assign((size_t)R, std::vector<double>((size_t)sd.nsp, 0.0));
+    cpart.assign((size_t)(want_cov ? R : 0), std::vector<double>((size_t)sd.nsp * sd.nsp, 0.0));
+    std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
+    for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < R; ++r)
+            th.emplace_back([&, r]() {
+                MRank& rk = M->ranks[r];
+                std::lock_guard<std::mutex> l(rk.c->mu);
+                rk.rc = solve_rank(M, &rk, sd, false, &pieces[r], kind, variance, x_h, xs_h, rhs_h, part[r].data(), want_cov ? cpart[r].data() : nullptr,
+                                   z_host, bufs[r].get(), seq);
+                if (rk.rc != 0) {
+                    rk.err = gp_last_error();
+                    M->abort.store(1);
+                    if (rk.rc != -1992) (void)hipStreamSynchronize(rk.c->sm);
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    M->tr = nullptr;
+    if (tr.f) fclose(tr.f);
+    for (int r = 0; r < R; ++r) {
+        std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
+        (void)hipSetDevice(M->ranks[r].device);
+        bufs[r].reset();
+    }
+    (void)hipSetDevice(c->device);
+    for (int r = 0; r < R; ++r)
+        if (M->ranks[r].rc != 0 && M->ranks[r].rc != -1999) return set_err_text(M->ranks[r].rc, "rank " + std::to_string(r) + ": " + M->ranks[r].err);
+    for (int r = 0; r < R; ++r)
+        if (M->ranks[r].rc != 0) return set_err_text(M->ranks[r].rc, M->ranks[r].err);
+    M->solves++;
+    return 0;
+}
+
+// scaled training inputs of a posterior in the padded block layout of its pieces: [d][npad]
+int32_t padded_inputs(gp_post* post, std::vector<double>& x_h) {
+    gp_multi_post* mp = post->pieces;
+    gp_ctx* c = post->ctx;
+    const int d = post->d;
+    const long np = post->np;
+    std::vector<double> x1((size_t)d * np);
+    MCHK(hipSetDevice(c->device));
+    MCHK(hipMemcpy(x1.data(), post->xs, sizeof(double) * x1.size(), hipMemcpyDeviceToHost));
+    x_h.assign((size_t)d * mp->npad, 0.0);
+    to_padded(x1.data(), np, d, mp->valid, mp->nb, x_h.data(), mp->npad);
+    return 0;
+}
+}  // namespace
 
 // var_sub[s] = Σ_c (K_*x L⁻ᵀ)[s][c]² for the ns test points xs_h (scaled, dimension-major [d][ns_ld]) — the amount the posterior
 // variance lies below the prior variance — on the block-cyclic pieces of the factor.  Called with the main ctx locked.
@@ -1793,65 +2017,18 @@ int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, lo
     gp_ctx* c = post->ctx;
     gp_multi* M = c->multi;
     const int R = M->R, d = post->d;
-    const long n = mp->n, npad = mp->npad, nblk = mp->nblk, NB = mp->nb, np = post->np;
-    // scaled training inputs: device 0 holds them as [d][np]; every rank gets [d][npad]
-    std::vector<double> x1((size_t)d * np), x_h((size_t)d * npad, 0.0);
-    MCHK(hipSetDevice(c->device));
-    MCHK(hipMemcpy(x1.data(), post->xs, sizeof(double) * x1.size(), hipMemcpyDeviceToHost));
-    for (int dd = 0; dd < d; ++dd) memcpy(&x_h[(size_t)dd * npad], &x1[(size_t)dd * np], sizeof(double) * (size_t)n);
-    RC(size_xevents(M, nblk, false));
-    (void)hipSetDevice(c->device);
+    std::vector<double> x_h;
+    RC(padded_inputs(post, x_h));
     // cov_sub (nullable): ns×ns, (X Xᵀ)[s][t] — all test points in ONE chunk then (the caller bounds ns)
     const long CH = cov_sub ? std::max(ns, 1L) : 4096;
     for (long s0 = 0; s0 < ns; s0 += CH) {
         const long nsc = std::min(CH, ns - s0), nsp = (nsc + 127) / 128 * 128;
         std::vector<double> xs_h((size_t)d * nsp, 0.0);
         for (int dd = 0; dd < d; ++dd) memcpy(&xs_h[(size_t)dd * nsp], xs_scaled + (size_t)dd * ns_ld + s0, sizeof(double) * (size_t)nsc);
-        SolveDims sd{n, npad, nblk, NB, nsc, nsp, d};
-        const long seq = ++M->seq;
-        M->abort.store(0);
-        Trace tr;
-        if (const char* tp = getenv("GPMI_TRACE_SCHEDULE")) {
-            tr.f = fopen(tp, "w");
-            if (tr.f) {
-                char b[160];
-                snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":0,\"comm\":2,\"dry\":0,\"mode\":\"solve\"}", M->P, M->Q, nblk);
-                tr.line(b);
-            }
-        }
-        M->tr = tr.f ? &tr : nullptr;
-        std::vector<std::vector<double>> part((size_t)R, std::vector<double>((size_t)nsp, 0.0));
-        std::vector<std::vector<double>> cpart((size_t)(cov_sub ? R : 0), std::vector<double>((size_t)nsp * nsp, 0.0));
-        std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
-        for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
-        {
-            std::vector<std::thread> th;
-            for (int r = 0; r < R; ++r)
-                th.emplace_back([&, r]() {
-                    MRank& rk = M->ranks[r];
-                    std::lock_guard<std::mutex> l(rk.c->mu);
-                    rk.rc = solve_rank(M, &rk, sd, false, &mp->pieces[r], post->kind, post->variance, x_h.data(), xs_h.data(), part[r].data(),
-                                       cov_sub ? cpart[r].data() : nullptr, bufs[r].get(), seq);
-                    if (rk.rc != 0) {
-                        rk.err = gp_last_error();
-                        M->abort.store(1);
-                        if (rk.rc != -1992) (void)hipStreamSynchronize(rk.c->sm);
-                    }
-                });
-            for (auto& t : th) t.join();
-        }
-        M->tr = nullptr;
-        if (tr.f) fclose(tr.f);
-        for (int r = 0; r < R; ++r) {
-            std::lock_guard<std::mutex> l(M->ranks[r].c->mu);
-            (void)hipSetDevice(M->ranks[r].device);
-            bufs[r].reset();
-        }
-        (void)hipSetDevice(c->device);
-        for (int r = 0; r < R; ++r)
-            if (M->ranks[r].rc != 0 && M->ranks[r].rc != -1999) return set_err_text(M->ranks[r].rc, "rank " + std::to_string(r) + ": " + M->ranks[r].err);
-        for (int r = 0; r < R; ++r)
-            if (M->ranks[r].rc != 0) return set_err_text(M->ranks[r].rc, M->ranks[r].err);
+        SolveDims sd{mp->n, mp->npad, mp->nblk, mp->nb, nsc, nsp, d};
+        sd.valid = mp->valid.data();
+        std::vector<std::vector<double>> part, cpart;
+        RC(run_solve(c, sd, mp->pieces, post->kind, post->variance, x_h.data(), xs_h.data(), nullptr, cov_sub != nullptr, nullptr, part, cpart));
         for (long i = 0; i < nsc; ++i) {
             double acc = 0;
             for (int r = 0; r < R; ++r) acc += part[r][i];
@@ -1864,8 +2041,228 @@ int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, lo
                     for (int r = 0; r < R; ++r) acc -= cpart[r][(size_t)i * nsp + j];  // (the SYRK kernel computes C −= X Xᵀ from zero)
                     cov_sub[(size_t)i * ns + j] = cov_sub[(size_t)j * ns + i] = acc;
                 }
-        M->solves++;
     }
+    return 0;
+}
+
+// out[:, s] = C \ B[:, s] on the block-cyclic pieces (C = the fitted K + Σy): the columns of B travel as rows, forward pass
+// X = Bᵀ L⁻ᵀ and one backward sweep per column.  B, out: n×ncols column-major host arrays.  Called with the main ctx locked.
+int32_t multi_solve(gp_post* post, const double* B, int ncols, double* out) {
+    gp_multi_post* mp = post->pieces;
+    gp_ctx* c = post->ctx;
+    const long n = mp->n, npad = mp->npad, nsp = (ncols + 127) / 128 * 128;
+    std::vector<double> rhs_h((size_t)nsp * npad, 0.0), z_h((size_t)ncols * npad, 0.0);
+    to_padded(B, n, ncols, mp->valid, mp->nb, rhs_h.data(), npad);
+    SolveDims sd{n, npad, mp->nblk, mp->nb, ncols, nsp, post->d};
+    sd.valid = mp->valid.data();
+    sd.rhs = true;
+    sd.nbwd = ncols;
+    std::vector<std::vector<double>> part, cpart;
+    RC(run_solve(c, sd, mp->pieces, post->kind, post->variance, nullptr, nullptr, rhs_h.data(), false, z_h.data(), part, cpart));
+    to_compact(z_h.data(), npad, ncols, mp->valid, mp->nb, out, n);
+    return 0;
+}
+
+// Sequential conditioning on the pieces (src/exact_gpr_posterior.jl:46-56, update_chol src/util/common_covmat_ops.jl:38-42): the factor
+// is EXTENDED where it lives.  New observations become new block rows (their own padded blocks) of a new set of pieces:
+//   U12ᵀ = K(x2, x1) L11⁻ᵀ     the forward solve on the old pieces; every rank keeps the rows of the blocks it owns ("sink")
+//   U22ᵀ = chol(C22 − U12ᵀU12)  n2 ≤ 4 096: X Xᵀ is summed from the ranks' SYRKs, factored on the first device, its blocks sent to their owners
+//   α    = L⁻ᵀ L⁻¹ δ           forward + backward sweep over the extended pieces
+// Called with the main ctx locked.  Status −1991: the forward / backward consistency check failed (the caller gathers instead).
+int32_t multi_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post* post, void* alpha_out,
+                     double* logpdf_out) {
+    gp_multi_post* mp0 = old->pieces;
+    gp_ctx* c = old->ctx;
+    gp_multi* M = c->multi;
+    const int P = M->P, Q = M->Q, R = M->R, d = old->d;
+    const long NB = mp0->nb, nblk0 = mp0->nblk, npad0 = mp0->npad, n0 = mp0->n;
+    const long n2 = x2->n, nsp = (n2 + 127) / 128 * 128;
+    const long lcm = lcm_of(P, Q);
+    const long nb2 = ((n2 + NB - 1) / NB + lcm - 1) / lcm * lcm;
+    const long nblk1 = nblk0 + nb2, npad1 = nblk1 * NB, n1 = n0 + n2, Sp = nb2 * NB, lds = Sp + 32;
+    const long nlb_r0 = nblk0 / P, nlb_c0 = nblk0 / Q, nlb_r1 = nblk1 / P, nlb_c1 = nblk1 / Q;
+    const long ld2 = nlb_c1 * NB + 32, m_loc2 = nlb_r1 * NB, n_loc2 = nlb_c1 * NB;
+    const size_t A2_b = sizeof(double) * (size_t)(m_loc2 + 128) * ld2;
+    std::vector<long> valid1 = mp0->valid;
+    for (long t = 0; t < nb2; ++t) valid1.push_back(std::max(0L, std::min(NB, n2 - t * NB)));
+    const double* dl = (const double*)delta_all;
+
+    // ---- host marshalling: scaled new inputs (as the fit scaled the old ones), their noise, the old inputs in block layout
+    std::vector<double> xs2_h((size_t)d * nsp, 0.0), xs2S_h((size_t)d * Sp, 0.0), nz_h((size_t)Sp, 0.0), x0_h;
+    {
+        const double* pd = (const double*)x2->data;
+        for (int dd = 0; dd < d; ++dd) {
+            const double sc = old->nscale == 1 ? old->scale[0] : (old->nscale > 1 ? old->scale[dd] : 1.0);
+            for (long i = 0; i < n2; ++i) {
+                const double v = sc * (x2->layout == 0 ? pd[i] : (x2->layout == 1 ? pd[(long)dd + i * x2->d] : pd[i + (long)dd * x2->n]));
+                xs2_h[(size_t)dd * nsp + i] = v;
+                xs2S_h[(size_t)dd * Sp + i] = v;
+            }
+        }
+        for (long i = 0; i < n2; ++i) nz_h[i] = noise2->kind == 0 ? noise2->s : ((const double*)noise2->diag)[i];
+    }
+    RC(padded_inputs(old, x0_h));
+
+    // ---- new pieces: zero, the old piece copied in (device-local), the new block rows filled below
+    std::vector<void*> A2((size_t)R, nullptr);
+    auto drop_new = [&]() {
+        for (int r = 0; r < R; ++r) {
+            MRank& rk = M->ranks[r];
+            std::lock_guard<std::mutex> l(rk.c->mu);
+            (void)hipSetDevice(rk.device);
+            if (A2[r]) ctx_release(rk.c, A2[r], 0);
+            A2[r] = nullptr;
+            rk.A2 = nullptr;
+        }
+        (void)hipSetDevice(c->device);
+    };
+    int32_t rc = 0;
+    for (int r = 0; r < R && rc == 0; ++r) {
+        MRank& rk = M->ranks[r];
+        std::lock_guard<std::mutex> l(rk.c->mu);
+        rc = [&]() -> int32_t {
+            MCHK(hipSetDevice(rk.device));
+            RC(ctx_alloc(rk.c, A2_b, &A2[r]));
+            const auto& pc = mp0->pieces[r];
+            MCHK(hipMemsetAsync(A2[r], 0, A2_b, rk.c->sm));
+            MCHK(hipMemcpy2DAsync(A2[r], sizeof(double) * ld2, pc.A, sizeof(double) * pc.ld, sizeof(double) * nlb_c0 * NB, nlb_r0 * NB, hipMemcpyDeviceToDevice, rk.c->sm));
+            rk.A2 = (double*)A2[r];
+            rk.ld2 = ld2;
+            return 0;
+        }();
+    }
+    (void)hipSetDevice(c->device);
+    if (rc != 0) {
+        drop_new();
+        return rc;
+    }
+
+    // ---- U12ᵀ = K(x2, x1) L11⁻ᵀ on the old pieces, rows kept by their new owners; X Xᵀ from the ranks' SYRKs
+    std::vector<std::vector<double>> part, cpart;
+    {
+        SolveDims sd{n0, npad0, nblk0, NB, n2, nsp, d};
+        sd.valid = mp0->valid.data();
+        sd.sink_nb2 = nb2;
+        rc = run_solve(c, sd, mp0->pieces, old->kind, old->variance, x0_h.data(), xs2_h.data(), nullptr, true, nullptr, part, cpart);
+    }
+    // ---- U22ᵀ = chol(K(x2, x2) + Σy2 − X Xᵀ) on the first device (identity padding up to the block boundary), blocks to their owners
+    double logdet2_half = 0;
+    if (rc == 0) {
+        std::vector<double> nxx((size_t)nsp * nsp, 0.0);
+        for (long i = 0; i < n2; ++i)
+            for (long j = 0; j <= i; ++j) {
+                double acc = 0;
+                for (int r = 0; r < R; ++r) acc += cpart[r][(size_t)i * nsp + j];  // (= −(X Xᵀ)[i][j]: the SYRK kernel computes C −= X Xᵀ from zero)
+                nxx[(size_t)i * nsp + j] = nxx[(size_t)j * nsp + i] = acc;
+            }
+        DevBufs mb(c);
+        void *x2_v = 0, *nz_v = 0, *S_v = 0, *T_v = 0;
+        int info_h = 0;
+        double scal_h[2] = {0, 0};
+        rc = [&]() -> int32_t {
+            MCHK(hipSetDevice(c->device));
+            RC(mb.get(sizeof(double) * (size_t)d * Sp, &x2_v));
+            RC(mb.get(sizeof(double) * (size_t)Sp, &nz_v));
+            RC(mb.get(sizeof(double) * (size_t)(Sp + 128) * lds, &S_v));
+            RC(mb.get(sizeof(double) * (size_t)nsp * nsp, &T_v));
+            if (!c->info_dev) MCHK(hipMalloc((void**)&c->info_dev, sizeof(int)));
+            RC(ctx_scal(c, 16));
+            hipStream_t sm = c->sm;
+            MCHK(hipMemcpyAsync(x2_v, xs2S_h.data(), sizeof(double) * (size_t)d * Sp, hipMemcpyHostToDevice, sm));
+            MCHK(hipMemcpyAsync(nz_v, nz_h.data(), sizeof(double) * (size_t)Sp, hipMemcpyHostToDevice, sm));
+            MCHK(hipMemcpyAsync(T_v, nxx.data(), sizeof(double) * (size_t)nsp * nsp, hipMemcpyHostToDevice, sm));
+            MCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), sm));
+            MCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * 16, sm));
+            MCHK(hipMemsetAsync(S_v, 0, sizeof(double) * (size_t)(Sp + 128) * lds, sm));
+            RC(eng_assemble(c, sm, old->kind, old->variance, (const double*)x2_v, n2, Sp, d, (const double*)nz_v, plain_map(1, 0, 0), (double*)S_v, lds, Sp, Sp));
+            hipLaunchKernelGGL(mk_addmat_kernel, dim3((unsigned)std::min<long>(1024, (nsp * nsp + 255) / 256)), dim3(256), 0, sm, (double*)S_v, lds, (const double*)T_v,
+                               nsp, nsp, nsp);
+            MCHK(hipGetLastError());
+            RC(eng_potrf(c, sm, (double*)S_v, lds, Sp, Sp, c->info_dev, 0, n2, c->scal_dev));
+            MCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, sm));
+            MCHK(hipMemcpyAsync(scal_h, c->scal_dev, sizeof(double), hipMemcpyDeviceToHost, sm));
+            MCHK(hipStreamSynchronize(sm));
+            if (info_h != 0) return (int32_t)n0 + info_h;  // order of the failing leading minor of the bordered matrix
+            for (long t = 0; t < nb2; ++t)
+                for (long u = 0; u <= t; ++u) {
+                    const long I = nblk0 + t, J = nblk0 + u;
+                    MRank& rk = M->ranks[(size_t)(I % P) * Q + (size_t)(J % Q)];
+                    MCHK(hipMemcpy2DAsync(rk.A2 + (I / P) * NB * ld2 + (J / Q) * NB, sizeof(double) * ld2, (const double*)S_v + t * NB * lds + u * NB,
+                                          sizeof(double) * lds, sizeof(double) * NB, NB, hipMemcpyDefault, sm));
+                }
+            MCHK(hipStreamSynchronize(sm));
+            return 0;
+        }();
+        if (rc != 0) (void)hipStreamSynchronize(c->sm);
+        logdet2_half = scal_h[0];
+    }
+    // ---- α = L⁻ᵀ L⁻¹ δ over the extended pieces; ‖L⁻¹δ‖² from the forward pass
+    std::vector<gp_multi_post::Piece> pieces1;
+    for (int r = 0; r < R; ++r) pieces1.push_back({M->ranks[r].c, A2[r], ld2, m_loc2, n_loc2});
+    std::vector<double> z_h((size_t)npad1, 0.0), al((size_t)n1, 0.0);
+    double sqm = 0;
+    if (rc == 0) {
+        std::vector<double> rhs_h((size_t)128 * npad1, 0.0);
+        to_padded(dl, n1, 1, valid1, NB, rhs_h.data(), npad1);
+        SolveDims sd{n1, npad1, nblk1, NB, 1, 128, d};
+        sd.valid = valid1.data();
+        sd.rhs = true;
+        sd.nbwd = 1;
+        rc = run_solve(c, sd, pieces1, old->kind, old->variance, nullptr, nullptr, rhs_h.data(), false, z_h.data(), part, cpart);
+        if (rc == 0) {
+            for (int r = 0; r < R; ++r) sqm += part[r][0];
+            to_compact(z_h.data(), npad1, 1, valid1, NB, al.data(), n1);
+            double da = 0, dn = 0;
+            for (long i = 0; i < n1; ++i) {
+                da += dl[i] * al[i];
+                dn += std::fabs(dl[i] * al[i]);
+            }
+            if (!(std::fabs(da - sqm) <= 1e-7 * (dn + std::fabs(sqm)))) {
+                char b[200];
+                snprintf(b, sizeof b, "sequential update on the pieces: delta'alpha = %.15g but ||L^-1 delta||^2 = %.15g", da, sqm);
+                rc = set_err_text(-1991, b);
+            }
+        }
+    }
+    for (int r = 0; r < R; ++r) M->ranks[r].A2 = nullptr;
+    // ---- the new handle: inputs + α on the first device (compact), the factor as the new pieces
+    const long np1 = (n1 + 127) / 128 * 128;
+    DevBufs mb(c);
+    void *xs_v = 0, *al_v = 0;
+    if (rc == 0) {
+        rc = [&]() -> int32_t {
+            MCHK(hipSetDevice(c->device));
+            RC(mb.get(sizeof(double) * (size_t)d * np1, &xs_v));
+            RC(mb.get(sizeof(double) * (size_t)np1, &al_v));
+            MCHK(hipMemset(xs_v, 0, sizeof(double) * (size_t)d * np1));
+            MCHK(hipMemset(al_v, 0, sizeof(double) * (size_t)np1));
+            MCHK(hipMemcpy2D(xs_v, sizeof(double) * np1, old->xs, sizeof(double) * old->np, sizeof(double) * n0, d, hipMemcpyDeviceToDevice));
+            MCHK(hipMemcpy2D((double*)xs_v + n0, sizeof(double) * np1, xs2_h.data(), sizeof(double) * nsp, sizeof(double) * n2, d, hipMemcpyHostToDevice));
+            MCHK(hipMemcpy(al_v, al.data(), sizeof(double) * (size_t)n1, hipMemcpyHostToDevice));
+            return 0;
+        }();
+    }
+    if (rc != 0) {
+        drop_new();
+        return rc;
+    }
+    if (alpha_out) memcpy(alpha_out, al.data(), sizeof(double) * (size_t)n1);
+    gp_multi_post* mp = new gp_multi_post();
+    mp->P = P; mp->Q = Q; mp->n = n1; mp->npad = npad1; mp->nblk = nblk1; mp->nb = NB;
+    mp->valid = valid1;
+    mp->pieces = pieces1;
+    for (int r = 0; r < R; ++r) M->ranks[r].c->refs++;  // every piece keeps its rank context alive
+    post->ctx = c;
+    post->dtype = 0;
+    post->n = n1; post->np = np1; post->ld = np1 + c->ldpad; post->mtot = np1 + 128; post->d = d;
+    post->kind = old->kind; post->variance = old->variance; post->nscale = old->nscale;
+    post->scale = old->scale;
+    post->A = nullptr; post->A_bytes = 0;
+    post->xs = mb.keep(xs_v); post->xs_bytes = sizeof(double) * (size_t)d * np1;
+    post->alpha = mb.keep(al_v); post->alpha_bytes = sizeof(double) * (size_t)np1;
+    post->logdet_half = old->logdet_half + logdet2_half;
+    post->pieces = mp;
+    if (logpdf_out) *logpdf_out = -0.5 * ((double)n1 * 1.8378770664093454835606594728112 + 2.0 * post->logdet_half + sqm);
     return 0;
 }
 
@@ -1886,38 +2283,46 @@ void multi_post_release(gp_post* post) {
 }
 
 // Block-cyclic pieces -> the single-device row-major lower factor on the ctx's first device (288 GB of HBM hold the 34 GB of
-// N = 65 536 many times over), so that everything downstream of a fit — predictive variances / covariances, sequential
-// updates, sampling, held-out logpdf — runs on the resident factor exactly as after a single-device fit.  Called with the
-// main ctx locked.
+// N = 65 536 many times over), for what is not done on the pieces (C.U handed out, factor_mul, > 4 096 test points with a full
+// covariance).  Only the real points travel: the padding inside the blocks (the tail of a fit, the tail of every batch of a
+// sequential update) is dropped and the single-device identity padding up to np is written instead.  Called with the main ctx locked.
+__global__ void mk_unit_diag_kernel(double* A, long ld, long i0, long i1) {
+    const long i = i0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < i1) A[i * ld + i] = 1.0;
+}
 int32_t multi_gather(gp_post* post) {
     gp_multi_post* mp = post->pieces;
     if (!mp) return 0;
     gp_ctx* c = post->ctx;
-    const long NB = mp->nb, np = post->np, ld = post->ld, mtot = post->mtot;
+    const long NB = mp->nb, n = post->n, np = post->np, ld = post->ld, mtot = post->mtot;
     const int P = mp->P, Q = mp->Q;
+    const std::vector<long> off = block_offsets(mp->valid);
     MCHK(hipSetDevice(c->device));
     void* A_v = nullptr;
     const size_t A_b = sizeof(double) * (size_t)(mtot + 128) * ld;
     RC(ctx_alloc(c, A_b, &A_v));
     double* A = (double*)A_v;
     int32_t rc = [&]() -> int32_t {
-        MCHK(hipMemsetAsync(A + np * ld, 0, sizeof(double) * (size_t)(mtot - np + 128) * ld, c->sm));
+        MCHK(hipMemsetAsync(A + n * ld, 0, sizeof(double) * (size_t)(mtot - n + 128) * ld, c->sm));
         for (size_t r = 0; r < mp->pieces.size(); ++r) {
             auto& pc = mp->pieces[r];
             const int p = (int)r / Q, q = (int)r % Q;
-            for (long li = 0; li * NB < pc.m_loc && li < mp->nblk / P; ++li) {
-                const long gi = li * P + p;
-                if (gi * NB >= np) continue;
-                const long rows = std::min(NB, np - gi * NB);
+            for (long li = 0; li < mp->nblk / P; ++li) {
+                const long gi = li * P + p, rows = mp->valid[gi];
+                if (rows <= 0) continue;
                 for (long lj = 0; lj < mp->nblk / Q; ++lj) {
                     const long gj = lj * Q + q;
                     if (gj > gi) break;
-                    const long cols = std::min(NB, np - gj * NB);
+                    const long cols = mp->valid[gj];
                     if (cols <= 0) continue;
-                    MCHK(hipMemcpy2DAsync(A + gi * NB * ld + gj * NB, sizeof(double) * ld, (const double*)pc.A + li * NB * pc.ld + lj * NB,
+                    MCHK(hipMemcpy2DAsync(A + off[gi] * ld + off[gj], sizeof(double) * ld, (const double*)pc.A + li * NB * pc.ld + lj * NB,
                                           sizeof(double) * pc.ld, sizeof(double) * cols, rows, hipMemcpyDefault, c->sm));
                 }
             }
+        }
+        if (np > n) {
+            hipLaunchKernelGGL(mk_unit_diag_kernel, dim3((unsigned)((np - n + 255) / 256)), dim3(256), 0, c->sm, A, ld, n, np);
+            MCHK(hipGetLastError());
         }
         MCHK(hipStreamSynchronize(c->sm));
         return 0;

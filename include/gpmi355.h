@@ -115,10 +115,18 @@ int32_t gp_ctx_multi_stats(gp_ctx* ctx, int64_t* fits, int64_t* retries, int64_t
 /* Predictive variances — and full covariances for up to 4 096 test points — of a multi-device posterior (gp_posterior_predict) are
  * computed on the distributed factor: a block forward solve with the factor left where the fit put it, N*×nb blocks of the solution
  * travelling, one SYRK per rank for the covariance — and with them gp_posterior_logpdf / gp_posterior_rand for up to 4 096 test points
- * ("multi_dist_predict", default 1; `solves` above counts them; sequential updates, gp_posterior_factor_mul / _solve and C.U still
- * gather the factor onto devices[0] first).
- * gp_multi_solve_trace writes that solve's schedule for a P×Q grid (dry run of the real rank threads, like gp_multi_schedule_trace). */
+ * ("multi_dist_predict", default 1; `solves` above counts the passes over the pieces).  On the pieces as well:
+ *   gp_posterior_solve  (<= 128 columns): the columns travel as rows — forward pass, then one backward block sweep per column;
+ *   gp_posterior_update (<= 4 096 new observations): the factor is EXTENDED where it lives — K(x2, x1) L11⁻ᵀ by the forward pass, every
+ *                       rank keeping the rows of the new blocks it owns; chol(C22 − U12ᵀU12) on devices[0], its blocks sent to their
+ *                       owners; α by a forward + backward pass over the extended pieces.  The new posterior is again a multi-device
+ *                       posterior (each batch of observations ends in its own padded blocks).
+ * gp_posterior_factor_mul, C.U (gp_posterior_get_factor) and covariances of more than 4 096 test points gather the factor onto devices[0].
+ * gp_multi_solve_trace / _ex write the schedule of such a pass for a P×Q grid (dry run of the real rank threads, like
+ * gp_multi_schedule_trace); flags: 1 = given right-hand sides, 2 = rows kept for an extended factor (sequential update),
+ * 4 = followed by two backward sweeps. */
 int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk, const char* path);
+int32_t gp_multi_solve_trace_ex(int32_t P, int32_t Q, int32_t nblk, int32_t flags, const char* path);
 /* The schedule the multi-device driver issues for a P×Q grid over nblk block columns (look-ahead depth 1..3; comm 1 =
  * send/recv transport, 2 = copies), written as JSON lines to `path`: every stream operation with its block footprint, every
  * event record / wait, every transfer — produced by the SAME rank-thread code that drives the devices, run without a device

@@ -73,7 +73,8 @@ def test_lookahead_depths_and_ragged_sizes(agp, depth, P, Q, n, nb):
 
 
 def test_multi_sequential_update_and_rand_after_gather(agp):
-    """posterior(f_post(x2, σ²), y2) and rand on a posterior that was fitted block-cyclically (the factor is gathered first)."""
+    """posterior(f_post(x2, σ²), y2) on a posterior that was fitted block-cyclically (extended on the pieces, then gathered for
+    C.U) and prior sampling through the gathered factor."""
     n1, n2 = 900, 300
     x, y = o.synth_inputs(n1 + n2, 3, 5)
     of = o.GP(o.Kernel(o.MATERN32))
@@ -197,6 +198,81 @@ def test_predictive_variance_on_the_distributed_factor(agp, P, Q, tmp_path):
         assert np.max(np.abs(post.data.C.U - opost.U)) <= 1e-10
         np.testing.assert_allclose(post.var(agp.RowVecs(xs)), vo, atol=1e-9)
         assert ctx.multi_stats()["solves"] == 8
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("P,Q", [(1, 1), (2, 1), (2, 2), (4, 2), (2, 3), (3, 1), (8, 1), (1, 4)], ids=lambda v: str(v))
+def test_sequential_update_and_solve_on_the_pieces(agp, P, Q, tmp_path):
+    """posterior(f_post(x2, Σ2), y2) on a multi-device posterior WITHOUT gathering the factor (src/exact_gpr_posterior.jl:46-56,
+    update_chol src/util/common_covmat_ops.jl:38-42): the block-cyclic factor is extended where it lives (csrc/multi.hip:
+    multi_update) — twice in a row, so that the pieces hold two batches with their own padded blocks — and `C \\ B`
+    (gp_posterior_solve) by a forward pass + backward sweeps on the pieces.  α, logpdf, predictions and C.U against the oracle's batch
+    posterior at the single-GPU tolerances; the schedule of the device run goes through the happens-before checker."""
+    import os
+    import sys
+    from pathlib import Path
+
+    import scipy.linalg as sla
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import multi_schedule_check as M
+
+    n1, n2, n3, d, nb = 1100, 300, 41, 3, 128
+    n = n1 + n2 + n3
+    x, y = o.synth_inputs(n, d, 90 + P * 10 + Q)
+    rng = np.random.default_rng(P * 11 + Q)
+    s2 = 0.04 + 0.05 * rng.random(n)
+    of = o.GP(o.Kernel(o.MATERN52, 1.3, 0.8), 0.2)
+    ob2 = o.posterior(o.FiniteGP(of, x[: n1 + n2], s2[: n1 + n2]), y[: n1 + n2])
+    ob3 = o.posterior(o.FiniteGP(of, x, s2), y)
+    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    try:
+        f = agp.GP(0.2, 1.3 * agp.Matern52Kernel() @ agp.ScaleTransform(0.8), ctx=ctx)
+        p1 = agp.posterior(f(agp.RowVecs(x[:n1]), s2[:n1]), y[:n1])
+        # C \ B on the pieces (3 columns: forward pass + 3 backward sweeps)
+        B = rng.standard_normal((n1, 3))
+        ob1 = o.posterior(o.FiniteGP(of, x[:n1], s2[:n1]), y[:n1])
+        ref = sla.cho_solve((ob1.U, False), B)
+        assert _relnorm(p1.data.C.solve(B), ref) <= 1e-8
+        assert _relnorm(p1.data.C.solve(B[:, 0]), ref[:, 0]) <= 1e-8
+        s0 = ctx.multi_stats()["solves"]
+        assert s0 == 2
+        trace = tmp_path / "update.jsonl"
+        os.environ["GPMI_TRACE_SCHEDULE"] = str(trace)
+        try:
+            p2 = agp.posterior(p1(agp.RowVecs(x[n1 : n1 + n2]), s2[n1 : n1 + n2]), y[n1 : n1 + n2])
+        finally:
+            os.environ.pop("GPMI_TRACE_SCHEDULE", None)
+        assert ctx.multi_stats()["solves"] == s0 + 2       # K(x2, x1) L11⁻ᵀ on the old pieces, then α on the extended ones: no gather
+        hdr, problems, rs = M.check_trace(trace)
+        assert hdr.get("mode") == "solve" and hdr["flags"] == 5 and hdr["dry"] == 0 and not problems and not rs, (problems[:3], rs[:3])
+        assert _relnorm(p2.data.alpha, ob2.alpha) <= 1e-8
+        np.testing.assert_allclose(p2.logpdf_value, o.logpdf(o.FiniteGP(of, x[: n1 + n2], s2[: n1 + n2]), y[: n1 + n2]), rtol=1e-10)
+        xs = rng.standard_normal((200, d)) * 1.2
+        m2, v2 = p2.mean_and_var(agp.RowVecs(xs))              # predictions of the updated posterior: still on the pieces
+        mo2, vo2 = ob2.mean_and_var(xs)
+        np.testing.assert_allclose(m2, mo2, atol=1e-8)
+        np.testing.assert_allclose(v2, vo2, atol=1e-9)
+        np.testing.assert_allclose(p2.cov(agp.RowVecs(xs[:70])), ob2.cov(xs[:70]), atol=1e-9)
+        assert ctx.multi_stats()["solves"] == s0 + 4
+        # a second update on top (41 points: one more padded batch), then everything again
+        p3 = agp.posterior(p2(agp.RowVecs(x[n1 + n2 :]), s2[n1 + n2 :]), y[n1 + n2 :])
+        assert ctx.multi_stats()["solves"] == s0 + 6
+        assert _relnorm(p3.data.alpha, ob3.alpha) <= 1e-8
+        np.testing.assert_allclose(p3.logpdf_value, o.logpdf(o.FiniteGP(of, x, s2), y), rtol=1e-10)
+        m3, v3 = p3.mean_and_var(agp.RowVecs(xs))
+        mo3, vo3 = ob3.mean_and_var(xs)
+        np.testing.assert_allclose(m3, mo3, atol=1e-8)
+        np.testing.assert_allclose(v3, vo3, atol=1e-9)
+        B3 = rng.standard_normal(n)
+        assert _relnorm(p3.data.C.solve(B3), sla.cho_solve((ob3.U, False), B3)) <= 1e-8
+        # the old posteriors are untouched (the reference returns new objects): p1 still predicts from its own pieces
+        np.testing.assert_allclose(p1.var(agp.RowVecs(xs[:50])), ob1.mean_and_var(xs[:50])[1], atol=1e-9)
+        # C.U gathers the extended pieces — only the real points travel, the padding between the batches is dropped
+        assert np.max(np.abs(p3.data.C.U - ob3.U)) <= 1e-9
+        np.testing.assert_allclose(p3.var(agp.RowVecs(xs)), vo3, atol=1e-9)   # (now the gathered, single-device path)
+        assert np.max(np.abs(p2.data.C.U - ob2.U)) <= 1e-9
     finally:
         ctx.close()
 

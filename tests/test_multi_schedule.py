@@ -68,6 +68,32 @@ def test_checker_finds_unwaited_solution_blocks_and_partial_sums():
         assert M.check_config(2, 3, 6, 0, COPIES, mutate=edit, solve=True)[1]
 
 
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_solve_update_and_backward_sweeps_on_the_pieces_are_ordered(grid):
+    """the other passes over the distributed factor, traced from the real rank threads without a device: `C \\ B` (given right-hand
+    sides, forward pass + two backward block sweeps separated by the rank barrier), the sequential update's forward pass (every rank
+    keeps the rows of the new blocks it owns in its piece of the extended factor), and both together"""
+    P, Q = grid
+    for flags in (1 | 4, 2, 1 | 2 | 4):
+        for nblk in (1, 2, 5, 9):
+            problems, rs = M.check_config(P, Q, nblk, 0, COPIES, solve=flags)
+            assert not problems and not rs, (grid, flags, nblk, problems[:3], rs[:3])
+
+
+def test_checker_needs_the_barrier_between_backward_sweeps_and_the_sweep_events():
+    """without the waits on the peers' barrier events, sweep 2 resets partial sums a peer may still be fetching for sweep 1; without
+    the alr / accr waits a solution block or a partial sum is fetched before it is final"""
+    for tag in ("bar", "alr", "accr"):
+        edit = lambda lines, tag=tag: [ln for ln in lines if not (ln["t"] == "wait" and ln.get("tag") == tag)]  # noqa: E731
+        assert M.check_config(2, 2, 4, 0, COPIES, mutate=edit, solve=1 | 4)[1], tag
+    with __import__("tempfile").TemporaryDirectory() as td:   # the update pass writes the new block rows of every process column
+        path = Path(td) / "t.jsonl"
+        M.emit_trace(2, 3, 6, 0, COPIES, path, solve=2)
+        hdr, lines = M.load(path)
+    sinks = [ln for ln in lines if ln["t"] == "op" and ln["n"] == "sink"]
+    assert len(sinks) == 6 * 6 and all(ln["W"][0][0] == "A2" for ln in sinks)   # 6 new block rows (lcm) × 6 block columns, one owner each
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):

@@ -34,14 +34,17 @@ def nlb_before(k, p, P):  # number of global blocks i <= k with i ≡ p (mod P)
 
 
 def emit_trace(P, Q, nblk, depth, comm, path, solve=False):
-    """run the library's rank threads without a device (no GPU needed; the .so must be built); solve: the forward solve on the
-    distributed factor (predictive variances) instead of the fit"""
+    """run the library's rank threads without a device (no GPU needed; the .so must be built); solve: a pass over the distributed
+    factor instead of the fit — True / 0: the forward solve of the predictive variances, else the flags of gp_multi_solve_trace_ex
+    (1 given right-hand sides, 2 rows kept for an extended factor (sequential update), 4 followed by two backward sweeps)"""
     sys.path.insert(0, str(ROOT))
     import abstractgps_jl_amd as agp
 
     lib = agp._lib.load()
-    if solve:
+    if solve is True:
         agp._lib.check(lib.gp_multi_solve_trace(P, Q, nblk, str(path).encode()))
+    elif solve is not False and solve is not None:
+        agp._lib.check(lib.gp_multi_solve_trace_ex(P, Q, nblk, int(solve), str(path).encode()))
     else:
         agp._lib.check(lib.gp_multi_schedule_trace(P, Q, nblk, depth, comm, str(path).encode()))
 
@@ -78,6 +81,10 @@ def expand(fp, hdr):
         for s in range(a0, a1):
             for lj in range(b0, b1):
                 out.add(("Bb", r, s, lj))
+    elif name == "A2":  # the rank's piece of an extended factor (sequential update): local block rows [a0, a1) × local block columns [b0, b1)
+        for li in range(a0, a1):
+            for lj in range(b0, b1):
+                out.add(("A2", r, li, lj))
     elif name == "Lkk":
         out.add(("Lkk", r))
     elif name in ("acc", "alb", "tmp", "ACC", "X", "Xb", "T", "Vs", "Cv"):  # (the last six: buffers of the forward solve on the distributed factor)
@@ -248,12 +255,14 @@ if __name__ == "__main__":
                           f"{len(rs)} unordered conflicting pairs, e.g.")
                     for x in (problems + rs)[:6]:
                         print("   ", x)
-    for (P, Q) in GRIDS:   # the forward solve on the distributed factor (predictive variances without the gather)
+    # passes over the distributed factor: predictive variances (forward solve), C \\ B (given right-hand sides, forward + backward
+    # sweeps), the sequential update (rows kept for the extended factor)
+    for (P, Q), flags in itertools.product(GRIDS, (True, 1 | 4, 2, 1 | 2 | 4)):
         for nblk in (1, 2, 3, 5, 9, 17):
-            problems, rs = check_config(P, Q, nblk, 0, 2, solve=True)
+            problems, rs = check_config(P, Q, nblk, 0, 2, solve=flags)
             if problems or rs:
                 bad += 1
-                print(f"solve grid {P}x{Q} nblk {nblk}: {len(problems)} protocol findings, {len(rs)} unordered conflicting pairs, e.g.")
+                print(f"solve (flags {flags}) grid {P}x{Q} nblk {nblk}: {len(problems)} protocol findings, {len(rs)} unordered conflicting pairs, e.g.")
                 for x in (problems + rs)[:6]:
                     print("   ", x)
     print("configurations with findings:", bad)
