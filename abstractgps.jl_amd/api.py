@@ -528,6 +528,14 @@ class _Factor:
         check(self.ctx.lib.gp_posterior_solve(self.handle, D.ctypes.data, D.shape[1], out.ctypes.data))
         return np.ascontiguousarray(out).reshape(B.shape)
 
+    def Ut_mul(self, xi) -> np.ndarray:
+        """`C.U' * xi` (gp_posterior_factor_mul: the sampling transform of rand) — on the pieces for a multi-device factor."""
+        xi = np.asarray(xi, dtype=self.dtype)
+        D = np.asfortranarray(xi.reshape(self.n, -1))
+        out = np.empty_like(D, order="F")
+        check(self.ctx.lib.gp_posterior_factor_mul(self.handle, D.ctypes.data, D.shape[1], out.ctypes.data))
+        return np.ascontiguousarray(out).reshape(xi.shape)
+
     def free(self):
         self._fin()
 

@@ -257,6 +257,8 @@ bool multi_can_solve(gp_post* post);  // predictive variances on the distributed
 int32_t multi_predict_var(gp_post* post, const double* xs_scaled, long ns_ld, long ns, double* var_sub, double* cov_sub);
 // out = C \ B (n×ncols column-major host arrays) by a forward pass and ncols backward sweeps on the pieces
 int32_t multi_solve(gp_post* post, const double* B, int ncols, double* out);
+// out = L ξ (n×ncols column-major host arrays): every rank multiplies the blocks it holds, partial products summed on the host
+int32_t multi_factor_mul(gp_post* post, const double* xi, int ncols, double* out);
 // sequential conditioning on the pieces: the factor of `old` extended by new block rows into `post` (-1991: self-check failed)
 int32_t multi_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, const void* delta_all, gp_post* post, void* alpha_out,
                      double* logpdf_out);

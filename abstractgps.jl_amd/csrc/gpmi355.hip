@@ -1893,6 +1893,7 @@ int32_t gp_posterior_factor_mul(gp_post* post, const void* xi, int32_t ncols, vo
     if (!out) return set_arg_err(4, "out is NULL");
     gp_ctx* c = gd.c;
     HIPCHK(hipSetDevice(c->device));
+    if (post->dtype == 0 && multi_can_solve(post) && ncols <= 1024) return multi_factor_mul(post, (const double*)xi, ncols, (double*)out);  // on the pieces
     RC(multi_gather(post));
     return post->dtype == 0 ? factor_mul_impl<double>(post, xi, ncols, out) : factor_mul_impl<float>(post, xi, ncols, out);
 }

@@ -95,6 +95,30 @@ __global__ void mk_addmat_kernel(double* dst, long ldd, const double* src, long 
     }
 }
 
+// out[s][row] = Σ_{c < len(row)} A[row][c] · v[s][c] over the local columns of a block-cyclic piece of the LOWER factor: local row
+// `row` of global block gi = (row / NB)·P + p reaches over the ncb local block columns left of the diagonal and — on the rank that
+// owns the diagonal block — over its lower triangle (the upper triangle of a stored diagonal block is not part of the factor).
+// One workgroup per (local row, vector).
+__global__ __launch_bounds__(256) void mk_rowdot_kernel(const double* __restrict__ A, long ld, long NB, int P, int p, int Q, int q,
+                                                         const double* __restrict__ v, long ldv, double* __restrict__ out, long ldo) {
+    const long row = blockIdx.x, s = blockIdx.y;
+    const long gi = (row / NB) * P + p;
+    const long ncb = gi - 1 >= q ? (gi - 1 - q) / Q + 1 : 0;
+    const long len = ncb * NB + ((gi % Q == q) ? (row % NB) + 1 : 0);
+    const double* a = A + row * ld;
+    const double* x = v + s * ldv;
+    double acc = 0;
+    for (long c = threadIdx.x; c < len; c += 256) acc = fma(a[c], x[c], acc);
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[s * ldo + row] = red[0];
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -2060,6 +2084,70 @@ int32_t multi_solve(gp_post* post, const double* B, int ncols, double* out) {
     std::vector<std::vector<double>> part, cpart;
     RC(run_solve(c, sd, mp->pieces, post->kind, post->variance, nullptr, nullptr, rhs_h.data(), false, z_h.data(), part, cpart));
     to_compact(z_h.data(), npad, ncols, mp->valid, mp->nb, out, n);
+    return 0;
+}
+
+// out[:, s] = L ξ[:, s] = C.U' ξ (the sampling transform, src/finite_gp_projection.jl:233-237, 271-277) on the block-cyclic pieces: every
+// rank multiplies the blocks it holds with its share of ξ (one launch: the reach of every local row is contiguous in the piece), the
+// process rows' partial products are summed on the host.  No exchange between the ranks.  Called with the main ctx locked.
+int32_t multi_factor_mul(gp_post* post, const double* xi, int ncols, double* out) {
+    gp_multi_post* mp = post->pieces;
+    gp_ctx* c = post->ctx;
+    gp_multi* M = c->multi;
+    const int P = mp->P, Q = mp->Q, R = M->R;
+    const long n = mp->n, npad = mp->npad, NB = mp->nb, nlb_r = mp->nblk / P, nlb_c = mp->nblk / Q;
+    const long m_loc = nlb_r * NB, n_loc = nlb_c * NB;
+    std::vector<double> xi_pad((size_t)ncols * npad, 0.0), out_pad((size_t)ncols * npad, 0.0);
+    to_padded(xi, n, ncols, mp->valid, NB, xi_pad.data(), npad);
+    std::vector<std::vector<double>> part((size_t)R);
+    std::vector<int32_t> rcs((size_t)R, 0);
+    std::vector<std::string> errs((size_t)R);
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < R; ++r)
+            th.emplace_back([&, r]() {
+                MRank& rk = M->ranks[r];
+                std::lock_guard<std::mutex> l(rk.c->mu);
+                rcs[r] = [&]() -> int32_t {
+                    const int q = r % Q, p = r / Q;
+                    const auto& pc = mp->pieces[r];
+                    MCHK(hipSetDevice(rk.device));
+                    std::vector<double> v_loc((size_t)ncols * n_loc);
+                    for (int s = 0; s < ncols; ++s)
+                        for (long lc = 0; lc < nlb_c; ++lc)
+                            memcpy(&v_loc[(size_t)s * n_loc + lc * NB], &xi_pad[(size_t)s * npad + (lc * Q + q) * NB], sizeof(double) * (size_t)NB);
+                    DevBufs b(rk.c);
+                    void *v_v = 0, *o_v = 0;
+                    RC(b.get(sizeof(double) * v_loc.size(), &v_v));
+                    RC(b.get(sizeof(double) * (size_t)ncols * m_loc, &o_v));
+                    hipStream_t sm = rk.c->sm;
+                    part[r].assign((size_t)ncols * m_loc, 0.0);
+                    MCHK(hipMemcpyAsync(v_v, v_loc.data(), sizeof(double) * v_loc.size(), hipMemcpyHostToDevice, sm));
+                    hipLaunchKernelGGL(mk_rowdot_kernel, dim3((unsigned)m_loc, (unsigned)ncols), dim3(256), 0, sm, (const double*)pc.A, pc.ld, NB, P, p, Q, q,
+                                       (const double*)v_v, n_loc, (double*)o_v, m_loc);
+                    MCHK(hipGetLastError());
+                    MCHK(hipMemcpyAsync(part[r].data(), o_v, sizeof(double) * part[r].size(), hipMemcpyDeviceToHost, sm));
+                    MCHK(hipStreamSynchronize(sm));
+                    return 0;
+                }();
+                if (rcs[r] != 0) errs[r] = gp_last_error();
+            });
+        for (auto& t : th) t.join();
+    }
+    (void)hipSetDevice(c->device);
+    for (int r = 0; r < R; ++r)
+        if (rcs[r] != 0) return set_err_text(rcs[r], "rank " + std::to_string(r) + ": " + errs[r]);
+    for (int r = 0; r < R; ++r) {
+        const int p = r / Q;
+        for (int s = 0; s < ncols; ++s)
+            for (long li = 0; li < nlb_r; ++li) {
+                const double* src = &part[r][(size_t)s * m_loc + li * NB];
+                double* dst = &out_pad[(size_t)s * npad + (li * P + p) * NB];
+                for (long t = 0; t < NB; ++t) dst[t] += src[t];
+            }
+    }
+    to_compact(out_pad.data(), npad, ncols, mp->valid, NB, out, n);
+    M->solves++;
     return 0;
 }
 

@@ -121,7 +121,10 @@ int32_t gp_ctx_multi_stats(gp_ctx* ctx, int64_t* fits, int64_t* retries, int64_t
  *                       rank keeping the rows of the new blocks it owns; chol(C22 − U12ᵀU12) on devices[0], its blocks sent to their
  *                       owners; α by a forward + backward pass over the extended pieces.  The new posterior is again a multi-device
  *                       posterior (each batch of observations ends in its own padded blocks).
- * gp_posterior_factor_mul, C.U (gp_posterior_get_factor) and covariances of more than 4 096 test points gather the factor onto devices[0].
+ *   gp_posterior_factor_mul (<= 1 024 columns): every rank multiplies the blocks it holds with its share of ξ, the process rows'
+ *                       partial products are summed on the host — no exchange between the ranks.
+ * C.U (gp_posterior_get_factor) and covariances of more than 4 096 test points gather the factor onto devices[0] (real points only: the
+ * padding inside the blocks is dropped).
  * gp_multi_solve_trace / _ex write the schedule of such a pass for a P×Q grid (dry run of the real rank threads, like
  * gp_multi_schedule_trace); flags: 1 = given right-hand sides, 2 = rows kept for an extended factor (sequential update),
  * 4 = followed by two backward sweeps. */

@@ -267,12 +267,21 @@ def test_sequential_update_and_solve_on_the_pieces(agp, P, Q, tmp_path):
         np.testing.assert_allclose(v3, vo3, atol=1e-9)
         B3 = rng.standard_normal(n)
         assert _relnorm(p3.data.C.solve(B3), sla.cho_solve((ob3.U, False), B3)) <= 1e-8
+        # C.U' ξ (the sampling transform) on the extended pieces: every rank multiplies its blocks, no exchange
+        xi3 = rng.standard_normal((n, 2))
+        np.testing.assert_allclose(p3.data.C.Ut_mul(xi3), ob3.U.T @ xi3, atol=1e-10)
+        assert ctx.multi_stats()["solves"] == s0 + 9
         # the old posteriors are untouched (the reference returns new objects): p1 still predicts from its own pieces
         np.testing.assert_allclose(p1.var(agp.RowVecs(xs[:50])), ob1.mean_and_var(xs[:50])[1], atol=1e-9)
         # C.U gathers the extended pieces — only the real points travel, the padding between the batches is dropped
         assert np.max(np.abs(p3.data.C.U - ob3.U)) <= 1e-9
         np.testing.assert_allclose(p3.var(agp.RowVecs(xs)), vo3, atol=1e-9)   # (now the gathered, single-device path)
         assert np.max(np.abs(p2.data.C.U - ob2.U)) <= 1e-9
+        # rand(fx) of the PRIOR at the training inputs: factor of K + Σy fitted block-cyclically, C.U' ξ on its pieces
+        sb = ctx.multi_stats()["solves"]
+        xi1 = rng.standard_normal((n1, 2))
+        np.testing.assert_allclose(agp.rand(f(agp.RowVecs(x[:n1]), s2[:n1]), 2, xi=xi1), o.rand_from(o.FiniteGP(of, x[:n1], s2[:n1]), xi1), atol=1e-10)
+        assert ctx.multi_stats()["solves"] == sb + 1
     finally:
         ctx.close()
 
