@@ -340,6 +340,17 @@ function Base.getproperty(C::DeviceCholesky, s::Symbol)
     check(ccall((:gp_posterior_get_factor, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), getfield(C, :handle), U))
     return UpperTriangular(U)
 end
+# `C \ B` of user code (what `post.data.C \ v` does on a LinearAlgebra.Cholesky): forward + backward sweeps over the resident factor —
+# on the block-cyclic pieces when the factor comes from a multi-device fit (gp_posterior_solve)
+function Base.:\(C::DeviceCholesky, B::AbstractVecOrMat{<:Real})
+    size(B, 1) == getfield(C, :n) || throw(DimensionMismatch("C is $(getfield(C, :n))×$(getfield(C, :n)), B has $(size(B, 1)) rows"))
+    T = getfield(C, :T)
+    D = Matrix{T}(reshape(B, size(B, 1), :))
+    out = similar(D)
+    GC.@preserve D out check(ccall((:gp_posterior_solve, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+        getfield(C, :handle), D, size(D, 2), out))
+    return B isa AbstractVector ? vec(out) : out
+end
 function device_cholesky(h::Ptr{Cvoid}, n::Int, ::Type{T}) where {T}
     C = DeviceCholesky(h, n, T)
     finalizer(c -> ccall((:gp_posterior_free, libgpmi355), Int32, (Ptr{Cvoid},), getfield(c, :handle)), C)
