@@ -355,6 +355,37 @@ def test_conformance_approx_posterior(agp):
     _internal_interface(agp, rng, ap, xs, zs, np.float64, atol=1e-8, s2=1e-1, vfe_checks=False, check_posterior=False)
 
 
+@pytest.mark.parametrize("P,Q", [(2, 2), (3, 1), (1, 2)], ids=lambda v: str(v))
+def test_conformance_on_a_multi_device_context(agp, P, Q):
+    """The same conformance suites (src/util/TestUtils.jl:24-71, 87-106, 133-218) with every call going through a multi-device
+    context (virtual ranks): the prior (rand / logpdf / marginals / posterior through the block-cyclic driver) and the exact posterior
+    (predictions, held-out logpdf, sampling and posterior-of-a-posterior on the pieces) at the sizes the reference tests use — far
+    below one distribution block, so most blocks of the grid are padding."""
+    rng = np.random.default_rng(123456)
+    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=128)
+    try:
+        x = rng.standard_normal(37)
+        z = rng.standard_normal(23)
+        f = agp.GP(0.3, agp.Matern52Kernel(), ctx=ctx)
+        _internal_interface(agp, rng, f, x, z, np.float64, atol=1e-9, s2=1e-1, jitter=1e-8)
+        x = np.sort(rng.random(31)) * 3
+        y = np.sin(x) + 0.1 * rng.standard_normal(31)
+        fse = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
+        post = agp.posterior(fse(x, 0.1), y)
+        _internal_interface(agp, rng, post, rng.random(17) * 3, rng.random(11) * 3, np.float64, atol=1e-9, s2=1e-1, vfe_checks=False)
+        st = ctx.multi_stats()
+        assert st["fits"] >= 5 and st["retries"] == 0 and st["solves"] >= 10
+        # and the numbers: the multi-device posterior against a single-device one of the same data
+        p1 = agp.posterior(agp.GP(agp.SqExponentialKernel())(x, 0.1), y)
+        xs = rng.random(50) * 3
+        np.testing.assert_allclose(post.mean(xs), p1.mean(xs), atol=1e-10)
+        np.testing.assert_allclose(post.cov(xs), p1.cov(xs), atol=1e-10)
+        y2 = np.sin(xs[:9])
+        np.testing.assert_allclose(agp.posterior(post(xs[:9], 0.05), y2).mean(xs), agp.posterior(p1(xs[:9], 0.05), y2).mean(xs), atol=1e-9)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("multi", [False, True], ids=["one-device", "virtual-2x2"])
 def test_sqmahal_logdetcov_gradlogpdf(agp, multi):
     """Distributions.sqmahal / logdetcov / gradlogpdf on a FiniteGP (src/finite_gp_projection.jl:313-337) from the device's own
