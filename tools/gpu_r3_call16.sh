@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 3, call 16 (short): VFE row statistics from the Y GEMM's epilogue ("vfe_fuse_stats") — C5 with / without, the VFE tests with
-# it switched on for every ctx, and the C2 pair as a check that the shared GEMM kernel did not move
+# it switched on for every ctx, and the C2 pair as a check that the shared GEMM kernel did not move.
+# (Record of an experiment: the parameter was not kept — no gain, profiles/r3/c5_fuse_stats_{off,on}.log — so this script no longer runs as is.)
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/r3
