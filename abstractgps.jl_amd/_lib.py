@@ -83,7 +83,6 @@ PROTOTYPES = {
     "gpd_potrf": (i32, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
     "gpd_trsm": (i32, [vp, vp, i64, i64, vp, i64, i64]),
     "gpd_gemm_nt": (i32, [vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, PG, i64, i64]),
-    "gpd_gemm_tn": (i32, [vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32]),
     "gpd_trsv": (i32, [vp, vp, i64, i64, vp, i64, i32, i32]),
     "gpd_gemv_t": (i32, [vp, vp, i64, i64, i64, vp, vp]),
     "gpd_rowsumsq": (i32, [vp, vp, i64, i64, i64, vp]),

@@ -76,11 +76,7 @@ struct gp_ctx {
     long nb = 2048;        // outer panel width
     int lookahead = 1;
     int time_kernels = 0;
-    int gemm_variant = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
-    int trsm_mfma = 0;     // 1: 64-wide triangular solves as in-place MFMA updates with I − inv(L_jj) tiles
-    int trsm_leaf_mfma = 1; // 64-wide TRSM leaves on the matrix pipe (trsm64_mfma_kernel); 0: VALU trsm_64_kernel
-    int panel_fused = 1;   // 64-column leaves as one fused launch (panel64_kernel) instead of potf2_64 + trsm_64
     long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)
     long leaf_group = 128; // columns factored left-looking by consecutive leaves (64 = every leaf followed by its own GEMM)
     int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at
@@ -98,7 +94,6 @@ struct gp_ctx {
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
     int vfe_overlap = 1;   // VFE: kmat / ystats / partial-sum adds on the second stream beside the chunk GEMMs (double buffers)
     int vfe_sk = 0;        // VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))
-    int gemm_dma = 1;      // NT gemm operands through the LDS-DMA path (gemm_nt_dma_kernel); 0: register-staged kernel
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;
     long ldpad = 32;       // elements of padding per row: de-aliases power-of-two strides across HBM channels
@@ -122,7 +117,6 @@ struct gp_ctx {
     int* ticket_dev = nullptr;   // load tickets of panel64_kernel ([0]: main stream, [32]: panel stream)
     void* w_ws = nullptr;        // I − inv(L_jj) tiles for the MFMA triangular solve (trtri_64 output)
     size_t w_ws_bytes = 0;
-    void* lt_ws = nullptr;       // 64×64 transposed diagonal tile handed from potf2_64 to trsm_64 (fp64-sized)
     double* scal_dev = nullptr;  // [0] logdet accumulator, [8..] sumsq outputs
     long scal_cap = 0;
     std::atomic<int> refs{1};

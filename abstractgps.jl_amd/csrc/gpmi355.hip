@@ -113,7 +113,6 @@ void ctx_unref(gp_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->info_dev) (void)hipFree(c->info_dev);
     if (c->ticket_dev) (void)hipFree(c->ticket_dev);
-    if (c->lt_ws) (void)hipFree(c->lt_ws);
     if (c->w_ws) (void)hipFree(c->w_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
     if (c->sp_mask) (void)hipStreamDestroy(c->sp_mask);
@@ -194,7 +193,8 @@ static double lower_count(long M, long N, long row0, long col0) {
 
 template <typename T, typename CT = T>
 static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A, long lda, const T* B, long ldb,
-                           long M, long N, long K, GridMap g, bool kmajor = false) {
+                           long M, long N, long K, GridMap g) {
+    static_assert(std::is_same<T, CT>::value, "operands and result share one dtype (fp64 sums of fp32 products are formed by the callers)");
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     gp_ctx::GemmRec rec{};
     const bool timed = c->time_kernels != 0;
@@ -210,76 +210,59 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         rec.stream = (s == c->sp || (s == c->sp_mask && s));
         HIPCHK(hipEventRecord(rec.a, s));
     }
-    if (c->gemm_variant == 0) {
-        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
-        const long tm = (M + 127) / 128, tn = (N + 127) / 128;
-        const bool single_lower = g.lower && g.P == 1 && g.Q == 1 && g.row0 >= g.col0;
-        const long dt = single_lower ? (g.row0 - g.col0 + 127) / 128 : 0;
-        g.tm = (int)tm;
-        g.tn = (int)tn;
-        g.dt = (int)dt;
-        if (c->xcd_swizzle && tm * tn >= c->xcd_min_tiles) {  // XCD-aware 8×8 super-tile order (kernels.hpp xcd_tile)
-            const long tms = (tm + 7) / 8, tns = (tn + 7) / 8, dts = (dt + 7) / 8;
-            long nsuper;
-            if (single_lower) {
-                const long tri = std::min(tms, std::max(0L, tns - dts));
-                nsuper = tri * (dts + 1) + tri * (tri - 1) / 2 + (tms - tri) * tns;
-                g.compact = 3;
-            } else {
-                nsuper = tms * tns;
-                g.compact = 2;
-            }
-            grid = dim3((unsigned)(round_up(nsuper, 8) * 64), 1);
-        } else if (single_lower) {  // enumerate only the tiles on/below the diagonal
-            const long tri = std::min(tm, std::max(0L, tn - dt));
-            const long total = tri * (dt + 1) + tri * (tri - 1) / 2 + (tm - tri) * tn;
-            g.compact = 1;
-            grid = dim3((unsigned)total, 1);
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+    const long tm = (M + 127) / 128, tn = (N + 127) / 128;
+    const bool single_lower = g.lower && g.P == 1 && g.Q == 1 && g.row0 >= g.col0;
+    const long dt = single_lower ? (g.row0 - g.col0 + 127) / 128 : 0;
+    g.tm = (int)tm;
+    g.tn = (int)tn;
+    g.dt = (int)dt;
+    if (c->xcd_swizzle && tm * tn >= c->xcd_min_tiles) {  // XCD-aware 8×8 super-tile order (kernels.hpp xcd_tile)
+        const long tms = (tm + 7) / 8, tns = (tn + 7) / 8, dts = (dt + 7) / 8;
+        long nsuper;
+        if (single_lower) {
+            const long tri = std::min(tms, std::max(0L, tns - dts));
+            nsuper = tri * (dts + 1) + tri * (tri - 1) / 2 + (tms - tri) * tns;
+            g.compact = 3;
+        } else {
+            nsuper = tms * tns;
+            g.compact = 2;
         }
-        if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
-        if (kmajor)
-            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
-                               (int)N, (int)K, g);
-        else if ((c->gemm_streamk || c->sk_scope > 0) && c->gemm_dma && std::is_same<T, CT>::value && !g.beta0 && !g.ktri && g.nbatch <= 1 &&
-                 g.P == 1 && g.Q == 1 && g.compact <= 1 &&
-                 (g.compact == 1 ? (long)grid.x : tm * tn) <= c->sk_max_tiles) {
-            // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
-            const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
-            const long ntiles = g.compact == 1 ? (long)grid.x : tm * tn;
-            const long Gmax = 2L * (s == c->sm_mask && s ? c->num_cus - c->mask_r : (s == c->sp_mask && s ? c->mask_r : c->num_cus));
-            const long G = Gmax;  // fewer tiles than workgroups: every tile is cut along k
-            const long R = ntiles - (ntiles / G) * G;
-            // tail shares: never fewer workgroups than tail tiles; beyond that at least 16 k-steps per share
-            long G2 = std::min(G, std::max(R, R * nk / 16));
-            if (R == 0) G2 = 0;
-            hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
-                               (int)K, g, ntiles, (int)G2);
-        } else if ((c->gemm_dma || g.beta0 || g.ktri || g.nbatch > 1) && std::is_same<T, CT>::value) {
-            // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
-            // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
-            // request of 20 KiB on top of the 64 KiB static image pins that.  "gemm_pad_lds" overrides both.
-            const long pad = c->gemm_pad_user ? c->gemm_pad_lds : (sizeof(T) == 4 ? 20480 : 0);
-            if (pad > 0 && !c->gemm_pad_set) {
-                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
-                HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
-                c->gemm_pad_set = true;
-            }
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), (size_t)pad, s, C, ldc, A, lda, B, ldb,
-                               (int)M, (int)N, (int)K, g);
-        }
-        else
-            hipLaunchKernelGGL((gemm_nt_sub_kernel<T, false, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
-                               (int)N, (int)K, g);
+        grid = dim3((unsigned)(round_up(nsuper, 8) * 64), 1);
+    } else if (single_lower) {  // enumerate only the tiles on/below the diagonal
+        const long tri = std::min(tm, std::max(0L, tn - dt));
+        const long total = tri * (dt + 1) + tri * (tri - 1) / 2 + (tm - tri) * tn;
+        g.compact = 1;
+        grid = dim3((unsigned)total, 1);
+    }
+    if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
+    if ((c->gemm_streamk || c->sk_scope > 0) && !g.beta0 && !g.ktri && g.nbatch <= 1 && g.P == 1 && g.Q == 1 && g.compact <= 1 &&
+        (g.compact == 1 ? (long)grid.x : tm * tn) <= c->sk_max_tiles) {
+        // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
+        const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
+        const long ntiles = g.compact == 1 ? (long)grid.x : tm * tn;
+        const long Gmax = 2L * (s == c->sm_mask && s ? c->num_cus - c->mask_r : (s == c->sp_mask && s ? c->mask_r : c->num_cus));
+        const long G = Gmax;  // fewer tiles than workgroups: every tile is cut along k
+        const long R = ntiles - (ntiles / G) * G;
+        // tail shares: never fewer workgroups than tail tiles; beyond that at least 16 k-steps per share
+        long G2 = std::min(G, std::max(R, R * nk / 16));
+        if (R == 0) G2 = 0;
+        hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                           (int)K, g, ntiles, (int)G2);
     } else {
-        dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16));
-        if (kmajor)
-            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, true, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb, (int)M,
-                               (int)N, (int)K, g);
-        else
-            hipLaunchKernelGGL((gemm_nt_sub_ref_kernel<T, false, CT>), grid, dim3(256), 0, s, C, ldc, A, lda, B, ldb,
-                               (int)M, (int)N, (int)K, g);
+        // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
+        // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
+        // request of 20 KiB on top of the 64 KiB static image pins that.  "gemm_pad_lds" overrides both.
+        const long pad = c->gemm_pad_user ? c->gemm_pad_lds : (sizeof(T) == 4 ? 20480 : 0);
+        if (pad > 0 && !c->gemm_pad_set) {
+            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+            c->gemm_pad_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), (size_t)pad, s, C, ldc, A, lda, B, ldb,
+                           (int)M, (int)N, (int)K, g);
     }
     HIPCHK(hipGetLastError());
     if (timed) {
@@ -337,25 +320,10 @@ static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, lo
 template <typename T>
 static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long n, long mtot, int* info_dev,
                          long gcol0, long n_valid, double* logdet_dev) {
-    if (n <= 64 && c->panel_fused) return launch_leaf<T>(c, s, A, lda, j0, mtot, info_dev, gcol0, n_valid, logdet_dev, 0);
-    if (c->panel_fused && n <= c->leaf_group) {  // left-looking group: leaf t first applies the t tiles to its left itself
+    if (n <= 64) return launch_leaf<T>(c, s, A, lda, j0, mtot, info_dev, gcol0, n_valid, logdet_dev, 0);
+    if (n <= c->leaf_group) {  // left-looking group: leaf t first applies the t tiles to its left itself
         for (long t = 0; t < n / 64; ++t)
             RC(launch_leaf<T>(c, s, A, lda, j0 + 64 * t, mtot, info_dev, gcol0, n_valid, logdet_dev, (int)t));
-        return 0;
-    }
-    if (n <= 64) {
-        T* d = A + j0 * lda + j0;
-        if (!c->lt_ws) HIPCHK(hipMalloc(&c->lt_ws, sizeof(double) * 64 * 64));
-        const long mrows = mtot - j0 - 64;
-        T* lt = mrows > 0 ? (T*)c->lt_ws : (T*)nullptr;
-        hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(64), 0, s, d, lda, info_dev, (int)(gcol0 + j0),
-                           (int)n_valid, logdet_dev, lt);
-        HIPCHK(hipGetLastError());
-        if (mrows > 0) {
-            hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((mrows + 63) / 64)), dim3(64), 0, s,
-                               A + (j0 + 64) * lda + j0, lda, (int)mrows, d, lda, (const T*)lt);
-            HIPCHK(hipGetLastError());
-        }
         return 0;
     }
     const long h = split_half(n);
@@ -366,18 +334,7 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
     return 0;
 }
 
-// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n multiple of 64, M multiple of 64), all-MFMA:
-// W_j = I − inv(L_jj) for every 64×64 diagonal tile (trtri_64, batched), then recursively
-//   left half;  X_right −= X_left · L_21ᵀ;  right half;   base case X_j ← X_j − X_j W_jᵀ (in-place gemm).
-template <typename T>
-static int32_t trsm_rec_w(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n, const T* W) {
-    if (n <= 64) return launch_gemm<T>(c, s, X, ldx, X, ldx, W, 64, M, 64, 64, plain_map(0, 0, 0));
-    const long h = split_half(n);
-    RC(trsm_rec_w<T>(c, s, X, ldx, M, L, ldl, h, W));
-    RC(launch_gemm<T>(c, s, X + h, ldx, X, ldx, L + h * ldl, ldl, M, n - h, h, plain_map(0, 0, 0)));
-    RC(trsm_rec_w<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h, W + (h / 64) * 4096));
-    return 0;
-}
+// W_j = I − inv(L_jj) for every 64×64 diagonal tile of a lower factor (one batched launch; the 64-wide steps of the vector solves)
 template <typename T> static int32_t trtri_tiles(gp_ctx* c, hipStream_t s, const T* L, long ldl, long n, T** Wout) {
     const size_t need = sizeof(T) * (size_t)(n / 64 + 2) * 4096;  // + slack tiles (B-operand over-read of gemm_nt)
     if (c->w_ws_bytes < need) {
@@ -394,20 +351,18 @@ template <typename T> static int32_t trtri_tiles(gp_ctx* c, hipStream_t s, const
     *Wout = (T*)c->w_ws;
     return 0;
 }
-// 64-wide TRSM leaf: MFMA kernel (trsm64_mfma, one workgroup per 128 rows) or the VALU kernel (one lane per row)
+// 64-wide TRSM leaf on the matrix pipe (trsm64_mfma, one workgroup per 128 rows)
 template <typename T>
 static int32_t launch_trsm64(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl) {
+    (void)c;
     if (M <= 0) return 0;
-    if (c->trsm_leaf_mfma)
-        hipLaunchKernelGGL(trsm64_mfma_kernel<T>, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, X, ldx, (int)M, L, ldl);
-    else
-        hipLaunchKernelGGL(trsm_64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, X, ldx, (int)M, L, ldl,
-                           (const T*)nullptr);
+    hipLaunchKernelGGL(trsm64_mfma_kernel<T>, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, X, ldx, (int)M, L, ldl);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-// VALU base case (trsm_64, one lane per row): faster when nothing else runs, starves beside fp64 MFMA kernels.
+// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n, M multiples of 64): left half; X_right −= X_left · L_21ᵀ (MFMA GEMM);
+// right half; 64-wide leaves by trsm64_mfma.
 template <typename T>
 static int32_t trsm_rec_v(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
     if (n <= 64) return launch_trsm64<T>(c, s, X, ldx, M, L, ldl);
@@ -431,74 +386,21 @@ static int32_t trsm_upper_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, const T*
 }
 
 template <typename T>
-static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n,
-                        int force_mfma = -1) {
+static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
     if (M <= 0) return 0;
-    const bool mfma = force_mfma >= 0 ? force_mfma != 0 : c->trsm_mfma != 0;
-    if (!mfma) return trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, n);
-    T* W = nullptr;
-    RC(trtri_tiles<T>(c, s, L, ldl, n, &W));
-    return trsm_rec_w<T>(c, s, X, ldx, M, L, ldl, n, W);
+    return trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, n);
 }
 
-// Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows).  Right-looking over panels
-// of width nb.  Per panel k:  diag(k) = recursive Cholesky of the nb×nb diagonal block (fp64 VALU kernels —
-// issued on the main stream while no MFMA kernel runs: on gfx950 fp64 VALU work co-resident with fp64 MFMA
-// waves starves);  rows_below(k) = X ← X L_kk⁻ᵀ for all rows under it, all-MFMA (trsm_rec), on the panel
-// stream, overlapped with the bulk of the previous trailing update:
-//   main : diag(0) | U2(k−1) ............ | U1a(k) diag(k+1) U1b(k) | U2(k) ....
-//   panel:         | trtri(k) rows_below(k)|                         | trtri(k+1) rows_below(k+1)
-// U1a/U1b(k) = update of panel k+1's columns by panel k (diagonal block / rows below), U2(k) = the rest.
+// Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows): right-looking over panels of width nb with a
+// one-panel look-ahead (potrf_full_la below); nb = 0: the plain recursion on one stream.
 template <typename T>
 static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid, double* logdet_dev);
 
 template <typename T>
 static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
                           double* logdet_dev) {
-    long nb = c->nb;
-    if (nb <= 0) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
-    if (c->sched == 0) return potrf_full_la<T>(c, A, lda, np, mtot, info_dev, n_valid, logdet_dev);
-    nb = std::min(round_up(nb, 128), np);
-    const bool la = c->lookahead != 0;
-    hipStream_t sP = la ? c->sp : c->sm;
-    hipEvent_t ev_ready = nullptr, ev_panel = nullptr;
-    RC(potrf_rec<T>(c, c->sm, A, lda, 0, nb, nb, info_dev, 0, n_valid, logdet_dev));  // diag(0)
-    long kprev = -1, nbprev = 0;
-    for (long k = 0; k < np; k += nb) {
-        const long nbk = std::min(nb, np - k), k1 = k + nbk;
-        // ---- rows_below(k) on the panel stream
-        if (mtot > k1) {
-            if (la) {
-                RC(ctx_event(c, &ev_ready, false));
-                HIPCHK(hipEventRecord(ev_ready, c->sm));
-                HIPCHK(hipStreamWaitEvent(sP, ev_ready, 0));
-            }
-            RC(trsm_rec<T>(c, sP, A + k1 * lda + k, lda, mtot - k1, A + k * lda + k, lda, nbk, 1));
-            if (la) {
-                RC(ctx_event(c, &ev_panel, false));
-                HIPCHK(hipEventRecord(ev_panel, sP));
-            }
-        }
-        // ---- meanwhile: the bulk of the previous panel's trailing update (columns right of panel k)
-        if (kprev >= 0 && k1 < np)
-            RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + kprev, lda, A + k1 * lda + kprev, lda,
-                              mtot - k1, np - k1, nbprev, plain_map(1, k1, k1)));
-        if (la && mtot > k1) HIPCHK(hipStreamWaitEvent(c->sm, ev_panel, 0));
-        if (k1 < np) {
-            const long nb1 = std::min(nb, np - k1), k2 = k1 + nb1;
-            // U1a(k): diagonal block of panel k+1
-            RC(launch_gemm<T>(c, c->sm, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, nb1, nb1,
-                              nbk, plain_map(1, k1, k1)));
-            RC(potrf_rec<T>(c, c->sm, A, lda, k1, nb1, k2, info_dev, 0, n_valid, logdet_dev));  // diag(k+1)
-            // U1b(k): rows below it
-            if (mtot > k2)
-                RC(launch_gemm<T>(c, c->sm, A + k2 * lda + k1, lda, A + k2 * lda + k, lda, A + k1 * lda + k, lda,
-                                  mtot - k2, nb1, nbk, plain_map(0, 0, 0)));
-        }
-        kprev = k;
-        nbprev = nbk;
-    }
-    return 0;
+    if (c->nb <= 0) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    return potrf_full_la<T>(c, A, lda, np, mtot, info_dev, n_valid, logdet_dev);
 }
 
 // CU-partitioned streams ("cu_split" = r > 0): the panel stream owns r CUs — mask bit i of hipExtStreamCreateWithCUMask is CU
@@ -1563,10 +1465,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "nb")) c->nb = (v <= 0) ? 0 : round_up(v, 128);
     else if (!strcmp(name, "lookahead")) c->lookahead = v != 0;
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
-    else if (!strcmp(name, "gemm_variant")) c->gemm_variant = (int)v;
-    else if (!strcmp(name, "sched")) c->sched = (int)v;
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
-    else if (!strcmp(name, "gemm_dma")) c->gemm_dma = v != 0;
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
     else if (!strcmp(name, "sk_u1")) c->sk_u1 = v != 0;
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
@@ -1574,12 +1473,9 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
         c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
         c->gemm_pad_user = true;
     }
-    else if (!strcmp(name, "panel_fused")) c->panel_fused = v != 0;
-    else if (!strcmp(name, "trsm_leaf_mfma")) c->trsm_leaf_mfma = v != 0;
     else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
-    else if (!strcmp(name, "trsm_mfma")) c->trsm_mfma = v != 0;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
     else if (!strcmp(name, "vfe_ks")) c->vfe_ks = std::max<int64_t>(512, round_up(v, 512));
     else if (!strcmp(name, "vfe_sk")) c->vfe_sk = v != 0;
@@ -2344,15 +2240,6 @@ int32_t gpd_gemm_nt(gp_ctx* c, double* cm, int64_t ldc, const double* a, int64_t
     std::lock_guard<std::mutex> l(c->mu);
     HIPCHK(hipSetDevice(c->device));
     return launch_gemm<double>(c, c->sm, cm, ldc, a, lda, b, ldb, m, n, k, to_map(g, row0, col0));
-}
-
-int32_t gpd_gemm_tn(gp_ctx* c, double* cm, int64_t ldc, const double* a, int64_t lda, const double* b, int64_t ldb,
-                    int64_t m, int64_t n, int64_t k, int32_t lower) {
-    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
-    if (m % 64 || n % 64 || k % 16) return set_arg_err(8, "m, n multiples of 64 and k multiple of 16 required");
-    std::lock_guard<std::mutex> l(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    return launch_gemm<double>(c, c->sm, cm, ldc, a, lda, b, ldb, m, n, k, plain_map(lower != 0, 0, 0), true);
 }
 
 int32_t gpd_trsv(gp_ctx* c, const double* lmat, int64_t ldl, int64_t np, double* r, int64_t ldr, int32_t nrhs,

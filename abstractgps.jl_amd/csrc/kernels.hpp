@@ -7,9 +7,9 @@
 //
 // Kernels (reference call site each one replaces):
 //   kmat_kernel        KernelFunctions.kernelmatrix (+ Σy on the diagonal)   src/base_gp.jl:70,74; src/finite_gp_projection.jl:133-136
-//   gemm_nt_sub_kernel the SYRK/GEMM trailing update inside LAPACK dpotrf/dtrsm (MFMA)  src/finite_gp_projection.jl:308
-//   potf2_64_kernel    unblocked dpotf2 of a 64×64 diagonal tile + Σ log L_ii   :308, :310
-//   trsm_64_kernel     X ← X L⁻ᵀ against a 64×64 tile (dtrsm)               src/util/common_covmat_ops.jl:54-60
+//   gemm_nt_dma_kernel / gemm_nt_sk_kernel  the SYRK/GEMM trailing update inside LAPACK dpotrf/dtrsm (MFMA)  src/finite_gp_projection.jl:308
+//   panel64_kernel     dpotf2 of a 64×64 diagonal tile + Σ log L_ii + X ← X L⁻ᵀ of the rows below it   :308, :310
+//   trsm64_mfma_kernel X ← X L⁻ᵀ against a 64×64 tile (dtrsm)               src/util/common_covmat_ops.jl:54-60
 //   trsv_*             forward / backward substitutions for vectors (dtrtrs/dpotrs)   src/exact_gpr_posterior.jl:33
 //   rowsumsq_kernel    sum(abs2, ·) reductions                              src/util/common_covmat_ops.jl:64-67
 //   kvec_kernel        K_*x α without materialising K_*x                    src/exact_gpr_posterior.jl:60-62
@@ -18,10 +18,6 @@
 #include "engine.hpp"
 #ifndef GPMI_GEMM_SCHED
 #define GPMI_GEMM_SCHED 1  // explicit MFMA / LDS interleave of the gemm k loop (sched_group_barrier)
-#endif
-#ifndef GPMI_POTF2_LDS
-#define GPMI_POTF2_LDS 2  // panel64, 16×16 block factorisation: 2 = four-column blocks (readlanes inside a block, one LDS publish per
-                          // block), 1 = one LDS publish per column, 0 = v_readlane only
 #endif
 #ifndef GPMI_ABL
 #define GPMI_ABL 0  // ablation switches of tools/gemm_ablate.hip (timing experiments only; 0 in the product build)
@@ -109,217 +105,12 @@ __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_nt_sub: C[M×N] -= A[M×K] · B[N×K]ᵀ    (all row-major)
-//   M, N multiples of 64; K multiple of 8*VEC (16 f64 / 32 f32).  128×128 block tile, 4 waves as
-//   2×2, each wave 64×64 = 4×4 MFMA 16×16 tiles (16 accumulators).  Operand tiles are staged
-//   global -> registers -> LDS, double-buffered, one barrier per K step.
-//   LDS image per operand and buffer: [8 chunks][128 rows] of 16 B; slot = row ^ f(chunk) with
-//   f(c) = (c&3) | (c&4 ? 12 : 0): conflict-free for the ds_read_b128 lane groups
-//   {0-3,12-15,20-27},... (MI355X_MICROARCH.md §LDS) AND for the 8-lane ds_write_b128 groups.
-//   Rows past M / N (M,N ≡ 64 mod 128) are over-read (allocations carry 128 slack rows) and
-//   their results are never stored.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_swz(int c) { return (c & 3) | ((c & 4) ? 12 : 0); }
-
-//   CT = double with T = float ("mixed"): C is fp64; the fp32 MFMA chain is flushed into fp64 accumulators every
-//   FLUSH k-steps (K = 256), so long reductions (the VFE SYRK over N data points) keep fp64-grade sums while the
-//   operands stream in fp32.
-template <typename T, bool KM, typename CT = T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_sub_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb,
-                                                              int M, int N, int K, GridMap g) {
-    using TR = Tr<T>;
-    constexpr bool MIX = !__is_same(T, CT);
-    constexpr int FLUSH = 8;
-    using chunk_t = typename TR::chunk_t;
-    using acc_t = typename TR::acc_t;
-    constexpr int VEC = TR::VEC;
-    constexpr int BK = 8 * VEC;
-
-    int bi = blockIdx.y, bj = blockIdx.x;
-    if (g.compact == 1) compact_tile(g, (int)blockIdx.x, bi, bj);
-    else if (g.compact >= 2) {
-        if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
-    }
-    const int m0 = bi * 128, n0 = bj * 128;
-    long gr0 = 0, gc0 = 0;
-    if (g.lower) {
-        gr0 = glob_idx(g.row0 + m0, g.nb, g.P, g.p);
-        gc0 = glob_idx(g.col0 + n0, g.nb, g.Q, g.q);
-        if (gc0 > gr0 + 127) return;  // whole tile above the diagonal (block-uniform)
-    }
-    __shared__ chunk_t As[2][8][128];
-    __shared__ chunk_t Bs[2][8][128];
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    bool active = (wr * 64 < M - m0) && (wc * 64 < N - n0);
-    if (g.lower && (gc0 + wc * 64 > gr0 + wr * 64 + 63)) active = false;
-
-    // staging map.  NT (KM=false): operands are [rows][k] with k contiguous; thread -> (chunk lp, rows lr + 32 i),
-    // one 16-B global load = one LDS chunk.  KM=true: operands are k-major, A[k][m] / B[k][n] with m / n
-    // contiguous (C -= AᵀB, e.g. the SYRK over data points of the VFE path); thread -> (chunk lp = tid>>5,
-    // VEC consecutive rows starting at (lq + 32 i)·VEC); VEC 16-B loads (k rows lp·VEC + r) are transposed
-    // VEC×VEC in registers into VEC LDS chunks.  Either way 4 chunks per operand per thread.
-    constexpr int NPASS = KM ? 128 / (32 * VEC) : 4;
-    constexpr int NLD = KM ? VEC : 1;
-    const int lp = KM ? (tid >> 5) : (tid & 7);
-    const int lr = KM ? (tid & 31) : (tid >> 3);
-    const int fsw = lds_swz(lp);
-    const T* Ag = KM ? A + (long)(lp * VEC) * lda + m0 + lr * VEC : A + (long)(m0 + lr) * lda + lp * VEC;
-    const T* Bg = KM ? B + (long)(lp * VEC) * ldb + n0 + lr * VEC : B + (long)(n0 + lr) * ldb + lp * VEC;
-    chunk_t ra[NPASS][NLD], rb[NPASS][NLD];
-    auto gload = [&](long kt) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i)
-#pragma unroll
-            for (int r = 0; r < NLD; ++r) {
-                if constexpr (KM) {
-                    ra[i][r] = *reinterpret_cast<const chunk_t*>(Ag + (kt * BK + r) * lda + 32 * VEC * i);
-                    rb[i][r] = *reinterpret_cast<const chunk_t*>(Bg + (kt * BK + r) * ldb + 32 * VEC * i);
-                } else {
-                    ra[i][r] = *reinterpret_cast<const chunk_t*>(Ag + (long)(32 * i) * lda + kt * BK);
-                    rb[i][r] = *reinterpret_cast<const chunk_t*>(Bg + (long)(32 * i) * ldb + kt * BK);
-                }
-            }
-    };
-
-    const int li = lane & 15, lg = lane >> 4;
-    // accumulators start at −C (the MFMA chain then yields A·Bᵀ − C; the epilogue stores the negation), so the
-    // C tile is read once up front, overlapped with the first operand loads, and the epilogue is store-only.
-    acc_t acc[4][4];
-    d4_t acc64[MIX ? 4 : 1][MIX ? 4 : 1];
-    CT* const Cw = C + (long)(m0 + wr * 64) * ldc + n0 + wc * 64 + li;
-    const CT* const Cr = active ? Cw : C + li;  // waves that store nothing preload from the (always valid) first tile:
-                                                // unconditional loads, no per-element branch
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const CT c0 = -Cr[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16];
-                if constexpr (MIX) {
-                    acc64[mt][nt][r] = c0;
-                    acc[mt][nt][r] = T(0);
-                } else {
-                    acc[mt][nt][r] = c0;
-                }
-            }
-
-    const int nk = K / BK;
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            if constexpr (KM) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    chunk_t ca, cb;
-#pragma unroll
-                    for (int r = 0; r < VEC; ++r) {
-                        ca[r] = ra[i][r][e];
-                        cb[r] = rb[i][r][e];
-                    }
-                    As[buf][lp][((lr + 32 * i) * VEC + e) ^ fsw] = ca;
-                    Bs[buf][lp][((lr + 32 * i) * VEC + e) ^ fsw] = cb;
-                }
-            } else {
-                As[buf][lp][(lr + 32 * i) ^ fsw] = ra[i][0];
-                Bs[buf][lp][(lr + 32 * i) ^ fsw] = rb[i][0];
-            }
-        }
-    };
-
-    gload(0);
-    sstore(0);
-    __syncthreads();
-
-    // Branch-free loop body (one basic block, so the MFMA / LDS / VMEM interleave below is what gets emitted):
-    //   global loads of tile kt+1 (the last iteration re-loads tile nk−1 and stores it into the idle buffer),
-    //   first half of the MFMAs, then the LDS stores of tile kt+1 spread between the MFMAs of the second half — a
-    //   ds_write_b128 costs ≈13 issue cycles, a v_mfma_f64_16x16x4 occupies the pipe for 64 — and one barrier.
-    //   Waves whose 64×64 sub-tile is not stored (above the diagonal / past the edge) still run the MFMAs.
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-#if !(GPMI_ABL & 1)
-        gload((kt + 1 < nk) ? kt + 1 : kt);
-#endif
-        chunk_t a[2][4], b[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 4 * h + lg;
-            const int fc = lds_swz(c);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[h][t] = As[cur][c][(wr * 64 + t * 16 + li) ^ fc];
-                b[h][t] = Bs[cur][c][(wc * 64 + t * 16 + li) ^ fc];
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[0][mt][v], b[0][nt][v], acc[mt][nt]);
-#if !(GPMI_ABL & 2)
-        sstore(cur ^ 1);
-#endif
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = TR::mfma(a[1][mt][v], b[1][nt][v], acc[mt][nt]);
-#if GPMI_GEMM_SCHED
-        // emitted order: 8 LDS reads, 16·VEC−4 MFMA, 8 LDS reads (second-half fragments), 4 MFMA, then
-        // {1 LDS store, 2·VEC MFMA} × 8 (NT staging: 8 stores per iteration)
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16 * VEC - 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x200, KM ? VEC : 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * VEC, 0);
-        }
-#endif
-        if constexpr (MIX) {
-            if ((kt % FLUSH) == FLUSH - 1) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc64[mt][nt][r] += (double)acc[mt][nt][r];
-                            acc[mt][nt][r] = T(0);
-                        }
-            }
-        }
-#if !(GPMI_ABL & 4)
-        __syncthreads();
-#endif
-    }
-
-    if (active) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    CT v;
-                    if constexpr (MIX) v = -(acc64[mt][nt][r] + (double)acc[mt][nt][r]);
-                    else v = -acc[mt][nt][r];
-                    Cw[(long)(mt * 16 + TR::crow(lane, r)) * ldc + nt * 16] = v;
-                }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// gemm_nt_dma: same contract as gemm_nt_sub<T, false> (C[M×N] -= A[M×K] · B[N×K]ᵀ, row-major, k contiguous), operand tiles
-//   moved global -> LDS by the LDS-DMA path (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass — in the
-//   register-staged kernel the 8 ds_write_b128 + lgkmcnt(0) + barrier tail of every k step cost ≈10 % of the MFMA pipe
-//   (tools/gemm_ablate.hip).
+// gemm_nt_dma: C[M×N] -= A[M×K] · B[N×K]ᵀ (all row-major, k contiguous; M, N multiples of 64, K multiple of 16 f64 / 32 f32).
+//   128×128 block tile, 4 waves as 2×2, each wave 64×64 = 4×4 MFMA 16×16 tiles (16 accumulators); rows past M / N
+//   (M, N ≡ 64 mod 128) are over-read (allocations carry 128 slack rows) and their results are never stored.  Operand tiles
+//   move global -> LDS by the LDS-DMA path (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass — in the
+//   register-staged predecessor (gemm_nt_sub, in the history at dbd752d) the 8 ds_write_b128 + lgkmcnt(0) + barrier tail of every
+//   k step cost ≈10 % of the MFMA pipe.
 //   LDS image per operand and buffer: 128 rows × 128 B, row-major (BK = 16 f64 / 32 f32 = 8 chunks of 16 B).  One
 //   wave-instruction fills 1 KiB = 8 whole rows: lane l writes slot l (the DMA destination is base + 16·lane) and
 //   FETCHES chunk (l&7) ^ swz(row) of global row (l>>3), swz(r) = (r>>1)&7 — the XOR lives on the source address.
@@ -662,24 +453,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sk_kernel(T* C, long ldc, cons
     }
 }
 
-// Debug reference (gemm_variant = 1): same contract, plain VALU, one thread per C element.
-template <typename T, bool KM, typename CT = T>
-__global__ __launch_bounds__(256) void gemm_nt_sub_ref_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
-                                                               int N, int K, GridMap g) {
-    const int col = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int row = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (row >= M || col >= N) return;
-    if (g.lower) {
-        const long gr = glob_idx(g.row0 + row, g.nb, g.P, g.p), gc = glob_idx(g.col0 + col, g.nb, g.Q, g.q);
-        // mirror the MFMA kernel's coverage: it updates whole 64×64 wave tiles touching the diagonal
-        if ((gc / 64) * 64 > (gr / 64) * 64 + 63) return;
-    }
-    CT s = 0;
-    for (int k = 0; k < K; ++k)
-        s += KM ? A[(long)k * lda + row] * B[(long)k * ldb + col] : A[(long)row * lda + k] * B[(long)col * ldb + k];
-    C[(long)row * ldc + col] -= s;
-}
-
 // ------------------------------------------------------------------------------------------------
 // kmat: out[r][c] = variance * κ(‖xr_r − xc_c‖) (+ noise_r on the global diagonal when sym)
 //   xr / xc: pre-scaled inputs, dimension-major [d][ldx], indexed by GLOBAL point index.
@@ -1019,13 +792,7 @@ __global__ __launch_bounds__(256) void noise_grad_kernel(const T* __restrict__ C
     if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// potf2_64: in-place lower Cholesky of one 64×64 tile by ONE wave; lane r keeps row r in registers.
-//   Right-looking: after column c is final, every lane updates its remaining columns with the
-//   column-c entries broadcast through LDS.  info (device int32): first failing global column
-//   (1-based) if a pivot is not > 0 (LAPACK dpotrf info), untouched otherwise.
-//   logdet_acc += Σ_c log L_cc over columns with global index < n_valid.
-// ------------------------------------------------------------------------------------------------
+// 1/√x at full precision (v_rsq estimate + Newton) and a lane broadcast by v_readlane — the serial chain of the tile factorisation
 template <typename T> __device__ __forceinline__ T fast_rsqrt(T x);
 template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
     double r = __builtin_amdgcn_rsq(x);       // v_rsq_f64 estimate
@@ -1050,89 +817,11 @@ template <> __device__ __forceinline__ float lane_bcast<float>(float v, int srcl
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srclane));
 }
 
-// Blocked by PB = 8 columns.  Inside a block every cross-lane value (pivot, the multipliers L[t][c] of the block's
-// own columns) travels by v_readlane with a constant lane index — the serial chain per column is
-// readlane -> rsqrt -> scale -> readlane -> fma, no LDS round trip; the finished 8 columns are parked in LDS as
-// colb[t][k] and applied to the columns right of the block as one rank-8 update (8 consecutive doubles per
-// broadcast read, i.e. ds_read_b128 ×4 per target column instead of 8 separate reads).
-template <typename T>
-__global__ __launch_bounds__(64) void potf2_64_kernel(T* __restrict__ A, long lda, int* __restrict__ info, int col0,
-                                                       int n_valid, double* __restrict__ logdet_acc,
-                                                       T* __restrict__ lt_ws) {
-    using chunk_t = typename Tr<T>::chunk_t;
-    constexpr int VEC = Tr<T>::VEC;
-    constexpr int PB = 8;
-    __shared__ __attribute__((aligned(16))) T colb[64][PB];
-    const int r = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);  // look-ahead: this wave shares SIMDs with fp64-MFMA gemm waves and must win issue slots
-    T a[64];
-    const chunk_t* row = reinterpret_cast<const chunk_t*>(A + (long)r * lda);
-#pragma unroll
-    for (int t = 0; t < 64 / VEC; ++t) {
-        const chunk_t v = row[t];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) a[VEC * t + e] = v[e];
-    }
-    int bad = 0;
-    T mydiag = T(1), myrinv = T(1);
-#pragma unroll
-    for (int c0 = 0; c0 < 64; c0 += PB) {
-#pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            const int c = c0 + k;
-            const T piv = lane_bcast<T>(a[c], c);
-            if (!(piv > T(0)) && bad == 0) bad = c + 1;
-            const T ri = fast_rsqrt<T>(piv);  // 1 / L_cc
-            const T dd = piv * ri;            // L_cc
-            const T v = (r == c) ? dd : a[c] * ri;
-            a[c] = v;
-            if (r == c) {
-                mydiag = dd;
-                myrinv = ri;
-            }
-            colb[r][k] = v;
-#pragma unroll
-            for (int t = c + 1; t < c0 + PB; ++t) a[t] = fma(-v, lane_bcast<T>(v, t), a[t]);
-        }
-        if (c0 + PB < 64) {
-            __syncthreads();
-#pragma unroll
-            for (int t = c0 + PB; t < 64; ++t) {
-                T cb[PB];
-#pragma unroll
-                for (int q = 0; q < PB / VEC; ++q) {
-                    const chunk_t cv = *reinterpret_cast<const chunk_t*>(&colb[t][q * VEC]);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) cb[q * VEC + e] = cv[e];
-                }
-                T s = a[t];
-#pragma unroll
-                for (int k = 0; k < PB; ++k) s = fma(-a[c0 + k], cb[k], s);
-                a[t] = s;
-            }
-            __syncthreads();
-        }
-    }
-    T* wrow = A + (long)r * lda;
-#pragma unroll
-    for (int t = 0; t < 64; ++t)
-        if (t <= r) wrow[t] = a[t];
-    if (lt_ws != nullptr) {  // Lᵀ for trsm_64: lt[c][r] = L[r][c] (r > c), 1/L_cc on the diagonal, 0 above
-#pragma unroll
-        for (int c = 0; c < 64; ++c) lt_ws[c * 64 + r] = (c < r) ? a[c] : ((c == r) ? myrinv : T(0));
-    }
-    double ldsum = (col0 + r < n_valid) ? log((double)mydiag) : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ldsum += __shfl_xor(ldsum, o, 64);
-    if (r == 0) {
-        if (logdet_acc) atomicAdd(logdet_acc, ldsum);
-        if (bad && info && *info == 0) *info = col0 + bad;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // panel64: ONE launch per 64-column leaf of the panel factorisation — Cholesky of the 64×64 diagonal tile AND
-//   X ← X L⁻ᵀ for every row below it (replaces potf2_64 + trsm_64 and their dependent-launch gap).
+//   X ← X L⁻ᵀ for every row below it (one launch instead of a tile factorisation + a triangular solve and their dependent-launch gap).
+//   info (device int32): first failing global column (1-based) if a pivot is not > 0 (LAPACK dpotrf info), untouched otherwise;
+//   logdet_acc += Σ_c log L_cc over columns with global index < n_valid.
 //   grid = ceil(mrows / 128) workgroups (at least 1) of 4 waves; workgroup b owns rows [64 + 128 b, +128) under the
 //   tile.  EVERY workgroup factors the diagonal tile itself, redundantly and bit-identically, in LDS — the serial
 //   chain costs latency, not throughput, so replicating it is free and removes the global hand-off.  The input tile
@@ -1165,9 +854,8 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     __shared__ __attribute__((aligned(16))) T Ds[64 * LD];
     __shared__ __attribute__((aligned(16))) T Xs[XR * LD];
     __shared__ T Inv[4][16 * LI];
-    __shared__ T Lc[16 * LI];  // columns of the 16×16 block being factored (GPMI_POTF2_LDS 1)
     constexpr int LI2 = sizeof(T) == 8 ? 18 : 20;  // row pitch of Lr: a multiple of 16 B
-    __shared__ __attribute__((aligned(16))) T Lr[16 * LI2];  // rows of the 16×16 block being factored (GPMI_POTF2_LDS 2)
+    __shared__ __attribute__((aligned(16))) T Lr[16 * LI2];  // rows of the 16×16 block being factored
     __shared__ int writer_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #ifdef GPMI_PANEL_STAMPS
@@ -1318,7 +1006,6 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
     };
     // wave 0 only: factor the 16×16 diagonal block j (L16 into Ds, inv(L16) into Inv[j])
     auto factor16 = [&](int j) {
-#if GPMI_POTF2_LDS == 2
             // Four-column blocks.  The serial chain is pivot -> rsqrt -> scale -> next pivot; everything a later pivot of the SAME
             // block (and the first pivot of the next block) needs travels by v_readlane, so no LDS round trip sits on that chain.
             // After a block the four finished entries of every row are published ONCE (Lr[row][c0..c0+3], 32 B per lane) and the
@@ -1407,75 +1094,6 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
                     Inv[j][c * LI + li] = x[c];
                 }
             }
-#elif GPMI_POTF2_LDS
-            // lane = row (factor) and lane = column (inverse); the finished column c is published in LDS (Lc[c][·]) and
-            // every multiplier L[t][c] / L[c][k] is an LDS broadcast read — ~10 instructions per column instead of
-            // ~30 v_readlane pairs; only the pivot travels by readlane
-            T a[16], x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = Ds[(16 * j + li) * LD + 16 * j + c];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const T piv = lane_bcast<T>(a[c], c);
-                if (!(piv > T(0)) && bad == 0) bad = 16 * j + c + 1;
-                const T ri = fast_rsqrt<T>(piv);
-                const T dd = piv * ri;
-                const T v = (li == c) ? dd : a[c] * ri;
-                a[c] = v;
-                if (li == c) mydiag[j] = dd;
-                Lc[c * LI + li] = v;  // column c of L16 (rows >= c valid)
-                // the next pivot only needs a[c+1]: its multiplier travels by readlane (short critical path), the rest
-                // of the row update and the inverse read the published column from LDS
-                if (c + 1 < 16) a[c + 1] = fma(-v, lane_bcast<T>(v, c + 1 < 16 ? c + 1 : 15), a[c + 1]);
-                T s0 = (li == c) ? T(1) : T(0), s1 = T(0);
-#ifndef GPMI_EXP_NOINV
-#pragma unroll
-                for (int k = 0; k < c; ++k) {  // L[c][k], k < c; two partial sums halve the dependent FMA chain
-                    if (k & 1) s1 = fma(-Lc[k * LI + c], x[k], s1);
-                    else s0 = fma(-Lc[k * LI + c], x[k], s0);
-                }
-#endif
-                x[c] = (s0 + s1) * ri;
-#ifndef GPMI_EXP_NOUPD
-#pragma unroll
-                for (int t = c + 2; t < 16; ++t) a[t] = fma(-v, Lc[c * LI + t], a[t]);  // L[t][c]
-#endif
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c <= li) Ds[(16 * j + li) * LD + 16 * j + c] = a[c];
-                    Inv[j][c * LI + li] = x[c];
-                }
-            }
-#else
-            T a[16], x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = Ds[(16 * j + li) * LD + 16 * j + c];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const T piv = lane_bcast<T>(a[c], c);
-                if (!(piv > T(0)) && bad == 0) bad = 16 * j + c + 1;
-                const T ri = fast_rsqrt<T>(piv);
-                const T dd = piv * ri;
-                const T v = (li == c) ? dd : a[c] * ri;
-                a[c] = v;
-#pragma unroll
-                for (int t = c + 1; t < 16; ++t) a[t] = fma(-v, lane_bcast<T>(v, t), a[t]);
-                T sacc = (li == c) ? T(1) : T(0);
-#pragma unroll
-                for (int k = 0; k < c; ++k) sacc = fma(-lane_bcast<T>(a[k], c), x[k], sacc);
-                x[c] = sacc * ri;
-                if (li == c) mydiag[j] = dd;
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c <= li) Ds[(16 * j + li) * LD + 16 * j + c] = a[c];
-                    Inv[j][c * LI + li] = x[c];
-                }
-            }
-#endif
     };
     // one 16×16 task each: block TRSM  P ← P · Inv_jᵀ   and block update  C ← C − P · Qᵀ
     auto trsm_blk = [&](T* P, int j) {
@@ -1688,70 +1306,10 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(T* __restrict__ X, lon
 }
 
 // ------------------------------------------------------------------------------------------------
-// trsm_64: X[M×64] ← X · L⁻ᵀ, L 64×64 lower (row-major).  One lane per row of X (row in registers),
-//   one wave (64 rows) per block so that M = 65 536 rows spread as 4 waves per CU.  Lᵀ sits in LDS so the
-//   column of L needed after x_c is final is one contiguous broadcast read.  lt_pre (nullable): the
-//   transposed tile with reciprocal diagonal that potf2_64 just wrote (linear copy); otherwise it is
-//   built here from L.  M multiple of 64.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(64) void trsm_64_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L,
-                                                      long ldl, const T* __restrict__ lt_pre) {
-    using chunk_t = typename Tr<T>::chunk_t;
-    constexpr int VEC = Tr<T>::VEC;
-    __shared__ __attribute__((aligned(16))) T Lt[64][64];  // Lt[c][t] = L[t][c]; Lt[c][c] = 1/L[c][c]
-    const int tid = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);
-    if (lt_pre != nullptr) {
-        const chunk_t* src = reinterpret_cast<const chunk_t*>(lt_pre);
-        chunk_t* dst = reinterpret_cast<chunk_t*>(&Lt[0][0]);
-#pragma unroll 8
-        for (int e = tid; e < 64 * 64 / VEC; e += 64) dst[e] = src[e];
-    } else {
-        const chunk_t* lrow = reinterpret_cast<const chunk_t*>(L + (long)tid * ldl);
-#pragma unroll
-        for (int t = 0; t < 64 / VEC; ++t) {
-            const chunk_t v = lrow[t];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int c = VEC * t + e;
-                Lt[c][tid] = (c == tid) ? T(1) / v[e] : v[e];
-            }
-        }
-    }
-    __syncthreads();
-    const int row = blockIdx.x * 64 + tid;
-    if (row >= M) return;
-    chunk_t* xr = reinterpret_cast<chunk_t*>(X + (long)row * ldx);
-    T x[64];
-#pragma unroll
-    for (int t = 0; t < 64 / VEC; ++t) {
-        const chunk_t v = xr[t];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) x[VEC * t + e] = v[e];
-    }
-#pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        const T v = x[c] * Lt[c][c];
-        x[c] = v;
-#pragma unroll
-        for (int t = c + 1; t < 64; ++t) x[t] = fma(-v, Lt[c][t], x[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 64 / VEC; ++t) {
-        chunk_t v;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = x[VEC * t + e];
-        xr[t] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // trtri_64 (batched): W_j = I − inv(L_jj) for the 64×64 diagonal tiles j of a lower factor (one wave per tile).
 //   With it the 64-wide triangular solve becomes an in-place MFMA update  X_j ← X_j − X_j W_jᵀ = X_j L_jj⁻ᵀ
-//   (gemm_nt_sub with C = A = X_j, B = W_j), so no fp64 VALU kernel has to share SIMDs with the fp64 MFMA
-//   trailing update (on gfx950 both run on the same DP pipe and the VALU kernel starves).
-//   Lane i runs the substitution of trsm_64 on row e_i, i.e. ends up holding column i of inv(L).
+//   — what the vector solves' 64-wide steps use (trsv_diag*).  Lane i runs the forward substitution on row e_i, i.e. ends up
+//   holding column i of inv(L).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void trtri_64_kernel(const T* __restrict__ L, long ldl, T* __restrict__ W) {

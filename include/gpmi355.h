@@ -140,13 +140,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  * names at gp_ctx_create):
  *   "nb"             outer panel width (multiple of 128; 0 = purely recursive)            default 2048
  *   "lookahead"      next panel on a second, high-priority stream (0/1)                   default 1
- *   "sched"          0 whole-panel look-ahead, 1 diagonal-first with all-MFMA rows-below  default 0
  *   "time_kernels"   bracket every MFMA GEMM launch with HIP events (gp_get_timings)      default 0
- *   "gemm_variant"   0 = MFMA kernels, 1 = VALU debug reference                           default 0
- *   "gemm_dma"       NT GEMM operands by LDS-DMA (1) or register staging (0)              default 1
- *   "panel_fused"    fused 64-column leaf kernel (1) or potf2_64 + trsm_64 (0)            default 1
- *   "trsm_leaf_mfma" MFMA TRSM leaf (1) or VALU leaf (0)                                  default 1
- *   "trsm_mfma"      all-MFMA blocked TRSM through I − inv(L_jj) tiles                    default 0
  *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
  *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail on launches of <= sk_max_tiles tiles   default 1
  *                    (0 in the rank contexts of a multi-device ctx: "multi_gemm_streamk").  The tail adds its k-slices into C with
@@ -322,10 +316,6 @@ int32_t gpd_trsm(gp_ctx* ctx, double* x, int64_t ldx, int64_t m, const double* l
 int32_t gpd_gemm_nt(gp_ctx* ctx, double* c, int64_t ldc, const double* a, int64_t lda, const double* b,
                     int64_t ldb, int64_t m, int64_t n, int64_t k, const gp_grid* g_or_null, int64_t row0,
                     int64_t col0);
-/* C (m×n) -= Aᵀ · B with k-major operands: A is k×m, B is k×n (row-major) — the SYRK over data points of
- * the VFE path.  lower != 0: 64×64 sub-tiles strictly above the diagonal of C are skipped. */
-int32_t gpd_gemm_tn(gp_ctx* ctx, double* c, int64_t ldc, const double* a, int64_t lda, const double* b,
-                    int64_t ldb, int64_t m, int64_t n, int64_t k, int32_t lower);
 /* nrhs vectors stored as rows r[s*ldr + i], i < np: forward (L z = r) or backward (Lᵀ a = r) solve in place. */
 int32_t gpd_trsv(gp_ctx* ctx, const double* l, int64_t ldl, int64_t np, double* r, int64_t ldr, int32_t nrhs,
                  int32_t forward);
@@ -335,7 +325,7 @@ int32_t gpd_gemv_t(gp_ctx* ctx, const double* l, int64_t ldl, int64_t nrows, int
 /* out_dev[i] = Σ_{c<ncols} x[i*ldx + c]² for i < nrows. */
 int32_t gpd_rowsumsq(gp_ctx* ctx, const double* x, int64_t ldx, int64_t nrows, int64_t ncols, double* out_dev);
 int32_t gpd_sync(gp_ctx* ctx);
-/* With parameter "time_kernels" = 1 every gpd_gemm_nt / gpd_gemm_tn launch is bracketed by HIP events on the ctx
+/* With parameter "time_kernels" = 1 every gpd_gemm_nt launch is bracketed by HIP events on the ctx
  * stream.  This synchronises the stream, returns the summed launch durations (ms) and the launch count since the
  * previous call, and clears the records (the caller knows the algorithmic flops of its own launches). */
 int32_t gpd_gemm_time(gp_ctx* ctx, double* ms_out, int64_t* launches_out);

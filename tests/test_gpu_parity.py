@@ -111,33 +111,28 @@ def test_mid_size_parity(agp, n, d, kind, layout):
 
 
 def test_variants_agree(agp):
-    """MFMA gemm vs the VALU debug gemm, look-ahead on/off, recursive-only, both panel schedules, VALU vs
-    all-MFMA triangular solves: same answer."""
+    """Panel widths, look-ahead on/off, recursive-only, XCD-aware workgroup order, stream-K tails: same answer."""
     x, y = o.synth_inputs(3000, 3, 9)
     f = agp.GP(agp.SqExponentialKernel())
     ctx = agp.default_context()
     vals = []
+
+    def reset():  # (stream-K tails stay off for the tests that follow in this process: hardware-dispatched GEMMs, no atomics in the update)
+        ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("xcd_swizzle", 0)
+        ctx.set_param("xcd_min_tiles", 256), ctx.set_param("gemm_streamk", 0), ctx.set_param("leaf_group", 128)
+
     try:
-        for nb, la, var, sched, tm, extra in [(2048, 1, 0, 0, 0, {}), (1024, 0, 0, 0, 0, {}), (0, 0, 0, 0, 0, {}),
-                                              (1024, 1, 1, 0, 0, {}), (1024, 1, 0, 1, 0, {}), (512, 0, 0, 1, 1, {}),
-                                              (1024, 1, 0, 0, 1, {}), (1024, 1, 0, 0, 0, {"gemm_dma": 0}),
-                                              (1024, 1, 0, 0, 0, {"panel_fused": 0}),
-                                              (512, 1, 0, 0, 0, {"xcd_swizzle": 1, "xcd_min_tiles": 4}),
-                                              (512, 0, 0, 0, 0, {"gemm_dma": 0, "xcd_swizzle": 1, "xcd_min_tiles": 4}),
-                                              (1024, 1, 0, 0, 0, {"gemm_streamk": 1}), (0, 0, 0, 0, 0, {"gemm_streamk": 1}),
-                                              (1024, 1, 0, 0, 0, {"trsm_leaf_mfma": 0})]:
-            ctx.set_param("nb", nb), ctx.set_param("lookahead", la), ctx.set_param("gemm_variant", var)
-            ctx.set_param("sched", sched), ctx.set_param("trsm_mfma", tm)
+        for nb, la, extra in [(2048, 1, {"gemm_streamk": 1}), (1024, 0, {}), (0, 0, {}), (1024, 1, {"gemm_streamk": 1}), (512, 0, {}),
+                              (512, 1, {"xcd_swizzle": 1, "xcd_min_tiles": 4}),
+                              (512, 0, {"xcd_swizzle": 1, "xcd_min_tiles": 4, "gemm_streamk": 1}), (0, 0, {"gemm_streamk": 1}),
+                              (1024, 1, {"leaf_group": 64}), (1024, 1, {"leaf_group": 256, "gemm_streamk": 1})]:
+            ctx.set_param("nb", nb), ctx.set_param("lookahead", la)
             for kname, kval in extra.items():
                 ctx.set_param(kname, kval)
             vals.append(float(agp.logpdf(f(agp.RowVecs(x), 0.01), y)))
-            ctx.set_param("gemm_dma", 1), ctx.set_param("panel_fused", 1), ctx.set_param("xcd_swizzle", 0)
-            ctx.set_param("xcd_min_tiles", 256), ctx.set_param("gemm_streamk", 0), ctx.set_param("trsm_leaf_mfma", 1)
+            reset()
     finally:
-        ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("gemm_variant", 0)
-        ctx.set_param("sched", 0), ctx.set_param("trsm_mfma", 0)
-        ctx.set_param("gemm_dma", 1), ctx.set_param("panel_fused", 1), ctx.set_param("xcd_swizzle", 0)
-        ctx.set_param("xcd_min_tiles", 256), ctx.set_param("gemm_streamk", 0), ctx.set_param("trsm_leaf_mfma", 1)
+        reset()
     ref = float(o.logpdf(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y))
     for v in vals:
         assert v == pytest.approx(ref, rel=1e-10)

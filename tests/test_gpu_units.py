@@ -182,30 +182,6 @@ def test_rowsumsq(lib, h):
     np.testing.assert_allclose(out.cpu().numpy(), (X[:, :777] ** 2).sum(1).cpu().numpy(), rtol=1e-13)
 
 
-@pytest.mark.parametrize("m,n,k,lower", [(128, 128, 16, 0), (192, 320, 144, 0), (512, 512, 1024, 1)])
-def test_gemm_tn_kmajor(lib, h, m, n, k, lower):
-    """C -= AᵀB with k-major operands (the VFE SYRK over data points)."""
-    from abstractgps_jl_amd._lib import check
-
-    g = torch.Generator(device="cuda").manual_seed(m + n + k)
-    ld = max(m, n) + 32
-    A = torch.randn(k + 128, ld, dtype=torch.float64, device="cuda", generator=g)
-    B = A if lower else torch.randn(k + 128, ld, dtype=torch.float64, device="cuda", generator=g)
-    Cm = torch.randn(max(m, n) + 128, ld, dtype=torch.float64, device="cuda", generator=g)
-    ref = Cm.clone()
-    ref[:m, :n] -= A[:k, :m].T @ B[:k, :n]
-    torch.cuda.synchronize()
-    check(lib.gpd_gemm_tn(h, P(Cm), ld, P(A), ld, P(B), ld, m, n, k, lower))
-    _sync(lib, h)
-    if lower:
-        r = torch.arange(m, device="cuda")[:, None]
-        c = torch.arange(n, device="cuda")[None, :]
-        mask = c <= r
-        assert (Cm[:m, :n] - ref[:m, :n])[mask].abs().max().item() < 1e-10
-    else:
-        assert (Cm - ref).abs().max().item() < 1e-10
-
-
 @pytest.mark.parametrize("group", [64, 128, 256, 512])
 def test_potrf_leaf_groups(lib, h, group):
     """left-looking leaf groups: a leaf applies the kpre = 0..group/64−1 tiles to its left itself before factoring (64 = every

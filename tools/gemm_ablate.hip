@@ -1,12 +1,12 @@
-// Timing-only ablation of the MFMA trailing-update kernel: build with -DGPMI_ABL=<mask> (1: no global loads in the
-// k loop, 2: no LDS stores, 4: no barrier) to see which part of the loop the MFMA pipe waits for.  Results are wrong
-// by construction for mask != 0.   hipcc --offload-arch=gfx950 -O3 -DGPMI_ABL=1 tools/gemm_ablate.hip -o /tmp/abl1
+// Timing-only ablation of the MFMA trailing-update kernel (gemm_nt_dma): build with -DGPMI_ABL=<mask> (fp32 instantiation: 8 no
+// epilogue stores, 16 no operand DMA inside the k loop, 32 no wait + barrier at the end of a step) to see which part of the loop
+// the MFMA pipe waits for.  Results are wrong by construction for mask != 0.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPMI_ABL=16 tools/gemm_ablate.hip -o /tmp/abl16
+// (Masks 1 / 2 / 4 belonged to the register-staged predecessor of the kernel, removed in round 3: history at dbd752d.)
 #include "../abstractgps.jl_amd/csrc/kernels.hpp"
 #include <cstdio>
 #include <vector>
-#ifndef GPMI_DMA
-#define GPMI_DMA 0
-#endif
+#define GPMI_DMA 1
 #include <cstdlib>
 using namespace gpmi;
 int main(int argc, char** argv) {
@@ -32,13 +32,8 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-#if GPMI_DMA
         hipLaunchKernelGGL((gemm_nt_dma_kernel<double, double>), dim3((unsigned)total), dim3(256), 0, 0, C, ldc, A, lda, A, lda,
                            (int)M, (int)M, (int)K, g);
-#else
-        hipLaunchKernelGGL((gemm_nt_sub_kernel<double, false, double>), dim3((unsigned)total), dim3(256), 0, 0, C, ldc, A, lda, A, lda,
-                           (int)M, (int)M, (int)K, g);
-#endif
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--sizes", default="4096,16384")
     ap.add_argument("--nbs", default="0,1024,2048,4096")
     ap.add_argument("--big", type=int, default=0)
-    ap.add_argument("--params", default="", help="comma list name=value applied to the ctx (e.g. sched=1,trsm_mfma=1)")
+    ap.add_argument("--params", default="", help="comma list name=value applied to the ctx (e.g. nb=1024,leaf_group=256)")
     args = ap.parse_args()
     ctx = agp.Context(0)
     for kv in [t for t in args.params.split(",") if t]:
