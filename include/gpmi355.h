@@ -284,10 +284,12 @@ int64_t gp_vfe_m(gp_vfe* post); /* number of pseudo-points */
 int32_t gp_vfe_get(gp_vfe* post, void* alpha_out_or_null, void* m_eps_out_or_null);
 int32_t gp_vfe_free(gp_vfe* post);
 
-/* ---- device-level building blocks (multi-process 2D block-cyclic driver) -------------------- */
-/* All pointers below are DEVICE pointers (fp64), row-major with the given leading dimension, i.e.
+/* ---- device-level building blocks ------------------------------------------------------------ */
+/* The operations the in-library multi-device driver composes (csrc/multi.hip calls the same engine functions), exposed on DEVICE
+ * memory so that they can be unit-tested one by one (tests/test_gpu_units.py) and driven by a caller that keeps its own
+ * device-resident data.  All pointers below are DEVICE pointers (fp64), row-major with the given leading dimension, i.e.
  * a row-major lower factor L — memory-identical to Julia's column-major C.U.  Work is issued on the
- * ctx main stream and NOT synchronised (the caller orders it against its RCCL traffic).
+ * ctx main stream and NOT synchronised (gpd_sync, or order it against your own stream work).
  * m, n multiples of 128; k multiple of 16 (gemm) / 64 (trsm, potrf). */
 
 /* Fill local tiles of K + Σy.  rows: global indices row0 + i (i < m) mapped through the block-cyclic
