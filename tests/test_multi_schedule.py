@@ -94,6 +94,35 @@ def test_checker_needs_the_barrier_between_backward_sweeps_and_the_sweep_events(
     assert len(sinks) == 6 * 6 and all(ln["W"][0][0] == "A2" for ln in sinks)   # 6 new block rows (lcm) × 6 block columns, one owner each
 
 
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_update_pass_fills_every_new_block_exactly_once(grid):
+    """completeness of the sequential update's forward pass: block (nblk + t, k) of the extended factor — for every new block row t and
+    every old block column k — is written by exactly one rank, the block-cyclic owner ((nblk + t) mod P, k mod Q), into the right local
+    block of its new piece"""
+    import math
+
+    P, Q = grid
+    lcm = P * Q // math.gcd(P, Q)
+    for nblk_in in (1, 3, 7):
+        with __import__("tempfile").TemporaryDirectory() as td:
+            path = Path(td) / "t.jsonl"
+            M.emit_trace(P, Q, nblk_in, 0, COPIES, path, solve=2)
+            hdr, lines = M.load(path)
+        nblk = hdr["nblk"]
+        seen = {}
+        for ln in lines:
+            if ln["t"] == "op" and ln["n"] == "sink":
+                (name, r, a0, a1, b0, b1, fl), = ln["W"]
+                assert name == "A2" and a1 == a0 + 1 and b1 == b0 + 1
+                p, q = r // Q, r % Q
+                key = (a0 * P + p, b0 * Q + q)          # global (block row, block column) of the local block written
+                assert key not in seen, (grid, key)
+                seen[key] = r
+                k, t = ln["k"]
+                assert key == (nblk + t, k) and p == (nblk + t) % P and q == k % Q, (grid, ln)
+        assert set(seen) == {(nblk + t, k) for t in range(lcm) for k in range(nblk)}, grid
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):
