@@ -123,6 +123,37 @@ def test_update_pass_fills_every_new_block_exactly_once(grid):
         assert set(seen) == {(nblk + t, k) for t in range(lcm) for k in range(nblk)}, grid
 
 
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_solve_passes_visit_every_block_column_once_per_sweep(grid):
+    """completeness of `C \\ B` on the pieces: the forward pass forms every X_k once on the diagonal owner (k mod P, k mod Q) and
+    every rank of process column k mod Q applies it to its block rows below k; each of the two backward sweeps solves every
+    diagonal block once, on its owner, in descending order"""
+    P, Q = grid
+    for nblk_in in (2, 5):
+        with __import__("tempfile").TemporaryDirectory() as td:
+            path = Path(td) / "t.jsonl"
+            M.emit_trace(P, Q, nblk_in, 0, COPIES, path, solve=1 | 4)
+            hdr, lines = M.load(path)
+        nblk = hdr["nblk"]
+        ops = [ln for ln in lines if ln["t"] == "op"]
+        fwd = [(ln["k"][0], ln["r"]) for ln in ops if ln["n"] == "trsm"]
+        assert sorted(fwd) == [(k, (k % P) * Q + k % Q) for k in range(nblk)], grid
+        gemms = {}
+        for ln in ops:
+            if ln["n"] == "gemm":
+                gemms.setdefault(ln["k"][0], set()).add(ln["r"])
+        for k in range(nblk):   # the ranks of process column k mod Q that own a block row below k
+            want = {p * Q + k % Q for p in range(P) if any(i % P == p for i in range(k + 1, nblk))}
+            assert gemms.get(k, set()) == want, (grid, k)
+        for sweep in (0, 1):
+            bw = [(ln["k"][0], ln["r"]) for ln in ops if ln["n"] == "trsv" and ln["k"][1] == sweep]
+            assert sorted(bw) == [(k, (k % P) * Q + k % Q) for k in range(nblk)], (grid, sweep)
+            per_rank = {}
+            for k, r in bw:                      # (file order = issue order of a rank's thread)
+                per_rank.setdefault(r, []).append(k)
+            assert all(v == sorted(v, reverse=True) for v in per_rank.values()), (grid, sweep)
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):
