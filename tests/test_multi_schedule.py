@@ -154,6 +154,40 @@ def test_solve_passes_visit_every_block_column_once_per_sweep(grid):
             assert all(v == sorted(v, reverse=True) for v in per_rank.values()), (grid, sweep)
 
 
+@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_fit_updates_every_block_by_every_earlier_panel_exactly_once(grid, comm):
+    """completeness of the factorisation schedule (right-looking): block (i, j) of the lower triangle — and the right-hand-side
+    block row — is updated by every panel k < j exactly once, whichever stream (look-ahead or bulk) and look-ahead depth carries the
+    update, and is then finalised exactly once (Cholesky of the diagonal block / triangular solve of the rows below it)"""
+    P, Q = grid
+    for nblk_in, depth in ((1, 2), (4, 1), (5, 2), (9, 3)):
+        with __import__("tempfile").TemporaryDirectory() as td:
+            path = Path(td) / "t.jsonl"
+            M.emit_trace(P, Q, nblk_in, depth, comm, path)
+            hdr, lines = M.load(path)
+        nblk = hdr["nblk"]
+        upd, fin = {}, {}
+        for ln in lines:
+            if ln["t"] != "op" or ln["n"] not in ("la", "bulk", "potrf", "potrf_diag", "trsm"):
+                continue
+            for f in ln["W"]:
+                for key in M.expand(f, hdr):
+                    if key[0] != "A":
+                        continue
+                    _, r, li, lj = key
+                    gi = "rhs" if li == "rhs" else li * P + r // Q
+                    gj = lj * Q + r % Q
+                    if ln["n"] in ("la", "bulk"):
+                        upd.setdefault((gi, gj), []).append(ln["k"][1])       # k = [first target column, panel]
+                    else:
+                        fin.setdefault((gi, gj), []).append(ln["k"][0])
+        for j in range(nblk):
+            for i in list(range(j, nblk)) + ["rhs"]:
+                assert sorted(upd.get((i, j), [])) == list(range(j)), (grid, depth, (i, j), upd.get((i, j)))
+                assert fin.get((i, j)) == [j], (grid, depth, (i, j), fin.get((i, j)))
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):
