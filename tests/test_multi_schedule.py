@@ -188,6 +188,92 @@ def test_fit_updates_every_block_by_every_earlier_panel_exactly_once(grid, comm)
                 assert fin.get((i, j)) == [j], (grid, depth, (i, j), fin.get((i, j)))
 
 
+def _operand_dataflow(hdr, lines):
+    """-> (reads checked, findings): for every update (look-ahead / bulk GEMM of panel k) and every rows-below solve of panel k, the
+    LATEST write — in happens-before order — to each operand-buffer block it reads (A / B operand slots, the L_kk image) must be the
+    fetch of panel k's block.  (Race-freedom makes the writes to one block totally ordered, so "latest" is well defined.)"""
+    import re
+
+    g, problems = M.build(hdr, lines)
+    assert not problems and not M.races(g)
+    n = len(g.label)
+    succ, indeg = [[] for _ in range(n)], [0] * n
+    for i, ps in enumerate(g.preds):
+        for q in ps:
+            succ[q].append(i)
+            indeg[i] += 1
+    order, stack = [], [i for i in range(n) if indeg[i] == 0]
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        for j in succ[i]:
+            indeg[j] -= 1
+            if indeg[j] == 0:
+                stack.append(j)
+    reach = [0] * n
+    for i in order:
+        b = 0
+        for q in g.preds[i]:
+            b |= reach[q] | (1 << q)
+        reach[i] = b
+    writers = {}
+    for i in range(n):
+        for loc in g.wr[i]:
+            writers.setdefault(loc, []).append(i)
+    pat = re.compile(r"r(\d+)\.(\w+):(\w+)\((-?\d+),(-?\d+)\)")
+    checked, bad = 0, []
+    for i in range(n):
+        m = pat.match(g.label[i])
+        if not m or m.group(3) not in ("la", "bulk", "trsm"):
+            continue
+        panel = int(m.group(5)) if m.group(3) in ("la", "bulk") else int(m.group(4))
+        for loc in g.rd[i]:
+            if loc[0] not in ("Ab", "Bb", "Lkk"):
+                continue
+            cands = [w for w in writers.get(loc, []) if (reach[i] >> w) & 1]
+            if not cands:
+                bad.append((g.label[i], loc, "never written before"))
+                continue
+            last = max(cands, key=lambda w: bin(reach[w]).count("1"))
+            assert all(w == last or (reach[last] >> w) & 1 for w in cands)
+            mw = pat.match(g.label[last])
+            checked += 1
+            if not mw or mw.group(3) not in ("pullA", "pullB", "pull_lkk") or int(mw.group(4)) != panel:
+                bad.append((g.label[i], loc, g.label[last]))
+    return checked, bad
+
+
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_updates_consume_the_blocks_of_their_own_panel(grid):
+    """data flow of the traced schedule (copies transport): what an update of panel k reads from the operand slots — and what the
+    rows-below solve of panel k reads from the L_kk image — is what the fetch of PANEL k put there, never a neighbour's (the slots are
+    reused every depth + 1 steps); ordering alone (the race check) would not notice a stale-but-ordered slot"""
+    P, Q = grid
+    for nblk_in, depth in ((4, 1), (7, 2), (9, 3)):
+        with __import__("tempfile").TemporaryDirectory() as td:
+            path = Path(td) / "t.jsonl"
+            M.emit_trace(P, Q, nblk_in, depth, COPIES, path)
+            hdr, lines = M.load(path)
+        checked, bad = _operand_dataflow(hdr, lines)
+        assert not bad, (grid, depth, bad[:3])
+        assert checked > 0 or P * Q == 1
+
+
+def test_dataflow_check_notices_a_stale_slot():
+    """a fetch that never happens (rank 3's B-operand pulls of panel 5 removed from the trace): every later access is still ordered —
+    the events are all there — so the race check is silent, but the update of panel 5 now reads what panel 2 left in the slot"""
+    with __import__("tempfile").TemporaryDirectory() as td:
+        path = Path(td) / "t.jsonl"
+        M.emit_trace(2, 2, 9, 2, COPIES, path)
+        hdr, lines = M.load(path)
+    kept = [ln for ln in lines if not (ln["t"] == "op" and ln["n"] == "pullB" and ln["r"] == 3 and ln["k"][0] == 5)]
+    assert len(kept) < len(lines)
+    g, problems = M.build(hdr, kept)
+    assert not problems and not M.races(g)
+    checked, bad = _operand_dataflow(hdr, kept)
+    assert bad and all("(5," in b[0] or ",5)" in b[0] for b in bad) and any("pullB(2," in b[2] for b in bad), bad[:4]
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):
