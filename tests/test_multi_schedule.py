@@ -189,11 +189,14 @@ def test_fit_updates_every_block_by_every_earlier_panel_exactly_once(grid, comm)
 
 
 def _operand_dataflow(hdr, lines):
-    """-> (reads checked, findings): for every update (look-ahead / bulk GEMM of panel k) and every rows-below solve of panel k, the
-    LATEST write — in happens-before order — to each operand-buffer block it reads (A / B operand slots, the L_kk image) must be the
-    fetch of panel k's block.  (Race-freedom makes the writes to one block totally ordered, so "latest" is well defined.)"""
+    """-> (reads checked, findings): provenance of the operand buffers.  Every write into an operand-type buffer (A / B operand
+    slots, staging images, the L_kk image) gets the PANEL its data comes from: a copy out of the factor matrix carries the block
+    column it read; a copy between buffers, a send and its matched receive carry the panel of what they read (the LATEST write to
+    that block in happens-before order — race-freedom makes the writes to one block totally ordered).  Then every update of panel k
+    and every rows-below solve of panel k must read blocks that carry panel k."""
     import re
 
+    Q = hdr["Q"]
     g, problems = M.build(hdr, lines)
     assert not problems and not M.races(g)
     n = len(g.label)
@@ -220,6 +223,49 @@ def _operand_dataflow(hdr, lines):
     for i in range(n):
         for loc in g.wr[i]:
             writers.setdefault(loc, []).append(i)
+    OPERAND = ("Ab", "Bb", "St", "Lkk")
+
+    def latest_writer(i, loc):
+        cands = [w for w in writers.get(loc, []) if (reach[i] >> w) & 1]
+        if not cands:
+            return None
+        last = max(cands, key=lambda w: bin(reach[w]).count("1"))
+        assert all(w == last or (reach[last] >> w) & 1 for w in cands)
+        return last
+
+    tag = [None] * n          # panel carried by what node i writes into operand-type buffers
+    for i in order:
+        if not any(loc[0] in OPERAND for loc in g.wr[i]) or ":init(" in g.label[i]:
+            continue
+        if ":recv<-" in g.label[i]:
+            sends = [q for q in g.preds[i] if ":send->" in g.label[q]]
+            assert len(sends) == 1
+            tag[i] = tag[sends[0]]
+            continue
+        tags = set()
+        for loc in g.rd[i]:
+            if loc[0] == "A":
+                tags.add(loc[3] * Q + loc[1] % Q)          # global block column of a block of the factor matrix
+            elif loc[0] in OPERAND:
+                w = latest_writer(i, loc)
+                tags.add(None if w is None else tag[w])
+        tag[i] = tags.pop() if len(tags) == 1 else ("mixed", sorted(map(str, tags)))
+    for i in order:            # sends carry the panel of what they read (they write nothing themselves)
+        if ":send->" in g.label[i]:
+            tags = set()
+            for loc in g.rd[i]:
+                if loc[0] == "A":
+                    tags.add(loc[3] * Q + loc[1] % Q)
+                elif loc[0] in OPERAND:
+                    w = latest_writer(i, loc)
+                    tags.add(None if w is None else tag[w])
+            if tags:
+                tag[i] = tags.pop() if len(tags) == 1 else ("mixed", sorted(map(str, tags)))
+    # (receives were tagged before their sends in the loop above when the send reads operand buffers: one more pass settles them)
+    for i in order:
+        if ":recv<-" in g.label[i] and any(loc[0] in OPERAND for loc in g.wr[i]):
+            sends = [q for q in g.preds[i] if ":send->" in g.label[q]]
+            tag[i] = tag[sends[0]]
     pat = re.compile(r"r(\d+)\.(\w+):(\w+)\((-?\d+),(-?\d+)\)")
     checked, bad = 0, []
     for i in range(n):
@@ -230,29 +276,25 @@ def _operand_dataflow(hdr, lines):
         for loc in g.rd[i]:
             if loc[0] not in ("Ab", "Bb", "Lkk"):
                 continue
-            cands = [w for w in writers.get(loc, []) if (reach[i] >> w) & 1]
-            if not cands:
-                bad.append((g.label[i], loc, "never written before"))
-                continue
-            last = max(cands, key=lambda w: bin(reach[w]).count("1"))
-            assert all(w == last or (reach[last] >> w) & 1 for w in cands)
-            mw = pat.match(g.label[last])
+            w = latest_writer(i, loc)
             checked += 1
-            if not mw or mw.group(3) not in ("pullA", "pullB", "pull_lkk") or int(mw.group(4)) != panel:
-                bad.append((g.label[i], loc, g.label[last]))
+            if w is None or tag[w] != panel:
+                bad.append((g.label[i], loc, "never written before" if w is None else f"{g.label[w]} carrying panel {tag[w]}"))
     return checked, bad
 
 
+@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
 @pytest.mark.parametrize("grid", M.GRIDS)
-def test_updates_consume_the_blocks_of_their_own_panel(grid):
-    """data flow of the traced schedule (copies transport): what an update of panel k reads from the operand slots — and what the
-    rows-below solve of panel k reads from the L_kk image — is what the fetch of PANEL k put there, never a neighbour's (the slots are
-    reused every depth + 1 steps); ordering alone (the race check) would not notice a stale-but-ordered slot"""
+def test_updates_consume_the_blocks_of_their_own_panel(grid, comm):
+    """data flow of the traced schedule, both transports: what an update of panel k reads from the operand slots — and what the
+    rows-below solve of panel k reads from the L_kk image — came out of PANEL k of the factor matrix (through the peer copy, or
+    through the owner's staging image, the send and its matched receive), never a neighbour's (the slots are reused every depth + 1
+    steps); ordering alone (the race check) would not notice a stale-but-ordered slot"""
     P, Q = grid
     for nblk_in, depth in ((4, 1), (7, 2), (9, 3)):
         with __import__("tempfile").TemporaryDirectory() as td:
             path = Path(td) / "t.jsonl"
-            M.emit_trace(P, Q, nblk_in, depth, COPIES, path)
+            M.emit_trace(P, Q, nblk_in, depth, comm, path)
             hdr, lines = M.load(path)
         checked, bad = _operand_dataflow(hdr, lines)
         assert not bad, (grid, depth, bad[:3])
@@ -271,7 +313,26 @@ def test_dataflow_check_notices_a_stale_slot():
     g, problems = M.build(hdr, kept)
     assert not problems and not M.races(g)
     checked, bad = _operand_dataflow(hdr, kept)
-    assert bad and all("(5," in b[0] or ",5)" in b[0] for b in bad) and any("pullB(2," in b[2] for b in bad), bad[:4]
+    assert bad and all("(5," in b[0] or ",5)" in b[0] for b in bad) and any("pullB(2," in b[2] and b[2].endswith("panel 2") for b in bad), bad[:4]
+
+
+def test_dataflow_check_follows_staging_sends_and_receives():
+    """send/recv transport: the owners' staging copy of panel 8 removed — their sends then ship what panel 2 left in the staging image
+    (same slot: 8 ≡ 2 mod depth + 1; same owners: 8 ≡ 2 mod Q); every transfer is still matched and ordered, the receivers' updates
+    of panel 8 are flagged with the panel the data really came from"""
+    with __import__("tempfile").TemporaryDirectory() as td:
+        path = Path(td) / "t.jsonl"
+        M.emit_trace(2, 2, 12, 2, SENDRECV, path)
+        hdr, lines = M.load(path)
+    owners = {ln["r"] for ln in lines if ln["t"] == "op" and ln["n"] == "stage" and ln["k"][0] == 8}
+    assert owners
+    kept = [ln for ln in lines if not (ln["t"] == "op" and ln["n"] == "stage" and ln["k"][0] == 8)]
+    g, problems = M.build(hdr, kept)
+    assert not problems and not M.races(g)
+    checked, bad = _operand_dataflow(hdr, kept)
+    assert bad and all(",8)" in b[0] for b in bad), bad[:4]
+    assert any("recv<-" in b[2] and b[2].endswith("panel 2") for b in bad), bad[:4]
+    assert {int(b[0].split(".")[0][1:]) for b in bad} - owners, "ranks other than the owners see the stale data"
 
 
 def _drop(pred, first_per=None):
