@@ -186,6 +186,17 @@ def test_fit_updates_every_block_by_every_earlier_panel_exactly_once(grid, comm)
             for i in list(range(j, nblk)) + ["rhs"]:
                 assert sorted(upd.get((i, j), [])) == list(range(j)), (grid, depth, (i, j), upd.get((i, j)))
                 assert fin.get((i, j)) == [j], (grid, depth, (i, j), fin.get((i, j)))
+        # backward sweep: every diagonal block solved once, on its owner; the block row k of Lᵀ applied by exactly the ranks of
+        # process row k mod P that hold block columns left of k
+        ops = [ln for ln in lines if ln["t"] == "op"]
+        assert sorted((ln["k"][0], ln["r"]) for ln in ops if ln["n"] == "trsv") == [(k, (k % P) * Q + k % Q) for k in range(nblk)]
+        gemv = {}
+        for ln in ops:
+            if ln["n"] == "gemv":
+                gemv.setdefault(ln["k"][0], set()).add(ln["r"])
+        for k in range(nblk):
+            want = {(k % P) * Q + q for q in range(Q) if any(j % Q == q for j in range(k))}
+            assert gemv.get(k, set()) == want, (grid, depth, k)
 
 
 def _operand_dataflow(hdr, lines):
