@@ -346,6 +346,38 @@ def test_dataflow_check_follows_staging_sends_and_receives():
     assert {int(b[0].split(".")[0][1:]) for b in bad} - owners, "ranks other than the owners see the stale data"
 
 
+@pytest.mark.parametrize("grid", M.GRIDS)
+def test_cost_model_ships_what_the_schedule_ships(grid):
+    """tools/grid_model.py prices the exchange of the multi-device fit from its own formula for who receives which
+    panel blocks; here that formula meets the schedule the library really issues (send/recv transport, traced without a device): per
+    ordered rank pair, the panel blocks the model ships over the link == the panel blocks the traced sends carry out of the owners'
+    staging images (the right-hand-side block row that rides along and the 32-column row padding are not in the model)"""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import grid_model as G
+
+    P, Q = grid
+    for nblk_in in (3, 6, 9):
+        with __import__("tempfile").TemporaryDirectory() as td:
+            path = Path(td) / "t.jsonl"
+            M.emit_trace(P, Q, nblk_in, 2, SENDRECV, path)
+            hdr, lines = M.load(path)
+        nblk = hdr["nblk"]
+        traced = {}
+        for ln in lines:
+            if ln["t"] == "send" and ln["R"][0][0] == "St":
+                blocks = sum(f[5] - f[4] for f in ln["R"])                      # local block rows [b0, b1) of the staging image
+                assert ln["n"] == (blocks + sum(1 for f in ln["R"] if f[6] & 2)) * 128 * 160   # (+ the RHS block row; rows of NB + 32)
+                traced[(ln["r"], ln["to"])] = traced.get((ln["r"], ln["to"]), 0) + blocks
+        m = G.model(nblk * 128, P, Q, 128)
+        assert m["nblk"] == nblk
+        want = {}
+        for (src, dst), b in m["link_bytes"].items():
+            want[(src[0] * Q + src[1], dst[0] * Q + dst[1])] = round(b / (128 * 128 * 8.0))
+        want = {k: v for k, v in want.items() if v}
+        traced = {k: v for k, v in traced.items() if v}
+        assert traced == want, (grid, nblk, sorted(set(traced.items()) ^ set(want.items()))[:6])
+
+
 def _drop(pred, first_per=None):
     """trace edit: remove the lines pred selects (first_per: only the first one per key)"""
     def f(lines):

@@ -125,6 +125,8 @@ def model(N, P, Q, NB, depth=2):
             "chain_bound_steps": sum(1 for b, c in zip(bulk_t, crit_t) if c > b), "nblk": nblk,
             "flop_imbalance": max(fl) / (sum(fl) / len(fl)) if sum(fl) else 1.0,
             "recv_gb_max": max(recv.values()) / 1e9, "link_gb_max": (max(link.values()) / 1e9 if link else 0.0),
+            "link_bytes": dict(link),   # ((p, q) source, (p, q) destination) -> panel bytes shipped over that link during the whole fit
+                                        # (tests/test_multi_schedule.py compares it with the transfers of the traced schedule)
             "tflops": (N**3 / 3) / t_total / 1e12, "frac_of_peak": (N**3 / 3) / t_total / (78.6e12 * R)}
 
 
