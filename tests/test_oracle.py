@@ -221,3 +221,36 @@ def test_oracle_vs_scikit_learn(kind, nu, ard):
     np.testing.assert_allclose(v, np.diag(c_sk), atol=1e-9)
     # and the Gram matrix itself (kernelmatrix parity is otherwise pinned by closed forms only)
     np.testing.assert_allclose(o.kernelmatrix(of.kernel, x), gpr.kernel_(x), rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("kind", [o.SE, o.MATERN32])
+def test_vfe_against_the_dense_textbook_formulas(kind):
+    """The sparse restatement at GENERAL pseudo-points z ≠ x against formulas that share no code with it: Q_ff = K_fu K_uu⁻¹ K_uf by
+    explicit inverses, DTC evidence = log N(y | m, Q_ff + Σy) by scipy's MvNormal, ELBO = DTC − ½ tr(Σy⁻¹ (K_ff − Q_ff)) (Titsias 2009,
+    eq. 9 — what src/sparse_approximations.jl:248-313 evaluates through Cholesky factors), predictive mean / covariance
+    K_*u Λ⁻¹ K_uf Σy⁻¹ (y − m) and K_** − K_*u K_uu⁻¹ K_u* + K_*u Λ⁻¹ K_u*, Λ = K_uu + K_uf Σy⁻¹ K_fu (:183-217).  Per-point noise,
+    constant mean, D = 2."""
+    n, mz, d, jitter = 120, 20, 2, 1e-6
+    x, y = o.synth_inputs(n, d, 70 + kind)
+    rng = np.random.default_rng(7 + kind)
+    z = rng.standard_normal((mz, d)) * 1.2
+    s2 = 0.05 + 0.1 * rng.random(n)
+    f = o.GP(o.Kernel(kind, 1.4, 0.9), 0.25)
+    fx = o.FiniteGP(f, x, s2)
+    Kff = o.kernelmatrix(f.kernel, x)
+    Kuu = o.kernelmatrix(f.kernel, z) + jitter * np.eye(mz)
+    Kuf = o.kernelmatrix(f.kernel, z, x)
+    Qff = Kuf.T @ np.linalg.inv(Kuu) @ Kuf
+    dtc = scipy.stats.multivariate_normal(mean=np.full(n, 0.25), cov=Qff + np.diag(s2), allow_singular=False).logpdf(y)
+    elbo = dtc - 0.5 * np.sum((np.diag(Kff) - np.diag(Qff)) / s2)
+    assert o.dtc_log_evidence(f, z, jitter, fx, y) == pytest.approx(dtc, rel=1e-9)
+    assert o.elbo(f, z, jitter, fx, y) == pytest.approx(elbo, rel=1e-9)
+    ap = o.vfe_posterior(f, z, jitter, fx, y)
+    xs = rng.standard_normal((30, d))
+    Ksu = o.kernelmatrix(f.kernel, xs, z)
+    Lam = Kuu + (Kuf / s2) @ Kuf.T
+    mean = 0.25 + Ksu @ np.linalg.solve(Lam, (Kuf / s2) @ (y - 0.25))
+    cov = o.kernelmatrix(f.kernel, xs) - Ksu @ np.linalg.solve(Kuu, Ksu.T) + Ksu @ np.linalg.solve(Lam, Ksu.T)
+    np.testing.assert_allclose(ap.mean(xs), mean, atol=1e-8)
+    np.testing.assert_allclose(ap.cov(xs), cov, atol=1e-8)
+    np.testing.assert_allclose(ap.mean_and_var(xs)[1], np.diag(cov), atol=1e-8)
