@@ -32,6 +32,21 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.skip(reason="no GPU in this container (gpu tests run via gpurun)"))
 
 
+def rank_devices(n: int) -> list:
+    """Device list for the n ranks of a multi-device context in the tests: n VIRTUAL ranks on GPU 0 — what the one-GPU test box
+    runs — unless GPMI_TEST_REAL_DEVICES=1 and the node has at least n GPUs: then one rank per device, i.e. the same tests over
+    real peer copies / real RCCL (the first thing to run on a multi-GPU node: `GPMI_TEST_REAL_DEVICES=1 pytest tests -m gpu -k multi`)."""
+    if os.environ.get("GPMI_TEST_REAL_DEVICES") == "1":
+        try:
+            import torch
+
+            if torch.cuda.device_count() >= n:
+                return list(range(n))
+        except Exception:
+            pass
+    return [0] * n
+
+
 @pytest.fixture(scope="session")
 def agp():
     # the .so is a build artefact (git-ignored): cross-compile it for gfx950 if this checkout has not been built yet

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import gp_oracle as o
+from tests.conftest import rank_devices
 
 pytestmark = pytest.mark.gpu
 
@@ -362,7 +363,7 @@ def test_conformance_on_a_multi_device_context(agp, P, Q):
     (predictions, held-out logpdf, sampling and posterior-of-a-posterior on the pieces) at the sizes the reference tests use — far
     below one distribution block, so most blocks of the grid are padding."""
     rng = np.random.default_rng(123456)
-    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=128)
+    ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=128)
     try:
         x = rng.standard_normal(37)
         z = rng.standard_normal(23)
@@ -392,7 +393,7 @@ def test_sqmahal_logdetcov_gradlogpdf(agp, multi):
     factorisation — the two terms logpdf adds up, returned separately (gp_logpdf_terms), and C \\ (m .- x) for vectors and
     matrices (gp_posterior_solve for the columns beyond the fitted one)."""
     x, y, s2, f, of, xin, rng = _setup(agp, 700, 3, 3)
-    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128) if multi else None
+    ctx = agp.Context(devices=rank_devices(4), P=2, Q=2, nb=128) if multi else None
     try:
         if ctx is not None:
             f = agp.GP(f.mean_fn, f.kernel, ctx=ctx)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import gp_oracle as o
+from tests.conftest import rank_devices
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +28,7 @@ def test_virtual_ranks_vs_oracle(agp, P, Q):
     of = o.GP(o.Kernel(o.MATERN52, 1.4, 0.8), 0.25)
     ofx = o.FiniteGP(of, x, s2)
     lp_ref, opost = o.logpdf_and_posterior(ofx, y)
-    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=nb)
     try:
         info = ctx.multi_info()
         assert (info["P"], info["Q"], info["nb"]) == (P, Q, nb) and info["comm"] == "copies"
@@ -59,7 +60,7 @@ def test_lookahead_depths_and_ragged_sizes(agp, depth, P, Q, n, nb):
     x, y = o.synth_inputs(n, 2, 7 + depth)
     of = o.GP(o.Kernel(o.SE, 1.0, 1.3))
     lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, x, 0.05), y)
-    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=nb)
     try:
         ctx.set_param("lookahead_depth", depth)
         assert ctx.multi_info()["lookahead_depth"] == depth
@@ -79,7 +80,7 @@ def test_multi_sequential_update_and_rand_after_gather(agp):
     x, y = o.synth_inputs(n1 + n2, 3, 5)
     of = o.GP(o.Kernel(o.MATERN32))
     ob = o.posterior(o.FiniteGP(of, x, 0.05), y)
-    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128)
+    ctx = agp.Context(devices=rank_devices(4), P=2, Q=2, nb=128)
     try:
         f = agp.GP(agp.Matern32Kernel(), ctx=ctx)
         p1 = agp.posterior(f(agp.RowVecs(x[:n1]), 0.05), y[:n1])
@@ -102,7 +103,7 @@ def test_multi_not_positive_definite_reports_first_minor(agp):
     s2 = np.full(n, 0.1)
     s2[400] = -5.0
     s2[650] = -7.0
-    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128)
+    ctx = agp.Context(devices=rank_devices(4), P=2, Q=2, nb=128)
     one = agp.Context(0)
     try:
         for c in (ctx, one):
@@ -119,7 +120,7 @@ def test_multi_fp32_and_wide_Y_and_other_entry_points_run_on_device0(agp):
     """what the block-cyclic driver does not take (fp32, more than 128 right-hand-side columns) runs on the single-device engine of
     devices[0] — `every other entry point works unchanged` of include/gpmi355.h"""
     x, y = o.synth_inputs(600, 3, 9)
-    ctx = agp.Context(devices=[0, 0], nb=128)
+    ctx = agp.Context(devices=rank_devices(2), nb=128)
     try:
         assert ctx.multi_info()["P"] == 2 and ctx.multi_info()["Q"] == 1       # default grid: P = ndev, Q = 1
         f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
@@ -159,7 +160,7 @@ def test_predictive_variance_on_the_distributed_factor(agp, P, Q, tmp_path):
     s2 = 0.03 + 0.05 * rng.random(n)
     of = o.GP(o.Kernel(o.MATERN32, 1.7, 0.7), -0.3)
     opost = o.posterior(o.FiniteGP(of, x, s2), y)
-    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=nb)
     try:
         f = agp.GP(-0.3, 1.7 * agp.Matern32Kernel() @ agp.ScaleTransform(0.7), ctx=ctx)
         post = agp.posterior(f(agp.RowVecs(x), s2), y)
@@ -226,7 +227,7 @@ def test_sequential_update_and_solve_on_the_pieces(agp, P, Q, tmp_path):
     of = o.GP(o.Kernel(o.MATERN52, 1.3, 0.8), 0.2)
     ob2 = o.posterior(o.FiniteGP(of, x[: n1 + n2], s2[: n1 + n2]), y[: n1 + n2])
     ob3 = o.posterior(o.FiniteGP(of, x, s2), y)
-    ctx = agp.Context(devices=[0] * (P * Q), P=P, Q=Q, nb=nb)
+    ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=nb)
     try:
         f = agp.GP(0.2, 1.3 * agp.Matern52Kernel() @ agp.ScaleTransform(0.8), ctx=ctx)
         p1 = agp.posterior(f(agp.RowVecs(x[:n1]), s2[:n1]), y[:n1])
@@ -293,7 +294,7 @@ def test_self_check_repeats_a_spoiled_fit_once(agp):
     x, y = o.synth_inputs(900, 2, 21)
     of = o.GP(o.Kernel(o.MATERN32))
     lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, x, 0.05), y)
-    ctx = agp.Context(devices=[0] * 4, P=2, Q=2, nb=128)
+    ctx = agp.Context(devices=rank_devices(4), P=2, Q=2, nb=128)
     try:
         f = agp.GP(agp.Matern32Kernel(), ctx=ctx)
         post = agp.posterior(f(agp.RowVecs(x), 0.05), y)

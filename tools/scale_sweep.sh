@@ -3,6 +3,8 @@
 # produce is missing from profiles/, and tools/grid_model.py is the only basis for the default grid).  One JSON line per run in
 # gpurun_out/scale_sweep.jsonl:  device counts 1/2/4/8 × the grids of each count × distribution blocks 512/1024/2048.
 #   bash tools/scale_sweep.sh [steps] [warmup]
+# Before the sweep, on such a node: the multi-device tests over REAL devices (peer copies and real RCCL instead of virtual ranks
+# and the stand-in library) —   GPMI_TEST_REAL_DEVICES=1 python -m pytest tests -q -m gpu -k "multi or conformance_on_a_multi"
 STEPS=${1:-3}; WARM=${2:-1}
 OUT=gpurun_out/scale_sweep.jsonl
 mkdir -p gpurun_out; : > $OUT
