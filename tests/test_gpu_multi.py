@@ -31,7 +31,8 @@ def test_virtual_ranks_vs_oracle(agp, P, Q):
     ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=nb)
     try:
         info = ctx.multi_info()
-        assert (info["P"], info["Q"], info["nb"]) == (P, Q, nb) and info["comm"] == "copies"
+        assert (info["P"], info["Q"], info["nb"]) == (P, Q, nb)
+        assert info["comm"] == "copies" or len(set(rank_devices(P * Q))) > 1   # (virtual ranks copy; real devices may use RCCL)
         f = agp.GP(0.25, 1.4 * agp.Matern52Kernel() @ agp.ScaleTransform(0.8), ctx=ctx)
         fx = f(agp.RowVecs(x), s2)
         assert agp.logpdf(fx, y) == pytest.approx(lp_ref, rel=1e-10)
