@@ -78,6 +78,9 @@ PROTOTYPES = {
     "gp_posterior_rand": (i32, [vp, PP, vp, PN, vp, i32, vp]),
     "gp_ctx_trim": (i32, [vp]),
     "gp_vfe_get": (i32, [vp, vp, vp]),
+    "gp_vfe_get_factors": (i32, [vp, vp, vp]),
+    "gp_vfe_n": (i64, [vp]),
+    "gp_vfe_get_by": (i32, [vp, vp]),
     "gp_vfe_free": (i32, [vp]),
     "gpd_assemble": (i32, [vp, PK, vp, i64, i64, i32, vp, PG, vp, i64, i64, i64]),
     "gpd_potrf": (i32, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
@@ -88,6 +91,7 @@ PROTOTYPES = {
     "gpd_rowsumsq": (i32, [vp, vp, i64, i64, i64, vp]),
     "gpd_sync": (i32, [vp]),
     "gpd_gemm_time": (i32, [vp, C.POINTER(dbl), C.POINTER(i64)]),
+    "gp_rccl_selftest": (i32, [i32, i64, C.POINTER(dbl)]),
     "gp_probe_mfma_f64": (i32, [vp, vp, vp, vp]),
     "gp_bench_mfma_f64": (i32, [vp, i32, C.POINTER(dbl)]),
     "gp_bench_mfma_f32": (i32, [vp, i32, i32, C.POINTER(dbl)]),

@@ -825,6 +825,45 @@ def _vfe_call(approx, fx: FiniteGP, y, want_post: bool):
     return (h if want_post else None), obj[0], ctx, dt, pz.n
 
 
+class _VfeData:
+    """Lazy view of an ApproxPosteriorGP's device-resident cache (field names of src/sparse_approximations.jl:73, ASCII)."""
+
+    _FIELDS = ("alpha", "m_eps", "U", "Lam_U", "b_y")
+
+    def __init__(self, post):
+        self._post = post
+
+    def keys(self):
+        return self._FIELDS
+
+    def __contains__(self, k):
+        return k in self._FIELDS
+
+    def __getattr__(self, k):
+        if k.startswith("_") or k not in self._FIELDS:
+            raise AttributeError(k)
+        return self[k]
+
+    def __getitem__(self, k):
+        p = self._post
+        st, dt, m = p._state, p._dtype, p._m
+        lib = st.ctx.lib
+        if k in ("alpha", "m_eps"):
+            a = np.empty(m, dtype=dt)
+            check(lib.gp_vfe_get(st.handle, a.ctypes.data if k == "alpha" else None, a.ctypes.data if k == "m_eps" else None))
+            return a
+        if k in ("U", "Lam_U"):
+            out = np.empty((m, m), dtype=dt, order="F")
+            check(lib.gp_vfe_get_factors(st.handle, out.ctypes.data if k == "U" else None, out.ctypes.data if k == "Lam_U" else None))
+            return out
+        if k == "b_y":
+            n = int(lib.gp_vfe_n(st.handle))
+            out = np.empty(max(n, 0), dtype=dt)
+            check(lib.gp_vfe_get_by(st.handle, out.ctypes.data))
+            return out
+        raise KeyError(k)
+
+
 class ApproxPosteriorGP(AbstractGP):
     """src/sparse_approximations.jl:25-29; the cache (:73) lives on the device."""
 
@@ -834,10 +873,10 @@ class ApproxPosteriorGP(AbstractGP):
 
     @property
     def data(self):
-        a = np.empty(self._m, dtype=self._dtype)
-        me = np.empty(self._m, dtype=self._dtype)
-        check(self._state.ctx.lib.gp_vfe_get(self._state.handle, a.ctypes.data, me.ctypes.data))
-        return {"alpha": a, "m_eps": me}
+        """The cache of src/sparse_approximations.jl:73 — (m_ε, Λ_ε, U, α, b_y, …) — read from the device on demand: `alpha`, `m_eps`
+        (M-vectors), `U` = cholesky(cov(fz)).U and `Lam_U` = Λ_ε.U (M×M upper, column-major), `b_y` (N-vector).  Mapping access
+        (`data["alpha"]`) and attribute access (`data.alpha`) both work; B_εf is never materialised (it is N×M)."""
+        return _VfeData(self)
 
     def _predict(self, x, what):
         st = self._state

@@ -1618,8 +1618,16 @@ int32_t gp_logpdf_terms(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
     HIPCHK(hipSetDevice(c->device));
     FitOut fo;
     std::vector<char> zero;
-    if (!Y) {  // a zero observation vector with a zero mean: the factorisation is all that is needed
+    if (!Y) {
+        // logdet only: the factorisation is all that is needed, but a multi-device fit verifies its result through the right-hand
+        // side that rides along ((K + Σy) α = δ on every row) — an all-zero δ would make that check vacuous (α = 0 whatever the
+        // factor holds).  A fixed pseudo-random probe in [−½, ½) rides instead; its sqmahal is discarded.
         zero.assign((size_t)x->n * (k->dtype == 0 ? 8 : 4), 0);
+        for (int64_t i = 0; i < x->n; ++i) {
+            const double v = (double)(((uint32_t)i * 2654435761u >> 8) & 0xffffu) / 65536.0 - 0.5 + 1.0 / 131072.0;
+            if (k->dtype == 0) ((double*)zero.data())[i] = v;
+            else ((float*)zero.data())[i] = (float)v;
+        }
         ncols = 1;
         ldy = x->n;
     }
@@ -2027,6 +2035,54 @@ int32_t gp_vfe_get(gp_vfe* p, void* alpha_out, void* meps_out) {
             if (p->dtype == 0) ((double*)meps_out)[i] = h[p->mp + i];
             else ((float*)meps_out)[i] = (float)h[p->mp + i];
         }
+    }
+    return 0;
+}
+
+int32_t gp_vfe_get_factors(gp_vfe* p, void* U_out, void* LamU_out) {
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    const long m = p->m;
+    // device row j of the row-major lower factor == host column j of the column-major upper factor (always fp64 on the device)
+    std::vector<double> h;
+    const void* srcs[2] = {p->Lz, p->Ld};
+    void* dsts[2] = {U_out, LamU_out};
+    for (int which = 0; which < 2; ++which) {
+        if (!dsts[which]) continue;
+        if (!srcs[which]) return set_arg_err(1, "the posterior holds no factor (objective-only fit)");
+        h.resize((size_t)m * (size_t)m);
+        HIPCHK(hipMemcpy2DAsync(h.data(), sizeof(double) * m, srcs[which], sizeof(double) * p->ld, sizeof(double) * m, m,
+                                hipMemcpyDeviceToHost, c->sm));
+        HIPCHK(hipStreamSynchronize(c->sm));
+        for (long j = 0; j < m; ++j)
+            for (long i = 0; i < m; ++i) {
+                const double v = i <= j ? h[(size_t)j * m + i] : 0.0;
+                if (p->dtype == 0) ((double*)dsts[which])[(size_t)j * m + i] = v;
+                else ((float*)dsts[which])[(size_t)j * m + i] = (float)v;
+            }
+    }
+    return 0;
+}
+
+int64_t gp_vfe_n(gp_vfe* p) {
+    Guard gd(p);
+    if (!gd.ok) return -1;
+    return p->n_obs;
+}
+
+int32_t gp_vfe_get_by(gp_vfe* p, void* by_out) {
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    if (!by_out) return set_arg_err(2, "b_y_out is NULL");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t es = p->dtype == 0 ? 8 : 4;
+    size_t off = 0;
+    for (const auto& sg : p->segs) {  // one segment per fit / update, in arrival order
+        if (sg->n > 0) HIPCHK(hipMemcpy((char*)by_out + off, sg->b, es * (size_t)sg->n, hipMemcpyDeviceToHost));
+        off += es * (size_t)sg->n;
     }
     return 0;
 }

@@ -137,10 +137,18 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
     std::string err;
+    long live = 0;  // communicators created through the CURRENT library and not yet destroyed (under g_rccl_mu)
     bool load() {
         const char* over = getenv("GPMI_RCCL_LIB");  // tests: a stand-in library (tests/rccl_mock)
         const std::string want = over ? over : "";
         if (h && want == name) return ok;
+        if (h && live > 0) {
+            // a different library is asked for while communicators of the loaded one are alive: their ncclCommDestroy must come
+            // from the library that created them, so the switch is refused (this context uses copies) and the pointers stay
+            err = "a different RCCL library (" + (name.empty() ? std::string("librccl") : name) + ") has live communicators";
+            return false;
+        }
+        if (h && h != (void*)1) (void)dlclose(h);
         ok = false;
         err.clear();
         name = want;
@@ -1334,7 +1342,12 @@ void multi_destroy(gp_multi* m) {
     if (!m) return;
     for (auto& rk : m->ranks) {
         (void)hipSetDevice(rk.device);
-        if (rk.comm && g_rccl.ok) (void)g_rccl.CommDestroy(rk.comm);
+        if (rk.comm) {
+            std::lock_guard<std::mutex> l(g_rccl_mu);
+            if (g_rccl.ok && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(rk.comm);
+            if (g_rccl.live > 0) --g_rccl.live;
+            rk.comm = nullptr;
+        }
         for (auto* v : {&rk.ready, &rk.lkk, &rk.accr, &rk.alr, &rk.sx, &rk.sa, &rk.bar})
             for (auto& x : *v)
                 if (x.ev) (void)hipEventDestroy(x.ev);
@@ -1488,6 +1501,7 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
             const int nrc = g_rccl.CommInitAll(comms.data(), ndev, devs.data());
             if (nrc == 0) {
                 for (int r = 0; r < ndev; ++r) m->ranks[r].comm = comms[r];
+                g_rccl.live += ndev;
                 m->comm = 1;
                 m->comm_note = standin ? "grouped send/recv through the stand-in library of GPMI_RCCL_LIB" : "RCCL grouped send/recv over xGMI (ncclCommInitAll)";
             } else {
@@ -2327,8 +2341,35 @@ int32_t multi_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, 
             MCHK(hipMemcpy2D(xs_v, sizeof(double) * np1, old->xs, sizeof(double) * old->np, sizeof(double) * n0, d, hipMemcpyDeviceToDevice));
             MCHK(hipMemcpy2D((double*)xs_v + n0, sizeof(double) * np1, xs2_h.data(), sizeof(double) * nsp, sizeof(double) * n2, d, hipMemcpyHostToDevice));
             MCHK(hipMemcpy(al_v, al.data(), sizeof(double) * (size_t)n1, hipMemcpyHostToDevice));
+            // Self-check of the NEW rows through an independent path (as multi_fit checks every row): the identity above,
+            // δᵀα = ‖L⁻¹δ‖², holds for ANY triangular L, so a wrong U12 (sink rows) or U22 block would pass it.  The rows of
+            //   (K([x1; x2], [x1; x2]) + Σy) α = δ   that belong to x2 involve U12 and U22:  K(x2, [x1; x2]) α + Σy2 α2 = δ2,
+            // with K·α evaluated from the inputs (kvec kernel, no factor).  A mismatch returns −1991: the caller gathers instead.
+            void* kv_v = nullptr;
+            RC(mb.get(sizeof(double) * (size_t)nsp, &kv_v));
+            RC(eng_kvec(c, c->sm, (const double*)xs_v + n0, np1, (const double*)xs_v, np1, d, old->kind, old->variance, n1, (const double*)al_v,
+                        (double*)kv_v, n2));
+            std::vector<double> kv((size_t)n2);
+            MCHK(hipMemcpyAsync(kv.data(), kv_v, sizeof(double) * (size_t)n2, hipMemcpyDeviceToHost, c->sm));
+            MCHK(hipStreamSynchronize(c->sm));
+            double res = 0, amax = 0, dmax = 0;
+            for (long i = 0; i < n1; ++i) {
+                amax = std::max(amax, std::fabs(al[(size_t)i]));
+                dmax = std::max(dmax, std::fabs(dl[i]));
+            }
+            for (long i = 0; i < n2; ++i) {
+                const double a2 = al[(size_t)(n0 + i)], lhs = kv[(size_t)i] + nz_h[(size_t)i] * a2;
+                res = std::max(res, std::fabs(lhs - dl[n0 + i]));
+            }
+            const double scale = (double)n1 * old->variance * amax + dmax;  // the bound multi_fit's every-row check uses
+            if (!(res <= 1e-9 * scale)) {
+                char b[220];
+                snprintf(b, sizeof b, "sequential update on the pieces: rows of the new observations miss (K + Sigma) alpha = delta by %.3g (scale %.3g)", res, scale);
+                return set_err_text(-1991, b);
+            }
             return 0;
         }();
+        if (rc != 0) (void)hipStreamSynchronize(c->sm);
     }
     if (rc != 0) {
         drop_new();
@@ -2424,4 +2465,59 @@ int32_t multi_gather(gp_post* post) {
     post->A_bytes = A_b;
     multi_post_release(post);
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gp_rccl_selftest: the transport's library on ONE device, without a multi-device context — dlopen (librccl, or GPMI_RCCL_LIB), the
+// seven entry points, ncclCommInitAll(1), and one grouped ncclSend / ncclRecv pair of `count` doubles from the rank to itself on a
+// stream (RCCL serves a self-pair as a local copy).  Proves on any GPU box what the multi-device driver assumes about the library:
+// the symbols exist with the prototypes used, grouped posting works on a communicator made by ncclCommInitAll, and NCCL_FLOAT64 is
+// the 8-byte element type (a wrong constant would move a different number of bytes — every element is compared).
+// max_abs_err_out (nullable): largest |received − sent|.  Status −1996: library unavailable; −1998: an RCCL call failed.
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t gp_rccl_selftest(int32_t device, int64_t count, double* max_abs_err_out) {
+    if (count < 1) return set_err_text(-2, "count must be >= 1");
+    MCHK(hipSetDevice(device));
+    std::lock_guard<std::mutex> l(g_rccl_mu);
+    if (!g_rccl.load()) return set_err_text(-1996, "RCCL is unavailable: " + g_rccl.err);
+    ncclComm_t_ comm = nullptr;
+    const int dev = device;
+    int nrc = g_rccl.CommInitAll(&comm, 1, &dev);
+    if (nrc != 0) return set_err_text(-1998, std::string("ncclCommInitAll(1): ") + g_rccl.GetErrorString(nrc));
+    ++g_rccl.live;
+    double *a = nullptr, *b = nullptr;
+    hipStream_t st = nullptr;
+    int32_t rc = [&]() -> int32_t {
+        MCHK(hipMalloc((void**)&a, sizeof(double) * (size_t)count));
+        MCHK(hipMalloc((void**)&b, sizeof(double) * (size_t)(count + 8)));
+        MCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        std::vector<double> h((size_t)count);
+        for (int64_t i = 0; i < count; ++i) h[(size_t)i] = 1.0 + (double)i * 0.5;
+        MCHK(hipMemcpy(a, h.data(), sizeof(double) * (size_t)count, hipMemcpyHostToDevice));
+        MCHK(hipMemset(b, 0xff, sizeof(double) * (size_t)(count + 8)));  // NaN pattern: untouched elements are detected
+        nrc = g_rccl.GroupStart();
+        if (nrc == 0) nrc = g_rccl.Send(a, (size_t)count, NCCL_FLOAT64, 0, comm, st);
+        if (nrc == 0) nrc = g_rccl.Recv(b, (size_t)count, NCCL_FLOAT64, 0, comm, st);
+        const int nrc2 = g_rccl.GroupEnd();
+        if (nrc == 0) nrc = nrc2;
+        if (nrc != 0) return set_err_text(-1998, std::string("grouped ncclSend/ncclRecv to self: ") + g_rccl.GetErrorString(nrc));
+        MCHK(hipStreamSynchronize(st));
+        std::vector<double> g((size_t)count + 8);
+        MCHK(hipMemcpy(g.data(), b, sizeof(double) * (size_t)(count + 8), hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int64_t i = 0; i < count; ++i) {
+            const double e = std::fabs(g[(size_t)i] - h[(size_t)i]);
+            worst = (e == e) ? std::max(worst, e) : 1e300;  // NaN = element never written
+        }
+        for (int64_t i = count; i < count + 8; ++i)
+            if (g[(size_t)i] == g[(size_t)i]) worst = 1e300;  // wrote past the count: the element type is wider than 8 bytes
+        if (max_abs_err_out) *max_abs_err_out = worst;
+        return 0;
+    }();
+    if (st) (void)hipStreamDestroy(st);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    (void)g_rccl.CommDestroy(comm);
+    --g_rccl.live;
+    return rc;
 }

@@ -247,8 +247,10 @@ function Distributions.gradlogpdf(fx::FiniteGP{<:HipGP}, X::AbstractMatrix)
     T = a.T
     D = a.m === nothing ? Matrix{T}(X) : Matrix{T}(X) .- a.m
     out = similar(D)
-    GC.@preserve D out check(ccall((:gp_posterior_solve, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+    # `post` must outlive the call: its finalizer frees the device factor the solve reads
+    GC.@preserve post D out check(ccall((:gp_posterior_solve, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
         getfield(post.data.C, :handle), D, size(D, 2), out))
+    finalize(post.data.C)   # an O(n²) device factor: release it now instead of leaving it to the GC
     return -out
 end
 
@@ -350,6 +352,12 @@ function Base.:\(C::DeviceCholesky, B::AbstractVecOrMat{<:Real})
     GC.@preserve D out check(ccall((:gp_posterior_solve, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
         getfield(C, :handle), D, size(D, 2), out))
     return B isa AbstractVector ? vec(out) : out
+end
+# logdet(post.data.C) (what src/finite_gp_projection.jl:310 does with its Cholesky): kept from the fit, no sweep over the factor
+function LinearAlgebra.logdet(C::DeviceCholesky)
+    out = Ref{Float64}(0.0)
+    GC.@preserve C check(ccall((:gp_posterior_logdet, libgpmi355), Int32, (Ptr{Cvoid}, Ref{Float64}), getfield(C, :handle), out))
+    return convert(getfield(C, :T), out[])
 end
 function device_cholesky(h::Ptr{Cvoid}, n::Int, ::Type{T}) where {T}
     C = DeviceCholesky(h, n, T)
@@ -496,18 +504,39 @@ function Statistics.cov(f::HipPosteriorGP, x::AbstractVector, z::AbstractVector)
 end
 
 # ---- VFE / DTC (src/sparse_approximations.jl:58-75, 183-217, 248-254, 282-286) ---------------------
-struct HipApproxPosteriorGP{Tapprox,Tprior<:HipGP} <: AbstractGP
+struct HipApproxPosteriorGP{Tapprox,Tprior<:HipGP,Tx,TΣ} <: AbstractGP
     approx::Tapprox
     prior::Tprior
     handle::Base.RefValue{Ptr{Cvoid}}
     T::DataType
     objective::Float64                 # ELBO / DTC evidence from the same streamed pass
+    x::Tx                              # cache.x  (src/sparse_approximations.jl:73, :115): every observation input seen so far
+    Σy::TΣ                             # cache.Σy (:73, :100): Diagonal over every observation seen so far
 end
-post_handle(f::HipApproxPosteriorGP) = (f.handle[], f.T, :gp_vfe_logpdf, :gp_vfe_rand)
-function approx_posterior(approx, prior, h::Base.RefValue{Ptr{Cvoid}}, ::Type{T}, obj) where {T}
+post_handle(f::HipApproxPosteriorGP) = (getfield(f, :handle)[], getfield(f, :T), :gp_vfe_logpdf, :gp_vfe_rand)
+function approx_posterior(approx, prior, h::Base.RefValue{Ptr{Cvoid}}, ::Type{T}, obj, x, Σy) where {T}
     finalizer(hh -> ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), hh[]), h)
-    return HipApproxPosteriorGP(approx, prior, h, T, Float64(obj))
+    return HipApproxPosteriorGP(approx, prior, h, T, Float64(obj), x, Σy)
 end
+# `post.data` — the cache NamedTuple of the reference (src/sparse_approximations.jl:73), read field by field by its tests
+# (test/sparse_approximations.jl:48-55, 76-83): m_ε, Λ_ε (a LinearAlgebra.Cholesky, so Λ_ε.U works), U, α, b_y from the device
+# (gp_vfe_get, gp_vfe_get_factors, gp_vfe_get_by), x and Σy from the host side.  B_εf (M×N) is never materialised and is not a field.
+function Base.getproperty(f::HipApproxPosteriorGP, s::Symbol)
+    s === :data || return getfield(f, s)
+    h, T = getfield(f, :handle), getfield(f, :T)
+    m = Int(ccall((:gp_vfe_m, libgpmi355), Int64, (Ptr{Cvoid},), h[]))
+    n = Int(ccall((:gp_vfe_n, libgpmi355), Int64, (Ptr{Cvoid},), h[]))
+    α = Vector{T}(undef, m); m_ε = Vector{T}(undef, m)
+    U = Matrix{T}(undef, m, m); ΛU = Matrix{T}(undef, m, m)
+    b_y = Vector{T}(undef, n)
+    GC.@preserve f α m_ε U ΛU b_y begin
+        check(ccall((:gp_vfe_get, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], α, m_ε))
+        check(ccall((:gp_vfe_get_factors, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], U, ΛU))
+        check(ccall((:gp_vfe_get_by, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), h[], b_y))
+    end
+    return (m_ε=m_ε, Λ_ε=Cholesky(ΛU, 'U', 0), U=UpperTriangular(U), α=α, b_y=b_y, x=getfield(f, :x), Σy=getfield(f, :Σy))
+end
+Base.propertynames(::HipApproxPosteriorGP) = (:approx, :prior, :data, :objective)
 
 # FiniteGP API of the two posterior types on the device
 for PT in (:HipPosteriorGP, :HipApproxPosteriorGP)
@@ -553,7 +582,7 @@ end
 function AbstractGPs.posterior(approx::Union{VFE,DTC}, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     r = vfe_call(approx, fx, y, true)
     r === nothing && return posterior(typeof(approx)(FiniteGP(fx.f.gp, approx.fz.x, approx.fz.Σy)), stock(fx), y)
-    return approx_posterior(approx, fx.f, r[1], r[3], r[2])
+    return approx_posterior(approx, fx.f, r[1], r[3], r[2], fx.x, Diagonal(collect(diag(fx.Σy))))
 end
 function AbstractGPs.approx_log_evidence(approx::Union{VFE,DTC}, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     r = vfe_call(approx, fx, y, false)
@@ -564,7 +593,7 @@ end
 AbstractGPs.elbo(vfe::VFE, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}) = approx_log_evidence(vfe, fx, y)  # :254
 
 function vfe_predict(f::HipApproxPosteriorGP, x::AbstractVector, what::Integer)
-    T = f.T
+    T = getfield(f, :T)
     px = points(x, T)
     px === nothing && throw(ArgumentError("unsupported input container for the accelerated posterior (use a Vector, ColVecs or RowVecs)"))
     xbuf, cx = px
@@ -573,10 +602,10 @@ function vfe_predict(f::HipApproxPosteriorGP, x::AbstractVector, what::Integer)
     m = (what & 1) != 0 ? Vector{T}(undef, ns) : T[]
     v = (what & 2) != 0 ? Vector{T}(undef, ns) : T[]
     c = (what & 4) != 0 ? Matrix{T}(undef, ns, ns) : Matrix{T}(undef, 0, 0)
-    GC.@preserve xbuf pm m v c begin
+    GC.@preserve f xbuf pm m v c begin
         check(ccall((:gp_vfe_predict, libgpmi355), Int32,
             (Ptr{Cvoid}, Ref{CPoints}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-            f.handle[], cx, pm === nothing ? C_NULL : pointer(pm), what, m, v, c))
+            getfield(f, :handle)[], cx, pm === nothing ? C_NULL : pointer(pm), what, m, v, c))
     end
     return m, v, c
 end
@@ -597,34 +626,35 @@ AbstractGPs.inducing_points(f::HipApproxPosteriorGP) = f.approx.fz.x            
 # update_posterior with new observations, same pseudo-points (src/sparse_approximations.jl:87-121)
 function AbstractGPs.update_posterior(f::HipApproxPosteriorGP, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
     @assert f.prior === fx.f
-    T = f.T
+    T = getfield(f, :T)
     xbuf, cx, nbuf, cn, m2 = joint_args(fx, f.prior.gp, T)
     yv = Vector{T}(y)
     obj = Ref{T}(zero(T))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve xbuf nbuf m2 yv begin
+    GC.@preserve f xbuf nbuf m2 yv begin
         check(ccall((:gp_vfe_update, libgpmi355), Int32,
             (Ptr{Cvoid}, Ref{CPoints}, Ref{CNoise}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{T}),
-            f.handle[], cx, cn, m2 === nothing ? C_NULL : pointer(m2), yv, h, obj))
+            getfield(f, :handle)[], cx, cn, m2 === nothing ? C_NULL : pointer(m2), yv, h, obj))
     end
-    return approx_posterior(f.approx, f.prior, h, T, obj[])
+    Σy = Diagonal(vcat(diag(getfield(f, :Σy)), diag(fx.Σy)))                                   # :99-100 (block-diagonal of two Diagonals)
+    return approx_posterior(f.approx, f.prior, h, T, obj[], vcat(getfield(f, :x), fx.x), Σy)   # :115
 end
 
 # update_posterior with new pseudo-points (src/sparse_approximations.jl:131-176): bordered K_zz factor + re-streamed new block
 # rows on the device; the approximation object is rebuilt with z = vcat(z_old, z_new) like _update_approx (:178-179)
 function AbstractGPs.update_posterior(f::HipApproxPosteriorGP, fz::FiniteGP{<:HipGP})
     @assert f.prior === fz.f                                                                   # :132
-    T = f.T
+    T = getfield(f, :T)
     pz = points(fz.x, T)
     pz === nothing && throw(ArgumentError("unsupported container for the new pseudo-points"))
     zbuf, cz = pz
     obj = Ref{T}(zero(T))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve zbuf begin
-        check(ccall((:gp_vfe_append, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ref{Ptr{Cvoid}}, Ref{T}), f.handle[], cz, h, obj))
+    GC.@preserve f zbuf begin
+        check(ccall((:gp_vfe_append, libgpmi355), Int32, (Ptr{Cvoid}, Ref{CPoints}, Ref{Ptr{Cvoid}}, Ref{T}), getfield(f, :handle)[], cz, h, obj))
     end
     fz_new = f.approx.fz.f(vcat(f.approx.fz.x, fz.x), f.approx.fz.Σy)                         # :160-162
-    return approx_posterior(typeof(f.approx)(fz_new), f.prior, h, T, obj[])
+    return approx_posterior(typeof(f.approx)(fz_new), f.prior, h, T, obj[], getfield(f, :x), getfield(f, :Σy))
 end
 
 end # module

@@ -282,6 +282,13 @@ int32_t gp_vfe_rand(gp_vfe* post, const gp_points* xs, const void* prior_mean_xs
 int64_t gp_vfe_m(gp_vfe* post); /* number of pseudo-points */
 /* α = U \ m_ε (length M) and m_ε — cache fields of src/sparse_approximations.jl:73. */
 int32_t gp_vfe_get(gp_vfe* post, void* alpha_out_or_null, void* m_eps_out_or_null);
+/* The two M×M factors of the cache (src/sparse_approximations.jl:73: `U` = cholesky(cov(fz)).U and `Λ_ε.U`, read field by field by
+ * test/sparse_approximations.jl:48-55, 76-83): M×M column-major UPPER triangular host arrays in the posterior's dtype (the strictly
+ * lower part is zero-filled); either pointer may be NULL.  The device keeps both as fp64 row-major lower factors — byte-identical. */
+int32_t gp_vfe_get_factors(gp_vfe* post, void* U_out_or_null, void* Lambda_U_out_or_null);
+int64_t gp_vfe_n(gp_vfe* post); /* observations seen so far (fit + every update_posterior) */
+/* b_y = U_y⁻ᵀ (y − m) of every observation seen so far, length gp_vfe_n(post) (cache field b_y, :66, :102), posterior's dtype. */
+int32_t gp_vfe_get_by(gp_vfe* post, void* b_y_out);
 int32_t gp_vfe_free(gp_vfe* post);
 
 /* ---- device-level building blocks ------------------------------------------------------------ */
@@ -331,6 +338,12 @@ int32_t gpd_sync(gp_ctx* ctx);
  * stream.  This synchronises the stream, returns the summed launch durations (ms) and the launch count since the
  * previous call, and clears the records (the caller knows the algorithmic flops of its own launches). */
 int32_t gpd_gemm_time(gp_ctx* ctx, double* ms_out, int64_t* launches_out);
+
+/* The multi-device transport's library on ONE device: dlopen (librccl, or the library GPMI_RCCL_LIB names), the seven entry points,
+ * ncclCommInitAll(1) and one grouped ncclSend / ncclRecv pair of `count` doubles from the rank to itself, every element compared.
+ * max_abs_err_out_or_null: largest |received − sent| (0 when the element type constant and the posting rules are what the driver
+ * assumes).  −1996: the library is unavailable; −1998: an RCCL call failed (text in gp_last_error()). */
+int32_t gp_rccl_selftest(int32_t device, int64_t count, double* max_abs_err_out_or_null);
 
 /* ---- probes used by tools/gpu_diag.py and bench.py ------------------------------------------ */
 /* D(16×16) = A(16×4)·B(4×16), all row-major host arrays: checks the f64 MFMA lane maps. */

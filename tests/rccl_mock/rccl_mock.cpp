@@ -204,7 +204,7 @@ int ncclGroupEnd() {
 int ncclSend(const void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t stream) {
     Comm* c = (Comm*)comm;
     const size_t es = dtype_bytes(dtype);
-    if (!c || !es || peer < 0 || peer >= c->w->n || peer == c->rank) return fail(4, "ncclSend: bad arguments");
+    if (!c || !es || peer < 0 || peer >= c->w->n) return fail(4, "ncclSend: bad arguments");  // a self pair inside one group is legal (served as a local copy), as in RCCL
     Op o{0, nullptr, count * es, peer, c, stream, nullptr};
     const int rc = post_send(buf, count * es, peer, c, stream, &o.x);
     if (rc != 0) return rc;
@@ -215,7 +215,7 @@ int ncclSend(const void* buf, size_t count, int dtype, int peer, void* comm, hip
 int ncclRecv(void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t stream) {
     Comm* c = (Comm*)comm;
     const size_t es = dtype_bytes(dtype);
-    if (!c || !es || peer < 0 || peer >= c->w->n || peer == c->rank) return fail(4, "ncclRecv: bad arguments");
+    if (!c || !es || peer < 0 || peer >= c->w->n) return fail(4, "ncclRecv: bad arguments");
     t_ops.push_back(Op{1, buf, count * es, peer, c, stream, nullptr});
     return t_depth > 0 ? 0 : run_ops(t_ops);
 }

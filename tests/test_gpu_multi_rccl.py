@@ -120,3 +120,57 @@ def test_device_trace_of_a_real_fit_passes_the_schedule_checker(agp, rccl_env, t
         hdr, problems, rs = M.check_trace(trace)
         assert hdr["dry"] == 0 and hdr["comm"] == (1 if comm == "rccl" else 2)
         assert not problems and not rs, (comm, problems[:3], rs[:3])
+
+
+_REAL_RCCL_SNIPPET = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+os.environ.pop("GPMI_RCCL_LIB", None)
+os.environ["GPMI_COMM"] = "rccl"
+import abstractgps_jl_amd as agp
+lib = agp._lib.load()
+err = ctypes.c_double(-1.0)
+rc = lib.gp_rccl_selftest(0, 1 << 20, ctypes.byref(err))
+out = {{"selftest_rc": rc, "selftest_err": err.value, "selftest_msg": lib.gp_last_error().decode(errors="replace") if rc else ""}}
+if rc == 0:
+    # the force_rccl path of gp_ctx_create_multi: ONE real device, the real library, ncclCommInitAll(1), a fit through the driver
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((700, 3)); y = np.sin(x.sum(1)) + 0.1 * rng.standard_normal(700)
+    one = agp.Context(0)
+    ref = agp.posterior(agp.GP(agp.SqExponentialKernel(), ctx=one)(agp.RowVecs(x), 0.01), y)
+    ctx = agp.Context(devices=[0], nb=128)
+    out["comm"] = ctx.multi_info()["comm"]
+    post = agp.posterior(agp.GP(agp.SqExponentialKernel(), ctx=ctx)(agp.RowVecs(x), 0.01), y)
+    out["logpdf_rel"] = abs(float(post.logpdf_value) - float(ref.logpdf_value)) / abs(float(ref.logpdf_value))
+    out["alpha_rel"] = float(np.linalg.norm(post.data.alpha - ref.data.alpha) / np.linalg.norm(ref.data.alpha))
+    out["stats"] = ctx.multi_stats()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_real_librccl_loads_and_moves_doubles_on_one_device(agp):
+    """The REAL librccl.so of the box (no stand-in): dlopen, the seven entry points, ncclCommInitAll(1), one grouped
+    ncclSend / ncclRecv pair of 2^20 doubles (every element compared: the ncclFloat64 constant), then a fit on a one-device
+    multi ctx created with GPMI_COMM=rccl (the `force_rccl` path of gp_ctx_create_multi).  In a subprocess with a timeout: a
+    library that hangs at initialisation costs this test, not the suite.  What it cannot show: transfers between distinct devices."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("GPMI_RCCL_LIB", "GPMI_COMM")}
+    r = subprocess.run([sys.executable, "-c", _REAL_RCCL_SNIPPET.format(root=str(ROOT))], env=env, capture_output=True, text=True, timeout=240)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[-1][7:])
+    assert out["selftest_rc"] == 0, out
+    assert out["selftest_err"] == 0.0, out
+    assert out["comm"] == "rccl", out
+    assert out["logpdf_rel"] <= 1e-10 and out["alpha_rel"] <= 1e-8, out
+
+
+def test_stand_in_library_passes_the_same_selftest(agp, rccl_env):
+    lib = agp._lib.load()
+    err = ctypes.c_double(-1.0)
+    assert lib.gp_rccl_selftest(0, 4096, ctypes.byref(err)) == 0, lib.gp_last_error()
+    assert err.value == 0.0
