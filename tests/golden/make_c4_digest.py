@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Digest of the ORACLE's result at the headline size (BASELINE config C4: N = 65 536, D = 3, SE, σ² = 0.01, seed 4).
 
-  python tests/golden/make_c4_digest.py [--n 65536] [--threads 8] [--out tests/golden/c4_oracle_digest.npz]
+  python tests/golden/make_c4_digest.py [--n 65536] [--threads 8] [--out tests/golden/digests/c4_oracle_digest.npz]
 
 Runs oracle.gp_oracle.logpdf_and_posterior_inplace (the fused pair in one Fortran-ordered N×N array: ≈ 35 GB of host
 memory, minutes of host BLAS) and stores what a checker needs to pin a device result WITHOUT re-running the oracle:
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--out", default=str(Path(__file__).resolve().parent / "c4_oracle_digest.npz"))
+    ap.add_argument("--out", default=str(Path(__file__).resolve().parent / "digests" / "c4_oracle_digest.npz"))
     a = ap.parse_args()
     from oracle import gp_oracle as o
 

@@ -1,7 +1,7 @@
 """GPU: BASELINE.json's configurations at FULL size.  C2, C3 (ScaleTransform AND ARDTransform), C4 and C5 are compared VALUE
 for value with the oracle run on the box's host cores inside this suite (logpdf rel <= 1e-10 — this is what validates logdet —
 and α rel <= 1e-8; C4 costs ≈ 135 s of host BLAS per run); C4 is additionally pinned against the committed digest of the
-oracle's result (tests/golden/c4_oracle_digest.npz, tests/golden/make_c4_digest.py) — the same file bench.py checks its timed
+oracle's result (tests/golden/digests/c4_oracle_digest.npz, tests/golden/make_c4_digest.py) — the same file bench.py checks its timed
 result against.  tools/fullsize_parity.py records the same comparisons with timings (profiles/r2/fullsize_parity.jsonl, asserted
 below when present).  All sizes are additionally checked through size-independent properties:
   * normal equations through an independent device path: the posterior mean at training inputs is K α, so
@@ -56,7 +56,7 @@ def _exact_values(agp, n, d, seed, kernel, okernel, sigma2=0.01):
 def _digest():
     from pathlib import Path
 
-    p = Path(__file__).resolve().parent / "golden" / "c4_oracle_digest.npz"
+    p = Path(__file__).resolve().parent / "golden" / "digests" / "c4_oracle_digest.npz"
     return np.load(p) if p.exists() else None
 
 
@@ -98,6 +98,10 @@ def test_c4_full_size_values_vs_oracle(agp):
         assert lp_gpu == pytest.approx(float(dig["logpdf"]), rel=1e-10)
         assert compare(alpha_gpu, dig) <= 1e-8
     lp, alpha, _ = o.logpdf_and_posterior_inplace(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y, threads=min(32, os.cpu_count() or 1))
+    if os.environ.get("GPMI_WRITE_C4_DIGEST"):  # (re)generate the committed digest from THIS oracle run (tests/golden/make_c4_digest.py)
+        from tests.golden.make_c4_digest import digest_of
+
+        np.savez(os.environ["GPMI_WRITE_C4_DIGEST"], n=n, d=3, seed=4, sigma2=0.01, logpdf=lp, logdet=_, **digest_of(alpha))
     assert lp_gpu == pytest.approx(lp, rel=1e-10)
     assert np.linalg.norm(alpha_gpu - alpha) / np.linalg.norm(alpha) <= 1e-8
     if dig is not None and int(dig["n"]) == n:
