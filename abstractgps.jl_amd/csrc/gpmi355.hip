@@ -309,8 +309,16 @@ static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, lo
         HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
         HIPCHK(hipDeviceSynchronize());
     }
+    int* const tk = c->ticket_dev + ((s == c->sp || (s == c->sp_mask && s)) ? 32 : 0);
+    if constexpr (std::is_same<T, double>::value) {
+        if (c->leaf_v2) {  // register-resident leaf (leaf.hip: panel64v2_kernel)
+            HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mrows, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, kpre,
+                                              c->leaf_xr, c->num_cus));
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(panel64_kernel<T>, dim3(nblk), dim3(256), 0, s, A + j0 * lda + j0, lda, (int)mrows, info_dev,
-                       (int)(gcol0 + j0), (int)n_valid, logdet_dev, c->ticket_dev + ((s == c->sp || (s == c->sp_mask && s)) ? 32 : 0), kpre);
+                       (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, kpre);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1474,6 +1482,8 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
         c->gemm_pad_user = true;
     }
     else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
+    else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
+    else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);

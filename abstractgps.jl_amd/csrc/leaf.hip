@@ -1,0 +1,22 @@
+// leaf.hip — translation unit of panel64v2_kernel (leaf.hpp) and its launcher; compiled with -mllvm -amdgpu-mfma-vgpr-form.
+#include "leaf.hpp"
+#include "engine.hpp"
+
+#include <algorithm>
+
+namespace gpmi {
+
+// one register-resident 64-column leaf on stream s (same contract as panel64_kernel: kernels.hpp).  xr: rows of X per workgroup
+// (64 / 128); 0 = 64 while that gives at most two workgroups per CU, else 128.
+int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* info_dev, int col0, int n_valid, double* logdet_dev, int* ticket,
+                       int kpre, int xr, int num_cus) {
+    const bool xr64 = xr == 64 || (xr == 0 && mrows <= 64L * 2 * num_cus);
+    const unsigned nb = (unsigned)std::max(1L, (mrows + (xr64 ? 63 : 127)) / (xr64 ? 64 : 128));
+    if (xr64)
+        hipLaunchKernelGGL(panel64v2_kernel<64>, dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
+    else
+        hipLaunchKernelGGL(panel64v2_kernel<128>, dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
+    return (int32_t)hipGetLastError();  // hipError_t of the launch (0 = hipSuccess)
+}
+
+}  // namespace gpmi
