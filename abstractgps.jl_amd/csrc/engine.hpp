@@ -79,6 +79,7 @@ struct gp_ctx {
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)
     long leaf_group = 128; // columns factored left-looking by consecutive leaves (64 = every leaf followed by its own GEMM)
+    int deterministic = 0; // 1: no floating-point atomics in the exact path (no stream-K tails, one thread per column in the backward sweep): bitwise repeatable
     int leaf_v2 = 1;       // fp64 leaves by panel64v2_kernel (register-resident leaf, round 4); 0: panel64_kernel
     int leaf_xr = 0;       // rows of X per leaf workgroup: 64 / 128; 0 = 64 while that gives at most two workgroups per CU, else 128
     int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at

@@ -236,7 +236,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         grid = dim3((unsigned)total, 1);
     }
     if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
-    if ((c->gemm_streamk || c->sk_scope > 0) && !g.beta0 && !g.ktri && g.nbatch <= 1 && g.P == 1 && g.Q == 1 && g.compact <= 1 &&
+    if (!c->deterministic && (c->gemm_streamk || c->sk_scope > 0) && !g.beta0 && !g.ktri && g.nbatch <= 1 && g.P == 1 && g.Q == 1 && g.compact <= 1 &&
         (g.compact == 1 ? (long)grid.x : tm * tn) <= c->sk_max_tiles) {
         // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
         const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
@@ -546,7 +546,7 @@ static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* 
                 hipLaunchKernelGGL((trsv_diag_kernel<T, false>), dim3(1), dim3(1024), smem, s, L, ldl, b0, nbv, R, ldr, nrhs, (const T*)W);
             HIPCHK(hipGetLastError());
             if (b0 > 0) {
-                hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((b0 + 255) / 256), (unsigned)(nbv / 64)),
+                hipLaunchKernelGGL(trsv_upd_bwd_kernel<T>, dim3((unsigned)((b0 + 255) / 256), c->deterministic ? 1u : (unsigned)(nbv / 64)),
                                    dim3(256), 0, s, L, ldl, b0, nbv, R, ldr, nrhs);
                 HIPCHK(hipGetLastError());
             }
@@ -1482,6 +1482,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
         c->gemm_pad_user = true;
     }
     else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
+    else if (!strcmp(name, "deterministic")) c->deterministic = v != 0;
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
     else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));

@@ -1504,8 +1504,23 @@ template <typename T>
 __global__ __launch_bounds__(256) void trsv_upd_bwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
                                                             T* __restrict__ R, long ldr, int nrhs) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    const long i0 = b0 + (long)blockIdx.y * 64;
     if (j >= b0) return;
+    if (gridDim.y == 1) {  // "deterministic": one thread owns its column, the 64-row pieces are summed in a fixed order, no atomics
+        for (int s = 0; s < nrhs; ++s) {
+            const T* a = R + (long)s * ldr;
+            T tot = 0;
+            for (int ch = 0; ch < nbv / 64; ++ch) {
+                const long i0 = b0 + 64L * ch;
+                T acc = 0;
+#pragma unroll 8
+                for (int i = 0; i < 64; ++i) acc = fma(L[(i0 + i) * ldl + j], a[i0 + i], acc);
+                tot += acc;
+            }
+            R[(long)s * ldr + j] -= tot;
+        }
+        return;
+    }
+    const long i0 = b0 + (long)blockIdx.y * 64;
     for (int s = 0; s < nrhs; ++s) {
         const T* a = R + (long)s * ldr;
         T acc = 0;

@@ -38,19 +38,23 @@ namespace gpmi {
 //   kpre > 0 (left-looking entry, as in panel64_kernel): the kpre tiles to the left are applied first, L_k staged in LDS, the left
 //   tile's rows of this workgroup loaded in natural layout and used as the B operands of P1 / both operands of P2.
 // ------------------------------------------------------------------------------------------------
-template <int XR>
-__global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
-                                                         int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket,
-                                                         int kpre) {
+// The body of one wave, specialised on the wave's role W (0: the pivot chain; 1..3: owners): what a wave owns is then known at compile
+// time — no exec-masked branch around any MFMA (the first version tested `t < nt`, `c < w` at run time: every such test became an
+// s_and_saveexec / s_cbranch pair that also fenced the scheduler, so operand reads from LDS were issued right before their use and
+// 140–160 cycles went by per MFMA instead of 62–70) — and the independent accumulators of a phase are updated slice by slice,
+// back to back.  All four instances execute the same barriers.
+template <int XR, int W>
+__device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0, int n_valid,
+                                          double* __restrict__ logdet_acc, int* __restrict__ ticket, int kpre, double* __restrict__ Lp,
+                                          double* __restrict__ Inv, double* __restrict__ dAx, int* __restrict__ writer_s) {
     using TR = Tr<double>;
     constexpr int LDP = 66, LIP = 18;            // row pitches (doubles): 16-byte aligned rows for the 4-double operand reads
     constexpr int NXT = XR / 16;                 // row tiles of X per workgroup
     constexpr int NTW = (NXT + 2) / 3;           // X row tiles per owner wave (waves 1..3)
-    __shared__ __attribute__((aligned(16))) double Lp[64 * LDP];     // published blocks of L (natural rows); pre-update: the left tile
-    __shared__ __attribute__((aligned(16))) double Inv[4][16 * LIP];
-    __shared__ __attribute__((aligned(16))) double dAx[64 * 4];      // hand-over of the next diagonal block (symmetric layout)
-    __shared__ int writer_s;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int T0 = W == 0 ? 0 : (W - 1) * NTW;
+    constexpr int NT = W == 0 ? 0 : ((NXT - T0) < 0 ? 0 : ((NXT - T0) < NTW ? (NXT - T0) : NTW));
+    constexpr int NTA = NT > 0 ? NT : 1;         // array extent
+    const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
 #ifdef GPMI_PANEL_STAMPS
     long stamps[20];
@@ -64,51 +68,36 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
     int xrows = mrows - (int)blockIdx.x * XR;
     xrows = xrows < 0 ? 0 : (xrows > XR ? XR : xrows);
     double* const Xg = A + (long)(64 + (long)blockIdx.x * XR) * lda;
-    // X row tiles of this wave: [t0, t0 + nt) — waves 1..3 (wave 0 runs the pivot chain)
-    const int t0 = w == 0 ? 0 : (w - 1) * NTW;
-    int nt = w == 0 ? 0 : ((NXT - t0) < NTW ? (NXT - t0) : NTW);
-    if (nt < 0) nt = 0;
-    const int nxt_valid = (xrows + 15) >> 4;
 
-    // 4 contiguous doubles of row π(li): the A operand of P1 for the 16×16 block at M (LDS)
-    auto aop = [&](const double* M, int pitch) -> d4_t {
-        const d2_t* src = reinterpret_cast<const d2_t*>(M + pirow * pitch + 4 * lg);
+    auto ld4 = [&](const double* p16) -> d4_t {  // 32 bytes as two 16-byte pieces (global or LDS)
+        const d2_t* src = reinterpret_cast<const d2_t*>(p16);
         const d2_t lo = src[0], hi = src[1];
-        d4_t a;
-        a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
-        return a;
-    };
-    auto p1 = [&](const d4_t& a, const d4_t& n, d4_t acc) -> d4_t {  // acc += tile(n) · Mᵀ  (a = aop(M))
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = TR::mfma(a[s], n[s], acc);
-        return acc;
-    };
-    auto p1n = [&](const d4_t& a, const d4_t& n, d4_t acc) -> d4_t {  // acc −= tile(n) · Mᵀ
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = TR::mfma(-a[s], n[s], acc);
-        return acc;
-    };
-    auto p2n = [&](const d4_t& n, d4_t acc) -> d4_t {  // acc(symmetric) −= L·Lᵀ, L natural
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = TR::mfma(-n[s], n[s], acc);
-        return acc;
-    };
-    auto ld_nat = [&](const double* rowptr, bool ok) -> d4_t {  // 32 bytes of a row (16-byte pieces)
         d4_t v;
-        v[0] = v[1] = v[2] = v[3] = 0.0;
-        if (ok) {
-            const d2_t* src = reinterpret_cast<const d2_t*>(rowptr);
-            const d2_t lo = src[0], hi = src[1];
-            v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-        }
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
         return v;
     };
-    auto st_nat = [&](double* rowptr, const d4_t& v) {
+    auto st4 = [&](double* p16, const d4_t& v) {
         d2_t lo, hi;
         lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
-        d2_t* dst = reinterpret_cast<d2_t*>(rowptr);
+        d2_t* dst = reinterpret_cast<d2_t*>(p16);
         dst[0] = lo;
         dst[1] = hi;
+    };
+    auto zero4 = [&]() -> d4_t {
+        d4_t v;
+        v[0] = v[1] = v[2] = v[3] = 0.0;
+        return v;
+    };
+    auto neg4 = [&](const d4_t& v) -> d4_t {
+        d4_t r;
+        r[0] = -v[0]; r[1] = -v[1]; r[2] = -v[2]; r[3] = -v[3];
+        return r;
+    };
+    // A operand of P1 for the 16×16 block at M (LDS): 4 contiguous doubles of row π(li)
+    auto aop = [&](const double* M, int pitch) -> d4_t { return ld4(M + pirow * pitch + 4 * lg); };
+    auto ld_x = [&](int t, long coloff) -> d4_t {  // this wave's X row tile t, 32 bytes at column coloff + 4 lg (zero past the last row)
+        const int row = 16 * (T0 + t) + li;
+        return row < xrows ? ld4(Xg + (long)row * lda + coloff + 4 * lg) : zero4();
     };
     auto ld_sym = [&](int t) -> d4_t {  // block (t, t) from the lower triangle, symmetric layout
         d4_t v;
@@ -121,19 +110,15 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
     };
 
     // ---- what this wave owns, loaded straight into registers
-    d4_t dA;            // wave 0: the block being factored; wave w >= 1: block (w, w)
-    d4_t y[4];          // wave w >= 1: blocks (w, c), c < w  (y[3] is never live: it keeps the unrolled indexing in bounds)
-    d4_t x[NTW][4];     // X row tiles
-    dA = ld_sym(w);
+    d4_t dA = ld_sym(W);  // wave 0: the block being factored; owner W: block (W, W)
+    d4_t y[3];            // owner W: blocks (W, c), c < W
+    d4_t x[NTA][4];       // X row tiles
 #pragma unroll
-    for (int c = 0; c < 4; ++c) y[c] = ld_nat(A + (long)(16 * w + li) * lda + 16 * c + 4 * lg, c < w);
+    for (int c = 0; c < 3; ++c) y[c] = c < W ? ld4(A + (long)(16 * W + li) * lda + 16 * c + 4 * lg) : zero4();
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int row = 16 * (t0 + t) + li;
-            x[t][c] = ld_nat(Xg + (long)row * lda + 16 * c + 4 * lg, t < nt && row < xrows);
-        }
+        for (int c = 0; c < 4; ++c) x[t][c] = ld_x(t, 16 * c);
 
     // ---- left-looking pre-update by the kpre tiles to the left (same rows): [D; X] −= [L_k; X_k] · L_kᵀ
     for (int k = 0; k < kpre; ++k) {
@@ -142,28 +127,30 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {  // stage L_k (64×64) into Lp: 1 024 pieces of 32 bytes over 256 threads
             const int e = tid + 256 * i, row = e >> 4, pc = e & 15;
-            const d4_t v = ld_nat(A + (long)row * lda + coff + 4 * pc, true);
-            st_nat(&Lp[row * LDP + 4 * pc], v);
+            st4(&Lp[row * LDP + 4 * pc], ld4(A + (long)row * lda + coff + 4 * pc));
         }
+        d4_t xk[NTA][4];  // the left tile's rows of this wave: requested before the barrier, consumed slice by slice behind it
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xk[t][q] = ld_x(t, coff + 16 * q);
         __syncthreads();
-        // one 16-column slice q of the left tile at a time (its rows of this wave in natural layout: 8 registers per row tile)
-#pragma unroll 1
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const d4_t dk = ld_nat(A + (long)(16 * w + li) * lda + coff + 16 * q + 4 * lg, true);  // rows 16w.. of the diagonal tile
-            d4_t xk[NTW];
+            const d4_t dk = ld4(&Lp[(16 * W + li) * LDP + 16 * q + 4 * lg]);  // rows 16W.. of the left tile (natural), from the staged image
+            d4_t na[4];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int row = 16 * (t0 + t) + li;
-                xk[t] = ld_nat(Xg + (long)row * lda + coff + 16 * q + 4 * lg, t < nt && row < xrows);
-            }
-            dA = p2n(dk, dA);
+            for (int c = 0; c < 4; ++c) na[c] = neg4(aop(&Lp[(16 * c) * LDP + 16 * q], LDP));
+            const d4_t ndk = neg4(dk);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const d4_t a = aop(&Lp[(16 * c) * LDP + 16 * q], LDP);
-                if (c < 3 && c < w) y[c] = p1n(a, dk, y[c]);
+            for (int s = 0; s < 4; ++s) {
+                dA = TR::mfma(ndk[s], dk[s], dA);
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
-                    if (t < nt && t0 + t < nxt_valid) x[t][c] = p1n(a, xk[t], x[t][c]);
+                for (int c = 0; c < 4; ++c) {
+                    if (c < W && c < 3) y[c] = TR::mfma(na[c][s], dk[s], y[c]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) x[t][c] = TR::mfma(na[c][s], xk[t][q][s], x[t][c]);
+                }
             }
         }
     }
@@ -175,7 +162,7 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         PSTAMP2();
-        if (w == 0) {
+        if constexpr (W == 0) {
             // P3: factor block (j, j) column by column on the accumulator; the identity rides transposed (accW).
             // What the measurements say (tools/lat_probe2.hip, tools/f16_probe.hip): fp64 VALU and the fp64 MFMA share ONE pipe on a
             // SIMD (an MFMA followed by 8 independent fma takes 62 + 56 cycles) and a VALU read of an MFMA result waits ≈ 30 cycles
@@ -232,7 +219,7 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
             for (int r = 0; r < 4; ++r) {
                 const int col = lg + 4 * r;
                 Lp[(16 * j + li) * LDP + 16 * j + col] = (li >= col) ? Ls[r] : 0.0;
-                Inv[j][col * LIP + li] = Ws[r];
+                Inv[j * 16 * LIP + col * LIP + li] = Ws[r];
                 if (col == li) dg = Ls[r];
             }
             mydiag[j] = dg;  // lanes (c, c & 3): L_cc of column 16j + c
@@ -248,65 +235,79 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
             }
         }
         // the ticket below says "this workgroup has READ the input tile": a workgroup barrier does not drain vmcnt, so do it by hand
-        if (j == 0 && w != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (j == 0 && W != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PSTAMP2();
         __syncthreads();  // B1: Inv_j and L(j, j) are published
         PSTAMP2();
-        if (j == 0 && tid == 128) tk_old = atomicAdd(ticket, 1);  // every load of the input tile has landed; the reply is awaited at the end
-        if (w != 0 && w > j) {  // this wave's block (w, j); the owner of row tile j+1 is on the critical path (it hands block (j+1, j+1) to wave 0)
-            const d4_t ai = aop(&Inv[j][0], LIP);
-            d4_t z;
-            z[0] = z[1] = z[2] = z[3] = 0.0;
-            y[j] = p1(ai, y[j], z);
-            st_nat(&Lp[(16 * w + li) * LDP + 16 * j + 4 * lg], y[j]);
-            dA = p2n(y[j], dA);
-            if (w == j + 1) {
+        if (j == 0 && W == 3 && lane == 0) tk_old = atomicAdd(ticket, 1);  // every load of the input tile has landed; the reply is awaited at the end
+        d4_t ai = zero4();
+        if constexpr (W != 0) ai = aop(&Inv[j * 16 * LIP], LIP);
+        if constexpr (W != 0) {
+            if (W > j) {  // this wave's block (W, j): the owner of row tile j+1 is on the critical path (it hands block (j+1, j+1) to wave 0)
+                d4_t r = zero4();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dAx[lane * 4 + r] = dA[r];
+                for (int s = 0; s < 4; ++s) r = TR::mfma(ai[s], y[j < 3 ? j : 0][s], r);
+                y[j < 3 ? j : 0] = r;
+                st4(&Lp[(16 * W + li) * LDP + 16 * j + 4 * lg], r);
+                const d4_t nr = neg4(r);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dA = TR::mfma(nr[s], r[s], dA);
+                if (W == j + 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dAx[lane * 4 + q] = dA[q];
+                }
             }
         }
         PSTAMP2();
         __syncthreads();  // B2: L(t, j) of every row tile below and the next diagonal block are published
-        if (w == 0) {
+        if constexpr (W == 0) {
             if (j < 3) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dA[r] = dAx[lane * 4 + r];
             }
         } else {
-            if (nt > 0) {  // X_j ← X_j Inv_jᵀ needs only Inv_j: it runs behind B2, in the shadow of wave 0's next block
-                const d4_t ai = aop(&Inv[j][0], LIP);
-                d4_t z;
-                z[0] = z[1] = z[2] = z[3] = 0.0;
+            // X_j ← X_j Inv_jᵀ needs only Inv_j: it runs behind B2, in the shadow of wave 0's next block; the operands of the updates are
+            // requested first so that their LDS round trip hides behind these MFMAs
+            d4_t na[4];
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
-                    if (t0 + t < nxt_valid) {
-                        x[t][j] = p1(ai, x[t][j], z);
-                        const int row = 16 * (t0 + t) + li;
-                        if (row < xrows) st_nat(Xg + (long)row * lda + 16 * j + 4 * lg, x[t][j]);  // column tile j of X is final
-                    }
+            for (int c = 0; c < 4; ++c) na[c] = (c > j) ? neg4(aop(&Lp[(16 * c) * LDP + 16 * j], LDP)) : zero4();
+            if constexpr (NT > 0) {
+                d4_t r[NTA];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) r[t] = zero4();
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) r[t] = TR::mfma(ai[s], x[t][j][s], r[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    x[t][j] = r[t];
+                    const int row = 16 * (T0 + t) + li;
+                    if (row < xrows) st4(Xg + (long)row * lda + 16 * j + 4 * lg, r[t]);  // column tile j of X is final
+                }
             }
             if (j < 3) {
 #pragma unroll
-                for (int c = j + 1; c < 4; ++c) {
-                    const d4_t a = aop(&Lp[(16 * c) * LDP + 16 * j], LDP);
-                    if (c < 3 && c < w) y[c] = p1n(a, y[j], y[c]);
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t)
-                        if (t < nt && t0 + t < nxt_valid) x[t][c] = p1n(a, x[t][j], x[t][c]);
-                }
+                    for (int c = j + 1; c < 4; ++c) {
+                        if (c < W && c < 3) y[c] = TR::mfma(na[c][s], y[j][s], y[c]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) x[t][c] = TR::mfma(na[c][s], x[t][j][s], x[t][c]);
+                    }
             }
         }
     }
     PSTAMP2();
-    if (tid == 128) writer_s = (tk_old == (int)gridDim.x - 1);
+    if (W == 3 && lane == 0) *writer_s = (tk_old == (int)gridDim.x - 1);
     __syncthreads();  // every published block is in Lp; writer_s is visible
-    if (writer_s) {
+    if (*writer_s) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int e = tid + 256 * i, row = e >> 6, c = e & 63;
             if (c <= row) A[(long)row * lda + c] = Lp[row * LDP + c];
         }
-        if (w == 0) {
+        if constexpr (W == 0) {
             double logd = 0.0;
             if (lg == (li & 3)) {
 #pragma unroll
@@ -324,12 +325,27 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
     }
 #ifdef GPMI_PANEL_STAMPS
     PSTAMP2();
-    if (blockIdx.x == 0 && lane == 0 && w < 2 && logdet_acc) {  // wave 0 at +8, wave 1 at +32 (cycles since the wave's first stamp)
-        long* dst = reinterpret_cast<long*>(logdet_acc) + 8 + 24 * w;
+    if (blockIdx.x == 0 && lane == 0 && W < 2 && logdet_acc) {  // wave 0 at +8, wave 1 at +32 (cycles since the wave's first stamp)
+        long* dst = reinterpret_cast<long*>(logdet_acc) + 8 + 24 * W;
         for (int i = 0; i < 20; ++i) dst[i] = i < nst ? stamps[i] - stamps[0] : 0;
     }
 #endif
 #undef PSTAMP2
+}
+
+template <int XR>
+__global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
+                                                         int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket,
+                                                         int kpre) {
+    __shared__ __attribute__((aligned(16))) double Lp[64 * 66];      // published blocks of L (natural rows); pre-update: the left tile
+    __shared__ __attribute__((aligned(16))) double Inv[4 * 16 * 18];
+    __shared__ __attribute__((aligned(16))) double dAx[64 * 4];      // hand-over of the next diagonal block (symmetric layout)
+    __shared__ int writer_s;
+    const int w = threadIdx.x >> 6;  // wave-uniform: each wave runs the instance of its role
+    if (w == 0) leaf_wave<XR, 0>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
+    else if (w == 1) leaf_wave<XR, 1>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
+    else if (w == 2) leaf_wave<XR, 2>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
+    else leaf_wave<XR, 3>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
 }
 
 }  // namespace gpmi

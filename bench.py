@@ -134,19 +134,24 @@ def pmc_traffic(n: int) -> dict:
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
 
 
-def other_configs(agp, ctx, steps: int = 3) -> dict:
+def other_configs(agp, ctx, steps: int = 5) -> dict:
     """The other single-GPU BASELINE configs, driver-observed: C2 (N = 16 384, D = 3, SE), C3 (N = 32 768, D = 8,
     Matern32 ∘ ScaleTransform(0.5)) — one (logpdf, posterior) pair per step, fraction of the fp64 MFMA peak with F_pair = N³/3 + 3N² —
     and C5 (VFE, N = 262 144, M = 4 096, fp32: posterior + ELBO per step, F = 2NM² + 2M³/3 against the fp32 MFMA peak).
-    Untimed with respect to the headline: runs after the C4 loop; one warm-up step each, `steps` timed steps, wall clock."""
+    Untimed with respect to the headline: runs after the C4 loop; one warm-up step each, `steps` (>= 5) timed steps, wall clock per step,
+    the MEDIAN is reported (min alongside)."""
     out = {}
+    last_times = []
 
     def timed(fn):
         fn()
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(steps):
+            t0 = time.perf_counter()
             fn()
-        return (time.perf_counter() - t0) / steps
+            ts.append(time.perf_counter() - t0)
+        last_times[:] = ts
+        return float(np.median(ts))
 
     for name, n, d, seed, kern, desc in (
             ("C2", 16384, 3, 2, agp.SqExponentialKernel(), "GP(SqExponentialKernel()) on 16384 3-D points, sigma2=0.01, fp64"),
@@ -159,8 +164,8 @@ def other_configs(agp, ctx, steps: int = 3) -> dict:
 
         dt = timed(pair)
         tf = f_pair(n) / dt / 1e12
-        out[name] = {"workload": desc, "ms_per_step": dt * 1e3, "steps": steps, "points_per_s": n / dt, "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                     "peak": FP64_MFMA_PEAK_TFLOPS}
+        out[name] = {"workload": desc, "ms_per_step": dt * 1e3, "ms_min": min(last_times) * 1e3, "steps": steps, "statistic": "median", "points_per_s": n / dt,
+                     "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS, "peak": FP64_MFMA_PEAK_TFLOPS}
     rng = np.random.default_rng(5)
     n, m, d = 262144, 4096, 3
     X = (rng.uniform(0, 1, (n, d)) * 4).astype(np.float32)
@@ -178,7 +183,8 @@ def other_configs(agp, ctx, steps: int = 3) -> dict:
 
     dt = timed(fit)
     flops = 2.0 * n * m * m + 2.0 * m**3 / 3
-    out["C5"] = {"workload": "VFE posterior + ELBO, N=262144, M=4096 pseudo-points, D=3, sigma2=0.1, jitter 1e-4, fp32", "ms_per_step": dt * 1e3, "steps": steps,
+    out["C5"] = {"workload": "VFE posterior + ELBO, N=262144, M=4096 pseudo-points, D=3, sigma2=0.1, jitter 1e-4, fp32", "ms_per_step": dt * 1e3,
+                 "ms_min": min(last_times) * 1e3, "steps": steps, "statistic": "median",
                  "points_per_s": n / dt, "tflops": flops / dt / 1e12, "frac_fp32": flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS,
                  "elbo": obj[-1]}
     ctx.trim()
@@ -200,6 +206,130 @@ def cached_cpu_baseline(n_full: int):
                                   f"profiles/{rnd}/fullsize_parity.jsonl; the live bounded sample is timed by the --gpus 1 run",
                         "two_factorisations": {"value": r["oracle_points_per_s_two_factorisations"], "unit": "points/s"}}
     return None
+
+
+HBM_SPEC_TBPS = 8.0      # MI355X_MICROARCH.md: HBM3E spec
+HBM_COPY_TBPS = 6.29     # MI355X_MICROARCH.md: measured float4 copy
+
+
+def digest_check(n: int, logpdf_val: float, alpha: np.ndarray) -> dict:
+    """The timed engine's result against the committed digest of the ORACLE's C4 run (tests/golden/digests/c4_oracle_digest.npz, written by
+    tests/golden/make_c4_digest.py / the GPU suite's C4 value test from the oracle on an MI355X box's host): logpdf, and α through its
+    norm, every 64th entry and eight seeded Gaussian projections.  Tolerances of SURVEY.md §8(c): 1e-10 / 1e-8."""
+    path = ROOT / "tests" / "golden" / "digests" / "c4_oracle_digest.npz"
+    if not path.exists():
+        return {"check_vs_oracle_digest": "digest file absent"}
+    dig = np.load(path)
+    if int(dig["n"]) != n:
+        return {"check_vs_oracle_digest": f"digest is for N={int(dig['n'])}"}
+    a = np.asarray(alpha, dtype=np.float64)
+    nrm = float(np.linalg.norm(a))
+    scale = float(dig["alpha_norm"]) / np.sqrt(n)
+    proj = np.array([float(np.random.default_rng(20260926 + i).standard_normal(n) @ a) / np.sqrt(n) for i in range(8)])
+    e = max(abs(nrm - float(dig["alpha_norm"])) / float(dig["alpha_norm"]),
+            float(np.linalg.norm(a[::64] - dig["alpha_sub"]) / np.linalg.norm(dig["alpha_sub"])),
+            float(np.max(np.abs(proj - dig["alpha_proj"])) / scale))
+    lp_rel = abs(logpdf_val - float(dig["logpdf"])) / abs(float(dig["logpdf"]))
+    return {"check_logpdf_rel_vs_oracle_digest": lp_rel, "check_alpha_rel_vs_oracle_digest": e,
+            "check_vs_oracle_digest": "pass" if (lp_rel <= 1e-10 and e <= 1e-8) else "FAIL"}
+
+
+def next_rows(agp, ctx, post, x, y, n: int, sigma2: float) -> dict:
+    """SURVEY.md §8(f) on the engine of this run, at the bench size, each with its roofline fraction (fp64 MFMA 78.6 TF/s; algorithmic flops):
+    predictive marginals at 4 096 points (TRSM against the resident factor: N²·N* flops), the full 1 024² predictive covariance (N²·N* + N·N*²),
+    sequential conditioning on 8 192 new observations (N²·n2 + N·n2² + n2³/3), value + gradient of logpdf (N³/3 for the factor + 2N³/3 for C⁻¹
+    by triangular inverse and LᵀL product).  One warm-up where the call is cheap, wall clock."""
+    out = {}
+    rng = np.random.default_rng(11)
+    pk = FP64_MFMA_PEAK_TFLOPS * 1e12
+
+    def rec(name, dt, flops, note):
+        out[name] = {"ms": dt * 1e3, "flops": flops, "tflops": flops / dt / 1e12, "frac": flops / dt / pk, "what": note}
+
+    xs = rng.standard_normal((4096, x.shape[1]))
+    post.mean_and_var(agp.RowVecs(xs[:256]))
+    t0 = time.perf_counter()
+    post.mean_and_var(agp.RowVecs(xs))
+    rec("mean_and_var_4096", time.perf_counter() - t0, float(n) * n * 4096, "marginals at 4096 test points: K_*x, TRSM with the resident factor, column sums")
+    t0 = time.perf_counter()
+    post.cov(agp.RowVecs(xs[:1024]))
+    rec("cov_1024", time.perf_counter() - t0, float(n) * n * 1024 + float(n) * 1024 * 1024, "full 1024x1024 predictive covariance: TRSM + SYRK")
+    n2 = 8192
+    x2 = rng.standard_normal((n2, x.shape[1]))
+    y2 = np.sin(x2.sum(1)) + 0.1 * rng.standard_normal(n2)
+    t0 = time.perf_counter()
+    p2 = agp.posterior(post(agp.RowVecs(x2), sigma2), y2)
+    rec("sequential_update_8192", time.perf_counter() - t0, float(n) * n * n2 + float(n) * n2 * n2 + n2**3 / 3.0,
+        "posterior(post(x2, s2), y2) with 8192 new observations: bordered Cholesky on the resident factor")
+    p2.data.C.free()
+    return out
+
+
+def grad_rows(agp, ctx) -> dict:
+    """value + gradient of logpdf w.r.t. (variance, scale, noise, y) at C2 and C4."""
+    out = {}
+    pk = FP64_MFMA_PEAK_TFLOPS * 1e12
+    for name, n, seed in (("C2", 16384, 2), ("C4", 65536, 4)):
+        x, y = synth_inputs(n, 3, seed)
+        fx = agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(1.0), ctx=ctx)(agp.RowVecs(x), 0.01)
+        if name == "C2":
+            agp.logpdf_and_grad(fx, y)
+        t0 = time.perf_counter()
+        lp, g = agp.logpdf_and_grad(fx, y)
+        dt = time.perf_counter() - t0
+        flops = float(n)**3  # N³/3 factor + 2N³/3 for C⁻¹ (trtri N³/3 + lauum N³/3)
+        out[name] = {"ms": dt * 1e3, "flops": flops, "tflops": flops / dt / 1e12, "frac": flops / dt / pk, "logpdf": float(lp),
+                     "what": "logpdf + d/d(variance, scale, noise, y): factor, C^-1 = L^-T L^-1 (triangular inverse + triangular product), one fused gradient pass"}
+        ctx.trim()
+    return out
+
+
+def rocsolver_comparator(sizes=(16384, 32768, 65536)) -> dict:
+    """COMPARATOR ONLY (SURVEY.md §7 allows vendor libraries as yardsticks; nothing in the product path loads them): rocsolver_dpotrf of an SPD
+    matrix of the same order on the same GPU, run after the timed region through ctypes.  Reports ms and the fraction of the fp64 MFMA peak
+    for N³/3 flops, next to which the engine's own factorisation phase can be read."""
+    import ctypes as C
+
+    import torch
+
+    out = {}
+    try:
+        rb = C.CDLL("/opt/rocm/lib/librocblas.so", mode=C.RTLD_GLOBAL)
+        rs = C.CDLL("/opt/rocm/lib/librocsolver.so", mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        return {"error": f"rocSOLVER unavailable: {e}"}
+    h = C.c_void_p()
+    if rb.rocblas_create_handle(C.byref(h)) != 0:
+        return {"error": "rocblas_create_handle failed"}
+    rb.rocblas_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    rs.rocsolver_dpotrf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    try:
+        for n in sizes:
+            g = torch.randn(n, 64, dtype=torch.float64, device="cuda")
+            a0 = g @ g.T
+            a0.diagonal().add_(float(n))
+            del g
+            ts = []
+            for rep in range(3 if n <= 32768 else 2):
+                a = a0.clone()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st = rs.rocsolver_dpotrf(h, 122, n, C.c_void_p(a.data_ptr()), n, C.c_void_p(info.data_ptr()))  # rocblas_fill_lower = 122
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+                del a
+            dt = min(ts[1:]) if len(ts) > 1 else ts[0]
+            out[f"N{n}"] = {"ms": dt * 1e3, "tflops": n**3 / 3 / dt / 1e12, "frac": n**3 / 3 / dt / (FP64_MFMA_PEAK_TFLOPS * 1e12), "status": int(st),
+                            "info": int(info.item())}
+            del a0
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001 — a comparator must never take the bench line down
+        out["error"] = repr(e)
+    finally:
+        rb.rocblas_destroy_handle(h)
+    out["note"] = "rocsolver_dpotrf (ROCm 7.2) on a random SPD matrix of the same order, same GPU, after the timed region; comparator only"
+    return out
 
 
 def selftest(ngpus: int, virtual: int, grid: str) -> int:
@@ -301,6 +431,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C3 / C5 lines (other_configs)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity properties")
+    ap.add_argument("--no-comparator", action="store_true", help="skip the rocsolver_dpotrf comparator (run after the timed region; never on the product path)")
     ap.add_argument("--dry-launcher", action="store_true",
                     help="launcher protocol only (gloo process group, barriers, max over ranks, rank 0 prints the line) with a stub step and no GPU: "
                          "what the world_size-2 CPU test runs")
@@ -426,6 +557,13 @@ def main():
                         "flops_per_launch_avg": gemm_flops / max(gemm_launches, 1),
                         "measured_mfma_f64_ceiling_tflops": mfma_ceiling.value}
             extra["phases_ms"] = phases
+            if not multi and phases["assemble_ms"] > 0:  # the Gram phase is HBM-write bound: 8·N(N+1)/2 written once + 8·N·D read
+                kb = 8.0 * n * (n + 1) / 2 + 8.0 * n * d
+                gbps = kb / (phases["assemble_ms"] * 1e-3) / 1e9
+                roofline["kmat"] = {"kernel": "kmat_kernel<double>", "bound": "hbm", "algorithmic_bytes": kb, "ms": phases["assemble_ms"], "achieved": gbps,
+                                    "unit": "GB/s", "frac_of_8TBps_spec": gbps / (HBM_SPEC_TBPS * 1e3), "frac_of_6.29TBps_copy": gbps / (HBM_COPY_TBPS * 1e3)}
+            if not args.no_check and n == 65536:
+                extra.update(digest_check(n, logpdf_val, alpha))
             if not args.no_check:  # size-independent parity properties at full size
                 r = np.asarray(post.data.delta, dtype=np.float64)
                 # (K + σ²I) α = δ  checked through a second, independent device path: posterior mean at the
@@ -434,8 +572,17 @@ def main():
                 m_tr = post.mean(agp.RowVecs(x[idx]))
                 extra["check_residual_max"] = float(np.max(np.abs(m_tr - (r[idx] - sigma2 * alpha[idx]))))
             if not multi and not args.no_other_configs and n == 65536:
+                nxt = next_rows(agp, ctx, post, x, y, n, sigma2)
                 post.data.C.free()
+                ctx.trim()
                 extra["other_configs"] = other_configs(agp, ctx)
+                nxt["value_and_gradient"] = grad_rows(agp, ctx)
+                extra["other_configs"]["next"] = nxt
+                ctx.trim()
+                if not args.no_comparator:
+                    extra["comparator_rocsolver_dpotrf"] = rocsolver_comparator()
+            if multi:
+                extra["multi_stats"] = ctx.multi_stats()  # fits / retries (repetitions after a failed self-check) / solves: a non-zero retry count is never silent
             if multi:
                 parallelism = (f"in-library 2D block-cyclic {info['P']}x{info['Q']}, nb={info['nb']}, look-ahead {info['lookahead_depth']}, "
                                f"transport {info['comm']}" + (f" [{args.virtual} virtual ranks on one GPU]" if args.virtual else "")

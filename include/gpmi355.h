@@ -148,6 +148,11 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    oracle at the stated tolerances but are NOT bitwise reproducible from run to run; 0 removes this source of
  *                    variation from the factorisation (hardware-dispatched GEMMs only, 1-5 % slower at N <= 32 768; the backward
  *                    vector sweep still adds four partial products per column with atomics)
+ *   "deterministic"  1: the exact path (gp_logpdf, gp_logpdf_terms, gp_posterior_fit and every method of its posterior) uses no
+ *                    floating-point atomics — no stream-K tails whatever "gemm_streamk" says, one thread per column in the backward
+ *                    sweep — so two calls with the same inputs on the same ctx return the same BITS (tests/test_gpu_api.py).  The VFE
+ *                    path, the gradient kernels and the multi-device backward sweep keep their atomics.  1-5 % slower at N <= 32 768.   default 0
+ *   "leaf_v2", "leaf_xr"  fp64 leaves by the register-resident panel64v2_kernel (csrc/leaf.hpp) / rows of X per leaf workgroup (0 auto)   default 1, 0
  *   "leaf_group"     columns factored left-looking by consecutive fused leaves (64/128/256/512)   default 128
  *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one

@@ -475,3 +475,32 @@ def test_gradient_for_inputs_of_any_dimension(agp, d, ard):
     np.testing.assert_allclose(g["scale"], go["scale"], rtol=1e-6, atol=1e-9)
     assert g["noise"] == pytest.approx(go["noise"], rel=1e-7)
     np.testing.assert_allclose(g["x"], go["x"], rtol=1e-6, atol=1e-8)
+
+
+def test_deterministic_mode_is_bitwise_repeatable(agp):
+    """ctx parameter "deterministic" = 1: no floating-point atomics in the exact path (no stream-K tails, one thread per column in the
+    backward sweep) — two fits on the same inputs return the same BITS (logpdf, α, the whole factor, predictive mean / variance), with
+    the look-ahead on (several panels) and without; and the result still meets the oracle tolerances."""
+    n, d = 3000, 3
+    x, y = o.synth_inputs(n, d, 77)
+    ref_lp, ref_post = o.logpdf_and_posterior(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y)
+    ctx = agp.Context(0)
+    ctx.set_param("deterministic", 1)
+    try:
+        for nb in (1024, 2048):
+            ctx.set_param("nb", nb)
+            f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
+            runs = []
+            for _ in range(3):
+                post = agp.posterior(f(agp.RowVecs(x), 0.01), y)
+                m, v = post.mean_and_var(agp.RowVecs(x[:64] + 0.1))
+                runs.append((np.float64(post.logpdf_value), np.array(post.data.alpha), np.array(post.data.C.U), np.array(m), np.array(v),
+                             np.float64(agp.logpdf(f(agp.RowVecs(x), 0.01), y))))
+                post.data.C.free()
+            for r in runs[1:]:
+                for a, b in zip(runs[0], r):
+                    assert np.array_equal(np.asarray(a), np.asarray(b))
+            assert runs[0][0] == pytest.approx(ref_lp, rel=1e-10) and runs[0][5] == pytest.approx(ref_lp, rel=1e-10)
+            assert np.linalg.norm(runs[0][1] - ref_post.alpha) / np.linalg.norm(ref_post.alpha) <= 1e-8
+    finally:
+        ctx.close()

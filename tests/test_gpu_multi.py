@@ -335,7 +335,28 @@ def test_schedule_under_truly_concurrent_streams():
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", DIAG_ITERS="9")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", DIAG_ITERS="4")  # 9 iterations cost 370 s of the suite: 4 still visit every grid x depth pair
     r = subprocess.run([sys.executable, str(root / "tools" / "multi_diag.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "FAILURES 0" in r.stdout
+
+
+def test_fresh_context_first_fits_with_every_diagnostic_on():
+    """The regime of round 2's wrong first fits, in the suite instead of a tool: fresh 8-rank contexts (8x1 and 4x2, 16 hardware queues,
+    stream-K and the high-priority comm stream on in the rank contexts), FIRST fit only, "multi_check" 7 (event markers, operand
+    verification against the owners' final blocks, NaN-poisoned buffers) and the shipped self-check ("multi_verify" 1, one repetition).
+    tools/multi_fresh_stress.py prints one line per wrong result / error and exits 1 on any: a library-side race that the repetition
+    would otherwise paper over shows up as a device-side finding of the diagnostics (an ERROR line), not as a silent retry.  The count
+    of repetitions is printed into the log (a non-zero count is the arguments-below-the-library effect of DESIGN.md §5.3)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    for comm in ("p2p", "rccl"):
+        r = subprocess.run([sys.executable, str(root / "tools" / "multi_fresh_stress.py"), "6", "check=7", "verify=1", f"comm={comm}", "grids=8x1,4x2", "n=1537"],
+                           capture_output=True, text=True, timeout=600)
+        tail = (r.stdout.strip().splitlines() or [""])[-1]
+        print(f"[fresh-context stress, {comm}] {tail}")
+        assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+        assert "0 bad of 12" in tail, tail
