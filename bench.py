@@ -118,10 +118,10 @@ def cpu_baseline(n_full: int, d: int):
 
 def pmc_traffic(n: int) -> dict:
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over THIS command
-    (tools/gpu_r3_prof.sh -> profiles/r3/pmc_bench_summary.json; FETCH_SIZE and WRITE_SIZE are reported in KiB and
+    (tools/gpu_r4_prof.sh -> profiles/r4/pmc_bench_summary.json; FETCH_SIZE and WRITE_SIZE are reported in KiB and
     FETCH_SIZE is doubled, the gfx950 correction for 16-B/lane streaming reads of MI355X_MICROARCH.md §HBM).
     PMC cannot be sampled from inside the timed run, so this is null when the summary is absent or for another N."""
-    path = next((q for q in (ROOT / "profiles" / r / "pmc_bench_summary.json" for r in ("r3", "r2", "r1")) if q.exists()), ROOT / "nonexistent")
+    path = next((q for q in (ROOT / "profiles" / r / "pmc_bench_summary.json" for r in ("r4", "r3", "r2", "r1")) if q.exists()), ROOT / "nonexistent")
     if n != 65536 or not path.exists():
         return {"traffic": None}
     s = json.loads(path.read_text())
@@ -257,6 +257,7 @@ def next_rows(agp, ctx, post, x, y, n: int, sigma2: float) -> dict:
     n2 = 8192
     x2 = rng.standard_normal((n2, x.shape[1]))
     y2 = np.sin(x2.sum(1)) + 0.1 * rng.standard_normal(n2)
+    agp.posterior(post(agp.RowVecs(x2), sigma2), y2).data.C.free()  # warm-up: the first call allocates the (N + n2)² block (hipMalloc of 43 GB ≈ 1.3 s)
     t0 = time.perf_counter()
     p2 = agp.posterior(post(agp.RowVecs(x2), sigma2), y2)
     rec("sequential_update_8192", time.perf_counter() - t0, float(n) * n * n2 + float(n) * n2 * n2 + n2**3 / 3.0,
@@ -536,6 +537,20 @@ def main():
             ctx.set_param("time_kernels", 0)
             gemm_ms, gemm_flops, gemm_bytes, gemm_launches = tm["gemm_ms"], tm["gemm_flops"], tm.get("gemm_bytes", 0.0), tm["gemm_launches"]
             kernel_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            # the same launches with the look-ahead off: every GEMM then has the machine to itself, so its event-bracketed duration is the
+            # kernel's own (with the look-ahead the register-resident leaves of the panel stream share CUs with the update, which shortens the
+            # wall time and lengthens each launch as the events — and rocprofv3 — see it)
+            kernel_alone = None
+            if not multi:
+                post.data.C.free()
+                ctx.set_param("lookahead", 0)
+                ctx.set_param("time_kernels", 1)
+                post = step()
+                tm0 = ctx.timings()
+                ctx.set_param("time_kernels", 0)
+                ctx.set_param("lookahead", 1)
+                if tm0["gemm_ms"] > 0:
+                    kernel_alone = tm0["gemm_flops"] / (tm0["gemm_ms"] * 1e-3) / 1e12
             mfma_ceiling = agp._lib.C.c_double()
             agp._lib.check(ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, agp._lib.C.byref(mfma_ceiling)))
             pair_tf = f_pair(n) / (dt / args.steps) / 1e12
@@ -550,6 +565,7 @@ def main():
                         "kernel": "gemm_nt_dma_kernel<double> (v_mfma_f64_16x16x4_f64 trailing update, LDS-DMA operands; launches of <= 4096 tiles run its "
                                   "persistent stream-K variant gemm_nt_sk_kernel — kernel_* and the per-launch averages cover both)",
                         "kernel_achieved": kernel_tflops, "kernel_frac": kernel_tflops / FP64_MFMA_PEAK_TFLOPS,
+                        "kernel_achieved_lookahead_off": kernel_alone, "kernel_frac_lookahead_off": None if kernel_alone is None else kernel_alone / FP64_MFMA_PEAK_TFLOPS,
                         "kernel_timing": "separate untimed pass with time_kernels=1 (HIP events around each launch on its stream)",
                         "algorithmic_bytes_per_launch_avg": gemm_bytes / max(gemm_launches, 1),
                         "launches_per_step": gemm_launches,

@@ -4,6 +4,17 @@
 #include "../abstractgps.jl_amd/csrc/kcommon.hpp"
 #include <cstdio>
 using namespace gpmi;
+
+typedef __attribute__((address_space(3))) void lds_void_p_t;
+__device__ __forceinline__ double rcp_full(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    const double q = fma(e, e, e);
+    return fma(r, q, r);
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long)(lds_void_p_t*)p; }
+__device__ __forceinline__ void lds_put_f64(unsigned addr, double v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_put_i32(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 template <int V> __global__ void f16(double* out, long* cyc, const double* in) {
     using TR = Tr<double>;
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
@@ -133,6 +144,45 @@ template <int V> __global__ void f16k(double* out, long* cyc, const double* in) 
     out[lane] = s + abuf[3][lane];
     if (lane == 0) cyc[12 + V] = t1 - t0;
 }
+// the same column loop as f16<0>, executed 16 times by a REAL loop (the 16 columns unrolled once): is the straight-line version fetch bound?
+__global__ void f16loop(double* out, long* cyc, const double* in) {
+    using TR = Tr<double>;
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    d4_t accA, accW, Ls, Ws;
+    for (int r = 0; r < 4; ++r) { accA[r] = in[lane * 4 + r]; accW[r] = (li == lg + 4 * r) ? 1.0 : 0.0; Ls[r] = 0; Ws[r] = 0; }
+    double sel = (lg == 0) ? fast_rsqrt<double>(lane_bcast<double>(accA[0], 0)) : 0.0;
+    long t0, t1, tm = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    asm volatile("" : "+v"(sel));
+#pragma unroll 1
+    for (int rep = 0; rep < 16; ++rep) {
+        if (rep == 1) { asm volatile("" : "+v"(sel)); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory"); asm volatile("" : "+v"(sel)); }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = c & 3, p = c >> 2;
+            const double pa = accA[p] * sel, npa = -pa;
+            const int c1 = (c + 1) & 15, k1 = c1 & 3, p1i = c1 >> 2;
+            const double l = lane_bcast<double>(pa, 16 * k + c1);
+            const double dnext = lane_bcast<double>(accA[p1i], 16 * k1 + c1);
+            accA = TR::mfma(npa, pa, accA);
+            __builtin_amdgcn_sched_barrier(0);
+            const double pw = accW[p] * sel;
+            Ls[p] = (lg == k) ? pa : Ls[p]; Ws[p] = (lg == k) ? pw : Ws[p];
+            const double piv = fma(-l, l, dnext);
+            const double ri = fast_rsqrt<double>(piv);
+            sel = (lg == k1) ? ri : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+            accW = TR::mfma(npa, pw, accW);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("" : "+v"(sel));
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    double s = sel;
+    for (int r = 0; r < 4; ++r) s += accA[r] + accW[r] + Ls[r] + Ws[r];
+    out[lane] = s;
+    if (lane == 0) { cyc[6] = tm - t0; cyc[7] = t1 - tm; }
+}
 int main() {
     double *out, *in; long* cyc;
     hipMalloc(&out, 8 * 64); hipMalloc(&in, 8 * 256); hipMalloc(&cyc, 8 * 16); hipMemset(cyc, 0, 8 * 16);
@@ -152,10 +202,12 @@ int main() {
         hipLaunchKernelGGL(f16k<0>, dim3(1), dim3(64), 0, 0, out, cyc, in); hipLaunchKernelGGL(f16k<1>, dim3(1), dim3(64), 0, 0, out, cyc, in);
         hipLaunchKernelGGL(f16k<2>, dim3(1), dim3(64), 0, 0, out, cyc, in); hipLaunchKernelGGL(f16k<3>, dim3(1), dim3(64), 0, 0, out, cyc, in);
     }
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(f16loop, dim3(1), dim3(64), 0, 0, out, cyc, in);
     hipDeviceSynchronize();
     long c[16]; hipMemcpy(c, cyc, sizeof(c), hipMemcpyDeviceToHost);
     const char* nm[] = {"full", "no W-update MFMA", "no MFMA at all", "no 1/sqrt chain", "no broadcasts", "only the two MFMAs + 2 mul"};
     for (int v = 0; v < 6; ++v) printf("%-28s %7.1f cycles per column\n", nm[v], (double)c[v] / 64.0);
+    printf("%-28s %7.1f cycles per column (first pass of the loop body)   %7.1f (passes 2..16, code resident)\n", "full, as a real loop", (double)c[6] / 16.0, (double)c[7] / 240.0);
     const char* nl[] = {"LDL full", "LDL no W-update MFMA", "LDL no MFMA at all", "LDL no saves"};
     for (int v = 0; v < 4; ++v) printf("%-28s %7.1f cycles per column\n", nl[v], (double)c[8 + v] / 64.0);
     const char* nk[] = {"kernel loop", "kernel loop, no LDS stream", "kernel loop, no saves", "kernel loop, neither"};
