@@ -313,7 +313,7 @@ static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, lo
     if constexpr (std::is_same<T, double>::value) {
         if (c->leaf_v2) {  // register-resident leaf (leaf.hip: panel64v2_kernel)
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mrows, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, kpre,
-                                              c->leaf_xr, c->num_cus));
+                                              c->leaf_xr, c->num_cus, 64));
             return 0;
         }
     }
@@ -329,6 +329,19 @@ template <typename T>
 static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long n, long mtot, int* info_dev,
                          long gcol0, long n_valid, double* logdet_dev) {
     if (n <= 64) return launch_leaf<T>(c, s, A, lda, j0, mtot, info_dev, gcol0, n_valid, logdet_dev, 0);
+    if constexpr (std::is_same<T, double>::value) {
+        if (n == 128 && c->leaf_v2 && c->leaf_cols == 128 && c->leaf_group >= 128) {  // one 128-column register-resident leaf (leaf.hip)
+            if (!c->ticket_dev) {
+                HIPCHK(hipMalloc((void**)&c->ticket_dev, sizeof(int) * 64));
+                HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
+                HIPCHK(hipDeviceSynchronize());
+            }
+            int* const tk = c->ticket_dev + ((s == c->sp || (s == c->sp_mask && s)) ? 32 : 0);
+            HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mtot - j0 - 128, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, 0,
+                                              c->leaf_xr, c->num_cus, 128));
+            return 0;
+        }
+    }
     if (n <= c->leaf_group) {  // left-looking group: leaf t first applies the t tiles to its left itself
         for (long t = 0; t < n / 64; ++t)
             RC(launch_leaf<T>(c, s, A, lda, j0 + 64 * t, mtot, info_dev, gcol0, n_valid, logdet_dev, (int)t));
@@ -1485,6 +1498,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "deterministic")) c->deterministic = v != 0;
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
     else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
+    else if (!strcmp(name, "leaf_cols")) c->leaf_cols = v == 64 ? 64 : 128;
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);

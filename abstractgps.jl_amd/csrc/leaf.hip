@@ -6,16 +6,24 @@
 
 namespace gpmi {
 
-// one register-resident 64-column leaf on stream s (same contract as panel64_kernel: kernels.hpp).  xr: rows of X per workgroup
-// (64 / 128); 0 = 64 while that gives at most two workgroups per CU, else 128.
+// one register-resident leaf on stream s: ncols = 64 (same contract as panel64_kernel: kernels.hpp) or 128 (kpre must be 0; mrows counts
+// the rows below the 128×128 tile).  xr: rows of X per workgroup (64 / 128); 0 = 64 while that gives at most two (ncols = 64) / one
+// (ncols = 128: 150 KB of LDS per workgroup) workgroups per CU, else 128.
 int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* info_dev, int col0, int n_valid, double* logdet_dev, int* ticket,
-                       int kpre, int xr, int num_cus) {
-    const bool xr64 = xr == 64 || (xr == 0 && mrows <= 64L * 2 * num_cus);
+                       int kpre, int xr, int num_cus, int ncols) {
+    const bool wide = ncols == 128;
+    const bool xr64 = xr == 64 || (xr == 0 && mrows <= 64L * (wide ? 1 : 2) * num_cus);
     const unsigned nb = (unsigned)std::max(1L, (mrows + (xr64 ? 63 : 127)) / (xr64 ? 64 : 128));
-    if (xr64)
-        hipLaunchKernelGGL(panel64v2_kernel<64>, dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
-    else
-        hipLaunchKernelGGL(panel64v2_kernel<128>, dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
+    if (wide) {
+        if (xr64)
+            hipLaunchKernelGGL((panel64v2_kernel<64, 8>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, 0);
+        else
+            hipLaunchKernelGGL((panel64v2_kernel<128, 8>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, 0);
+    } else if (xr64) {
+        hipLaunchKernelGGL((panel64v2_kernel<64, 4>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
+    } else {
+        hipLaunchKernelGGL((panel64v2_kernel<128, 4>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
+    }
     return (int32_t)hipGetLastError();  // hipError_t of the launch (0 = hipSuccess)
 }
 

@@ -38,22 +38,33 @@ namespace gpmi {
 //   kpre > 0 (left-looking entry, as in panel64_kernel): the kpre tiles to the left are applied first, L_k staged in LDS, the left
 //   tile's rows of this workgroup loaded in natural layout and used as the B operands of P1 / both operands of P2.
 // ------------------------------------------------------------------------------------------------
-// The body of one wave, specialised on the wave's role W (0: the pivot chain; 1..3: owners): what a wave owns is then known at compile
-// time — no exec-masked branch around any MFMA (the first version tested `t < nt`, `c < w` at run time: every such test became an
-// s_and_saveexec / s_cbranch pair that also fenced the scheduler, so operand reads from LDS were issued right before their use and
-// 140–160 cycles went by per MFMA instead of 62–70) — and the independent accumulators of a phase are updated slice by slice,
-// back to back.  All four instances execute the same barriers.
-template <int XR, int W>
+// The body of one wave, specialised on the wave's role W (0: the pivot chain; 1..3: owners) and on the number of 16-column tiles NC
+// of the leaf (4: a 64-column leaf; 8: a 128-column leaf): what a wave owns is then known at compile time — no exec-masked branch
+// around any MFMA (the first version tested `t < nt`, `c < w` at run time: every such test became an s_and_saveexec / s_cbranch pair
+// that also fenced the scheduler, operand reads from LDS were issued right before their use and 140–160 cycles went by per MFMA
+// instead of 62–70) — and the independent accumulators of a phase are updated slice by slice, back to back.
+// Ownership: row tile t ≥ 1 of the diagonal tile belongs to wave 1 + (t − 1) mod 3 (blocks (t, c), c < t, natural; block (t, t)
+// symmetric); the XR/16 row tiles of X are spread over waves 1..3.
+// Synchronisation per step j: B1 (Inv_j published by wave 0) — the owner of row tile j+1 solves its block (j+1, j), updates block
+// (j+1, j+1) and hands it over — B2 (wave 0 goes on with block j+1; nobody waits for the other row tiles here).  The other row tiles'
+// blocks (t, j) are solved and published AFTER B2; the owners meet at a counter in LDS (`pub`: one increment per owner and step) before
+// the updates that read them — wave 0 takes no part in that, so the pivot chain waits only for the one block it needs.
+// All four instances execute the same workgroup barriers.
+template <int XR, int W, int NC>
 __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0, int n_valid,
                                           double* __restrict__ logdet_acc, int* __restrict__ ticket, int kpre, double* __restrict__ Lp,
-                                          double* __restrict__ Inv, double* __restrict__ dAx, int* __restrict__ writer_s) {
+                                          double* __restrict__ Inv, double* __restrict__ dAx, int* __restrict__ writer_s,
+                                          int* __restrict__ pub) {
     using TR = Tr<double>;
-    constexpr int LDP = 66, LIP = 18;            // row pitches (doubles): 16-byte aligned rows for the 4-double operand reads
+    constexpr int NCOL = 16 * NC;                // columns of the leaf
+    constexpr int LDP = NCOL + 2, LIP = 18;      // row pitches (doubles): 16-byte aligned rows for the 4-double operand reads
     constexpr int NXT = XR / 16;                 // row tiles of X per workgroup
     constexpr int NTW = (NXT + 2) / 3;           // X row tiles per owner wave (waves 1..3)
     constexpr int T0 = W == 0 ? 0 : (W - 1) * NTW;
     constexpr int NT = W == 0 ? 0 : ((NXT - T0) < 0 ? 0 : ((NXT - T0) < NTW ? (NXT - T0) : NTW));
     constexpr int NTA = NT > 0 ? NT : 1;         // array extent
+    constexpr int ND = W == 0 ? 0 : (NC - W + 2) / 3;  // row tiles of the diagonal tile owned by this wave: t = W + 3 s
+    constexpr int NDA = ND > 0 ? ND : 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
 #ifdef GPMI_PANEL_STAMPS
@@ -67,7 +78,7 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
     const int pirow = 4 * (li & 3) + (li >> 2);  // π(li)
     int xrows = mrows - (int)blockIdx.x * XR;
     xrows = xrows < 0 ? 0 : (xrows > XR ? XR : xrows);
-    double* const Xg = A + (long)(64 + (long)blockIdx.x * XR) * lda;
+    double* const Xg = A + (long)(NCOL + (long)blockIdx.x * XR) * lda;
 
     auto ld4 = [&](const double* p16) -> d4_t {  // 32 bytes as two 16-byte pieces (global or LDS)
         const d2_t* src = reinterpret_cast<const d2_t*>(p16);
@@ -110,63 +121,80 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
     };
 
     // ---- what this wave owns, loaded straight into registers
-    d4_t dA = ld_sym(W);  // wave 0: the block being factored; owner W: block (W, W)
-    d4_t y[3];            // owner W: blocks (W, c), c < W
-    d4_t x[NTA][4];       // X row tiles
+    d4_t dA = W == 0 ? ld_sym(0) : zero4();  // wave 0: the block being factored
+    d4_t dAt[NDA];                           // owner: blocks (t, t), t = W + 3 s
+    d4_t y[NDA][NC];                         // owner: blocks (t, c), c < t (the rest is never touched)
+    d4_t x[NTA][NC];                         // X row tiles
 #pragma unroll
-    for (int c = 0; c < 3; ++c) y[c] = c < W ? ld4(A + (long)(16 * W + li) * lda + 16 * c + 4 * lg) : zero4();
+    for (int s = 0; s < ND; ++s) {
+        const int t = W + 3 * s;
+        dAt[s] = ld_sym(t);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[s][c] = c < t ? ld4(A + (long)(16 * t + li) * lda + 16 * c + 4 * lg) : zero4();
+    }
+    // the rows of the diagonal tile are requested BEFORE the X rows (the compiler may not move memory operations across the asm): the
+    // ticket of step 0 needs only them, so the X rows (2·NT·NC requests per lane, the larger half of the prologue's HBM burst) stay in
+    // flight behind the first block's factorisation
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) x[t][c] = ld_x(t, 16 * c);
+        for (int c = 0; c < NC; ++c) x[t][c] = ld_x(t, 16 * c);
 
-    // ---- left-looking pre-update by the kpre tiles to the left (same rows): [D; X] −= [L_k; X_k] · L_kᵀ
-    for (int k = 0; k < kpre; ++k) {
-        const long coff = -64L * (kpre - k);
-        if (k > 0) __syncthreads();  // the previous tile's operand reads are done
+    // ---- left-looking pre-update by the kpre 64-column tiles to the left (same rows; 64-column leaves only): [D; X] −= [L_k; X_k] · L_kᵀ
+    if constexpr (NC == 4) {
+        for (int k = 0; k < kpre; ++k) {
+            const long coff = -64L * (kpre - k);
+            if (k > 0) __syncthreads();  // the previous tile's operand reads are done
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // stage L_k (64×64) into Lp: 1 024 pieces of 32 bytes over 256 threads
-            const int e = tid + 256 * i, row = e >> 4, pc = e & 15;
-            st4(&Lp[row * LDP + 4 * pc], ld4(A + (long)row * lda + coff + 4 * pc));
-        }
-        d4_t xk[NTA][4];  // the left tile's rows of this wave: requested before the barrier, consumed slice by slice behind it
+            for (int i = 0; i < 4; ++i) {  // stage L_k (64×64) into Lp: 1 024 pieces of 32 bytes over 256 threads
+                const int e = tid + 256 * i, row = e >> 4, pc = e & 15;
+                st4(&Lp[row * LDP + 4 * pc], ld4(A + (long)row * lda + coff + 4 * pc));
+            }
+            d4_t xk[NTA][4];  // the left tile's rows of this wave: requested before the barrier, consumed slice by slice behind it
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xk[t][q] = ld_x(t, coff + 16 * q);
-        __syncthreads();
+                for (int q = 0; q < 4; ++q) xk[t][q] = ld_x(t, coff + 16 * q);
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const d4_t dk = ld4(&Lp[(16 * W + li) * LDP + 16 * q + 4 * lg]);  // rows 16W.. of the left tile (natural), from the staged image
-            d4_t na[4];
+            for (int q = 0; q < 4; ++q) {
+                const d4_t dk = ld4(&Lp[(16 * W + li) * LDP + 16 * q + 4 * lg]);  // rows 16W.. of the left tile (natural), from the staged image
+                d4_t na[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) na[c] = neg4(aop(&Lp[(16 * c) * LDP + 16 * q], LDP));
-            const d4_t ndk = neg4(dk);
+                for (int c = 0; c < 4; ++c) na[c] = neg4(aop(&Lp[(16 * c) * LDP + 16 * q], LDP));
+                const d4_t ndk = neg4(dk);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                dA = TR::mfma(ndk[s], dk[s], dA);
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (W == 0) dA = TR::mfma(ndk[s], dk[s], dA);
+                    if constexpr (W != 0) dAt[0] = TR::mfma(ndk[s], dk[s], dAt[0]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (c < W && c < 3) y[c] = TR::mfma(na[c][s], dk[s], y[c]);
+                    for (int c = 0; c < 4; ++c) {
+                        if constexpr (W != 0) {
+                            if (c < W) y[0][c] = TR::mfma(na[c][s], dk[s], y[0][c]);
+                        }
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) x[t][c] = TR::mfma(na[c][s], xk[t][q][s], x[t][c]);
+                        for (int t = 0; t < NT; ++t) x[t][c] = TR::mfma(na[c][s], xk[t][q][s], x[t][c]);
+                    }
                 }
             }
         }
+        if (kpre > 0) __syncthreads();  // Lp is free for the published blocks
     }
-    if (kpre > 0) __syncthreads();  // Lp is free for the published blocks
 
     int bad = 0, tk_old = -1;
-    double mydiag[4] = {1.0, 1.0, 1.0, 1.0};  // wave 0, lane (c, c & 3): L_cc of column 16j + c
+    double mydiag[NC];  // wave 0, lane (c, c & 3): L_cc of column 16j + c
+#pragma unroll
+    for (int j = 0; j < NC; ++j) mydiag[j] = 1.0;
     PSTAMP2();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        PSTAMP2();
+    for (int j = 0; j < NC; ++j) {
+        if (j < 4) PSTAMP2();
         if constexpr (W == 0) {
             // P3: factor block (j, j) column by column on the accumulator; the identity rides transposed (accW).
             // What the measurements say (tools/lat_probe2.hip, tools/f16_probe.hip): fp64 VALU and the fp64 MFMA share ONE pipe on a
             // SIMD (an MFMA followed by 8 independent fma takes 62 + 56 cycles) and a VALU read of an MFMA result waits ≈ 30 cycles
-            // longer than a dependent MFMA, so a column costs roughly the SUM of what this wave issues — ≈ 300 cycles, against ≈ 500
+            // longer than a dependent MFMA, so a column costs roughly the SUM of what this wave issues — ≈ 290 cycles, against ≈ 500
             // on 16 of 64 lanes in the round-3 leaf.  The pivot of column c+1 is formed from the value before the update and the
             // multiplier (A[c+1][c+1] − L[c+1][c]², one fma), so its 1/√ chain is issued between the two MFMAs of column c instead of
             // behind them; the finished columns are kept by v_cndmask (Ls, Ws) and written once per block; a non-positive pivot turns
@@ -234,51 +262,84 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
                 }
             }
         }
-        // the ticket below says "this workgroup has READ the input tile": a workgroup barrier does not drain vmcnt, so do it by hand
-        if (j == 0 && W != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PSTAMP2();
-        __syncthreads();  // B1: Inv_j and L(j, j) are published
-        PSTAMP2();
-        if (j == 0 && W == 3 && lane == 0) tk_old = atomicAdd(ticket, 1);  // every load of the input tile has landed; the reply is awaited at the end
-        d4_t ai = zero4();
-        if constexpr (W != 0) ai = aop(&Inv[j * 16 * LIP], LIP);
-        if constexpr (W != 0) {
-            if (W > j) {  // this wave's block (W, j): the owner of row tile j+1 is on the critical path (it hands block (j+1, j+1) to wave 0)
-                d4_t r = zero4();
+        if constexpr (W != 0 && NT > 0) {
+            // X is updated LEFT-looking: column tile j receives every update of the steps before it now, in the shadow of wave 0's
+            // factorisation of block (j, j) — x_j −= Σ_{c<j} x_c L(j, c)ᵀ (4j MFMAs per row tile; every L(j, c) was published before the
+            // owners' rendezvous of step j−1) — so that after B1 only the solve with Inv_j is left.  Together with the right-looking
+            // updates of the diagonal tile's rows (most work in the first steps) an owner's work per step is nearly constant and stays
+            // below the pivot chain's; right-looking X updates put 7/8 of a 128-column leaf's X work into its first steps, where wave 0
+            // then waited ≈ 3 000 cycles per step at B1.
+            if (j > 0) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) r = TR::mfma(ai[s], y[j < 3 ? j : 0][s], r);
-                y[j < 3 ? j : 0] = r;
-                st4(&Lp[(16 * W + li) * LDP + 16 * j + 4 * lg], r);
-                const d4_t nr = neg4(r);
+                for (int c = 0; c < j; ++c) {
+                    const d4_t na = neg4(aop(&Lp[(16 * j) * LDP + 16 * c], LDP));
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dA = TR::mfma(nr[s], r[s], dA);
-                if (W == j + 1) {
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dAx[lane * 4 + q] = dA[q];
+                        for (int t = 0; t < NT; ++t) x[t][j] = TR::mfma(na[q], x[t][c][q], x[t][j]);
                 }
             }
         }
-        PSTAMP2();
-        __syncthreads();  // B2: L(t, j) of every row tile below and the next diagonal block are published
+        // the ticket below says "this workgroup has READ the input tile": a workgroup barrier does not drain vmcnt, so do it by hand
+        if (j == 0 && W != 0) {
+            if (NC == 4 && kpre > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (after a pre-update everything has been consumed anyway)
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT * NC < 63 ? 2 * NT * NC : 0) : "memory");
+        }
+        if (j < 4) PSTAMP2();
+        __syncthreads();  // B1: Inv_j and L(j, j) are published
+        if (j < 4) PSTAMP2();
+        if (j == 0 && W == 3 && lane == 0) tk_old = atomicAdd(ticket, 1);  // every load of the input tile has landed; the reply is awaited at the end
+        d4_t ai = zero4();
+        if constexpr (W != 0) ai = aop(&Inv[j * 16 * LIP], LIP);
+        // one block (t, j) of an owned row tile: solve, publish, update the tile's diagonal block
+        auto solve_block = [&](int s) {
+            const int t = W + 3 * s;
+            d4_t r = zero4();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r = TR::mfma(ai[q], y[s][j][q], r);
+            y[s][j] = r;
+            st4(&Lp[(16 * t + li) * LDP + 16 * j + 4 * lg], r);
+            const d4_t nr = neg4(r);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dAt[s] = TR::mfma(nr[q], r[q], dAt[s]);
+        };
+        if constexpr (W != 0) {
+            if (j + 1 < NC && (j + 1 - W) >= 0 && (j + 1 - W) % 3 == 0) {  // this wave owns row tile j+1: it is on the pivot chain
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int s = (j + 1 - W) / 3;
+                solve_block(s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dAx[lane * 4 + q] = dAt[s][q];
+            }
+        }
+        if (j < 4) PSTAMP2();
+        __syncthreads();  // B2: block (j+1, j+1) is handed over
+        if (j < 1) PSTAMP2();
         if constexpr (W == 0) {
-            if (j < 3) {
+            if (j + 1 < NC) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dA[r] = dAx[lane * 4 + r];
             }
+            if (j < 1) PSTAMP2();
         } else {
-            // X_j ← X_j Inv_jᵀ needs only Inv_j: it runs behind B2, in the shadow of wave 0's next block; the operands of the updates are
-            // requested first so that their LDS round trip hides behind these MFMAs
-            d4_t na[4];
+            // the other owned row tiles below j+1: solve and publish their blocks (t, j), then tell the other owners
 #pragma unroll
-            for (int c = 0; c < 4; ++c) na[c] = (c > j) ? neg4(aop(&Lp[(16 * c) * LDP + 16 * j], LDP)) : zero4();
+            for (int s = 0; s < ND; ++s) {
+                const int t = W + 3 * s;
+                if (t > j + 1) solve_block(s);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // X_j ← X_j Inv_jᵀ needs only Inv_j
             if constexpr (NT > 0) {
                 d4_t r[NTA];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) r[t] = zero4();
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) r[t] = TR::mfma(ai[s], x[t][j][s], r[t]);
+                    for (int t = 0; t < NT; ++t) r[t] = TR::mfma(ai[q], x[t][j][q], r[t]);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     x[t][j] = r[t];
@@ -286,15 +347,20 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
                     if (row < xrows) st4(Xg + (long)row * lda + 16 * j + 4 * lg, r[t]);  // column tile j of X is final
                 }
             }
-            if (j < 3) {
+            if (j + 1 < NC) {
+                // every L(c, j), c > j, must be published: three owners, one increment each per step
+                while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3 * (j + 1)) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int c = j + 1; c < NC; ++c) {
+                    const d4_t na = neg4(aop(&Lp[(16 * c) * LDP + 16 * j], LDP));
 #pragma unroll
-                    for (int c = j + 1; c < 4; ++c) {
-                        if (c < W && c < 3) y[c] = TR::mfma(na[c][s], y[j][s], y[c]);
+                    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) x[t][c] = TR::mfma(na[c][s], x[t][j][s], x[t][c]);
+                        for (int s = 0; s < ND; ++s)
+                            if (c < W + 3 * s) y[s][c] = TR::mfma(na[q], y[s][j][q], y[s][c]);
                     }
+                }
             }
         }
     }
@@ -303,15 +369,15 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
     __syncthreads();  // every published block is in Lp; writer_s is visible
     if (*writer_s) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = tid + 256 * i, row = e >> 6, c = e & 63;
+        for (int i = 0; i < NCOL * NCOL / 256; ++i) {
+            const int e = tid + 256 * i, row = e / NCOL, c = e % NCOL;
             if (c <= row) A[(long)row * lda + c] = Lp[row * LDP + c];
         }
         if constexpr (W == 0) {
             double logd = 0.0;
             if (lg == (li & 3)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NC; ++j)
                     if (col0 + 16 * j + li < n_valid) logd += log(mydiag[j]);
             }
 #pragma unroll
@@ -333,19 +399,23 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
 #undef PSTAMP2
 }
 
-template <int XR>
+// NC = 4: the 64-column leaf (same contract as panel64_kernel).  NC = 8: a 128-column leaf — mrows counts the rows below the 128×128
+// tile, kpre must be 0 (what a 64-column leaf's in-leaf pre-update does for the second half of a 128-column group is here part of the
+// ordinary update loop, on registers that are already loaded).
+template <int XR, int NC = 4>
 __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
                                                          int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket,
                                                          int kpre) {
-    __shared__ __attribute__((aligned(16))) double Lp[64 * 66];      // published blocks of L (natural rows); pre-update: the left tile
-    __shared__ __attribute__((aligned(16))) double Inv[4 * 16 * 18];
-    __shared__ __attribute__((aligned(16))) double dAx[64 * 4];      // hand-over of the next diagonal block (symmetric layout)
-    __shared__ int writer_s;
+    __shared__ __attribute__((aligned(16))) double Lp[16 * NC * (16 * NC + 2)];  // published blocks of L (natural rows); pre-update: the left tile
+    __shared__ __attribute__((aligned(16))) double Inv[NC * 16 * 18];
+    __shared__ __attribute__((aligned(16))) double dAx[64 * 4];                  // hand-over of the next diagonal block (symmetric layout)
+    __shared__ int writer_s, pub;
     const int w = threadIdx.x >> 6;  // wave-uniform: each wave runs the instance of its role
-    if (w == 0) leaf_wave<XR, 0>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
-    else if (w == 1) leaf_wave<XR, 1>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
-    else if (w == 2) leaf_wave<XR, 2>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
-    else leaf_wave<XR, 3>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s);
+    if (threadIdx.x == 0) pub = 0;   // (the first barrier inside orders this before any increment)
+    if (w == 0) leaf_wave<XR, 0, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
+    else if (w == 1) leaf_wave<XR, 1, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
+    else if (w == 2) leaf_wave<XR, 2, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
+    else leaf_wave<XR, 3, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
 }
 
 }  // namespace gpmi

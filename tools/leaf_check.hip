@@ -100,6 +100,67 @@ int main(int argc, char** argv) {
         printf("non-PD tile: info v1 %d v2 %d %s\n", infos[0], infos[1], infos[0] == 38 && infos[1] == 38 ? "OK" : "MISMATCH");
         if (!(infos[0] == 38 && infos[1] == 38)) worst_fail = 1;
     }
+    // ---- the 128-column leaf (NC = 8) against two round-3 leaves (the second applies the first in-leaf: kpre = 1)
+    for (long M : Ms) {
+        const long ld = 128 + 32, rows = M + 128 + 256;
+        std::vector<double> h((size_t)rows * ld, 0.0);
+        unsigned long st = 777 + 31 * (unsigned long)M;
+        auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (double)((st >> 11) & 0xfffff) / 1048576.0 - 0.5; };
+        for (long r = 0; r < M + 128; ++r)
+            for (long c = 0; c < 128; ++c) h[r * ld + c] = 0.3 * rnd();
+        for (long r = 0; r < 128; ++r)
+            for (long c = 0; c < 128; ++c) h[r * ld + c] = exp(-0.05 * (double)((r - c) * (r - c))) + (r == c ? 6.0 : 0.0);
+        double *P1, *P2, *P3, *ldv;
+        int *info, *ticket;
+        CK(hipMalloc(&P1, sizeof(double) * h.size())); CK(hipMalloc(&P2, sizeof(double) * h.size())); CK(hipMalloc(&P3, sizeof(double) * h.size()));
+        CK(hipMalloc(&ldv, 8 * 64)); CK(hipMalloc(&info, 16)); CK(hipMalloc(&ticket, 256));
+        CK(hipMemset(ticket, 0, 256)); CK(hipMemset(info, 0, 16));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float t1 = 1e9f, t2 = 1e9f, t3 = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            float ms;
+            CK(hipMemcpy(P1, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(P2, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(P3, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+            CK(hipMemset(ldv, 0, 8 * 64));
+            CK(hipEventRecord(e0, 0));
+            launch_v1(P1, ld, M + 64, info, ldv + 0, ticket, 0);
+            launch_v1(P1 + 64 * ld + 64, ld, M, info, ldv + 0, ticket, 1);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); t1 = std::min(t1, ms);
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((panel64v2_kernel<64, 8>), dim3((unsigned)std::max(1L, (M + 63) / 64)), dim3(256), 0, 0, P2, ld, (int)M, info + 1, 0, 128, ldv + 1, ticket + 8, 0);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); t2 = std::min(t2, ms);
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((panel64v2_kernel<128, 8>), dim3((unsigned)std::max(1L, (M + 127) / 128)), dim3(256), 0, 0, P3, ld, (int)M, info + 2, 0, 128, ldv + 2, ticket + 16, 0);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1)); t3 = std::min(t3, ms);
+            CK(hipGetLastError());
+        }
+        std::vector<double> a(h.size()), b(h.size()), c3(h.size());
+        double lds[3]; int infos[3];
+        CK(hipMemcpy(a.data(), P1, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), P2, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(c3.data(), P3, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(lds, ldv, sizeof(lds), hipMemcpyDeviceToHost)); CK(hipMemcpy(infos, info, sizeof(infos), hipMemcpyDeviceToHost));
+        // the two-leaf reference counts n_valid = 64 per launch at col0 = 0: its second launch adds the first 64 columns of ITS tile — both 64-column halves are counted
+        double eL = 0, eX = 0, eL3 = 0, eX3 = 0;
+        for (long r = 0; r < M + 128; ++r)
+            for (long c = 0; c < 128; ++c) {
+                const double d2 = fabs(a[r * ld + c] - b[r * ld + c]), d3 = fabs(a[r * ld + c] - c3[r * ld + c]);
+                if (r < 128) { if (c <= r) { eL = fmax(eL, d2); eL3 = fmax(eL3, d3); } }
+                else { eX = fmax(eX, d2); eX3 = fmax(eX3, d3); }
+            }
+        const bool ok = eL < 1e-12 && eX < 1e-12 && eL3 < 1e-12 && eX3 < 1e-12 && fabs(lds[0] - lds[1]) < 1e-10 && fabs(lds[0] - lds[2]) < 1e-10 && infos[0] == infos[1] &&
+                        infos[0] == infos[2] && eL == eL && eX == eX;
+        if (!ok) worst_fail = 1;
+        printf("128 columns, M=%6ld: two v1 leaves %7.1f us  v2<64,8> %7.1f us  v2<128,8> %7.1f us | dL %.1e %.1e  dX %.1e %.1e  logdet %.12g %.12g %.12g info %d %d %d  %s\n",
+               M, t1 * 1e3, t2 * 1e3, t3 * 1e3, eL, eL3, eX, eX3, lds[0], lds[1], lds[2], infos[0], infos[1], infos[2], ok ? "OK" : "MISMATCH");
+        fflush(stdout);
+        (void)hipFree(P1); (void)hipFree(P2); (void)hipFree(P3); (void)hipFree(ldv); (void)hipFree(info); (void)hipFree(ticket);
+    }
     printf(worst_fail ? "LEAF CHECK FAILED\n" : "LEAF CHECK PASSED\n");
     return worst_fail;
 }

@@ -27,11 +27,12 @@ for name, n, d, seed, kern in cases:
     x, y = synth(n, d, seed)
     fx = agp.GP(kern, ctx=ctx)(agp.RowVecs(x), 0.01)
     ref = None
-    for tag, params in (("v1", {"leaf_v2": 0}), ("v2", {"leaf_v2": 1, "leaf_xr": 0}), ("v2_xr64", {"leaf_v2": 1, "leaf_xr": 64}),
-                        ("v2_xr128", {"leaf_v2": 1, "leaf_xr": 128}), ("v2_g64", {"leaf_v2": 1, "leaf_xr": 0, "leaf_group": 64}),
-                        ("v2_g256", {"leaf_v2": 1, "leaf_xr": 0, "leaf_group": 256}), ("v2_nb1024", {"leaf_v2": 1, "leaf_xr": 0, "nb": 1024})):
+    for tag, params in (("v1", {"leaf_v2": 0}), ("v2_c64", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 64}), ("v2_c128", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 128}),
+                        ("v2_c128_xr64", {"leaf_v2": 1, "leaf_xr": 64, "leaf_cols": 128}), ("v2_c128_xr128", {"leaf_v2": 1, "leaf_xr": 128, "leaf_cols": 128}),
+                        ("v2_c128_nb1024", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 128, "nb": 1024}), ("v2_c128_la0", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 128, "lookahead": 0})):
         ctx.set_param("leaf_group", 128)
         ctx.set_param("nb", 2048)
+        ctx.set_param("lookahead", 1)
         for k, v in params.items():
             ctx.set_param(k, v)
         ts = []
@@ -51,3 +52,5 @@ ctx.set_param("leaf_group", 128)
 ctx.set_param("nb", 2048)
 ctx.set_param("leaf_v2", 1)
 ctx.set_param("leaf_xr", 0)
+ctx.set_param("leaf_cols", 128)
+ctx.set_param("lookahead", 1)
