@@ -75,6 +75,7 @@ struct gp_ctx {
     std::mutex mu;
     long nb = 2048;        // outer panel width
     int lookahead = 1;
+    long lookahead_min_n = 24576;  // the look-ahead pays from here on (N <= 16 384: 0.5-3 % slower with it since the register-resident leaf; measured round 4)
     int time_kernels = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)

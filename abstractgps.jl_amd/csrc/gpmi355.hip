@@ -459,7 +459,7 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
     long nb = want_split ? c->cu_split_nb : c->nb;
     if (nb >= np) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
     nb = round_up(nb, 128);
-    bool la = c->lookahead != 0;
+    bool la = c->lookahead != 0 && np >= c->lookahead_min_n;
     bool split = false;
     hipStream_t sM = c->sm, sP = la ? c->sp : c->sm;
     hipEvent_t ev_u1 = nullptr, ev_panel = nullptr;
@@ -1485,6 +1485,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     if (c->multi && multi_set_param(c, name, v) == 0) return 0;  // (generic names are forwarded to the rank contexts too)
     if (!strcmp(name, "nb")) c->nb = (v <= 0) ? 0 : round_up(v, 128);
     else if (!strcmp(name, "lookahead")) c->lookahead = v != 0;
+    else if (!strcmp(name, "lookahead_min_n")) c->lookahead_min_n = std::max<int64_t>(0, v);
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;

@@ -53,15 +53,21 @@ namespace gpmi {
 template <int XR, int W, int NC>
 __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0, int n_valid,
                                           double* __restrict__ logdet_acc, int* __restrict__ ticket, int kpre, double* __restrict__ Lp,
-                                          double* __restrict__ Inv, double* __restrict__ dAx, int* __restrict__ writer_s,
-                                          int* __restrict__ pub) {
+                                          double* __restrict__ Inv, double* __restrict__ dAx, double* __restrict__ yx,
+                                          int* __restrict__ writer_s, int* __restrict__ pub) {
     using TR = Tr<double>;
     constexpr int NCOL = 16 * NC;                // columns of the leaf
     constexpr int LDP = NCOL + 2, LIP = 18;      // row pitches (doubles): 16-byte aligned rows for the 4-double operand reads
     constexpr int NXT = XR / 16;                 // row tiles of X per workgroup
-    constexpr int NTW = (NXT + 2) / 3;           // X row tiles per owner wave (waves 1..3)
-    constexpr int T0 = W == 0 ? 0 : (W - 1) * NTW;
-    constexpr int NT = W == 0 ? 0 : ((NXT - T0) < 0 ? 0 : ((NXT - T0) < NTW ? (NXT - T0) : NTW));
+    // X row tiles per owner wave.  64-column leaf: ⌈NXT/3⌉ each from wave 1 on.  128-column leaf: the rows of the diagonal tile cost the
+    // owners 204 / 100 / 144 MFMAs (row tiles {1,4,7} / {2,5} / {3,6}) and an X row tile 144, so X is dealt 1-2-1 (XR = 64) or 2-3-3
+    // (XR = 128) to even the waves out (with 2-2-0 wave 1 had 492 MFMAs against 144 of wave 3 and the pivot chain waited for it).
+    constexpr int N1 = NC == 8 ? (NXT == 4 ? 1 : 2) : ((NXT + 2) / 3);
+    constexpr int N2 = NC == 8 ? (NXT == 4 ? 2 : 3) : ((NXT - N1) < N1 ? (NXT - N1) : N1);
+    constexpr int N3 = NXT - N1 - N2;
+    static_assert(N3 >= 0, "X row tiles");
+    constexpr int T0 = W <= 1 ? 0 : (W == 2 ? N1 : N1 + N2);
+    constexpr int NT = W == 0 ? 0 : (W == 1 ? N1 : (W == 2 ? N2 : N3));
     constexpr int NTA = NT > 0 ? NT : 1;         // array extent
     constexpr int ND = W == 0 ? 0 : (NC - W + 2) / 3;  // row tiles of the diagonal tile owned by this wave: t = W + 3 s
     constexpr int NDA = ND > 0 ? ND : 1;
@@ -136,10 +142,14 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
     // ticket of step 0 needs only them, so the X rows (2·NT·NC requests per lane, the larger half of the prologue's HBM burst) stay in
     // flight behind the first block's factorisation
     asm volatile("" ::: "memory");
+    // X is consumed left-looking (column tile c first at step c), so only the first XPRE column tiles are requested here and tile c + XPRE
+    // at the top of step c: a wave can have 63 requests in flight — with all 2·NT·NC + 36 of a 128-column leaf in the prologue the issue
+    // itself stalled on the first returns and the owners reached the first barrier after 7 400 cycles
+    constexpr int XPRE = (NC == 4) ? 4 : 2;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) x[t][c] = ld_x(t, 16 * c);
+        for (int c = 0; c < NC; ++c) x[t][c] = c < XPRE ? ld_x(t, 16 * c) : zero4();
 
     // ---- left-looking pre-update by the kpre 64-column tiles to the left (same rows; 64-column leaves only): [D; X] −= [L_k; X_k] · L_kᵀ
     if constexpr (NC == 4) {
@@ -263,6 +273,10 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
             }
         }
         if constexpr (W != 0 && NT > 0) {
+            if (j + XPRE < NC) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) x[t][j + XPRE] = ld_x(t, 16 * (j + XPRE));
+            }
             // X is updated LEFT-looking: column tile j receives every update of the steps before it now, in the shadow of wave 0's
             // factorisation of block (j, j) — x_j −= Σ_{c<j} x_c L(j, c)ᵀ (4j MFMAs per row tile; every L(j, c) was published before the
             // owners' rendezvous of step j−1) — so that after B1 only the solve with Inv_j is left.  Together with the right-looking
@@ -280,15 +294,30 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
                 }
             }
         }
-        // the ticket below says "this workgroup has READ the input tile": a workgroup barrier does not drain vmcnt, so do it by hand
-        if (j == 0 && W != 0) {
-            if (NC == 4 && kpre > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (after a pre-update everything has been consumed anyway)
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT * NC < 63 ? 2 * NT * NC : 0) : "memory");
+        if constexpr (W != 0) {
+            // the owner of row tile j+1 leaves the RAW block (j+1, j) and block (j+1, j+1) — complete since the updates of step j−1 — in LDS
+            // before B1: wave 0 solves that one block itself right behind its factorisation (it is the only thing between two blocks of
+            // the pivot chain), so the chain never waits at a second barrier for another wave's MFMAs
+            if (j + 1 < NC && (j + 1 - W) >= 0 && (j + 1 - W) % 3 == 0) {
+                const int s = (j + 1 - W) / 3;
+                st4(&yx[lane * 4], y[s][j]);
+                st4(&dAx[lane * 4], dAt[s]);
+            }
         }
+        // the ticket below says "this workgroup has READ the input tile": a workgroup barrier does not drain vmcnt, so do it by hand
+        // Step 0 needs, of everything requested in the prologue, only what the owner of row tile 1 hands to wave 0: its block (1, 1) and
+        // block (1, 0) — the first six requests of wave 1 (requests return in order).  Everything else stays in flight behind B1(0); the
+        // ticket ("this workgroup has READ the input tile": a barrier does not drain vmcnt) is taken one step later, when it has landed.
+        if (j == 0 && W == 1) {
+            constexpr int DLOADS = 4 * ND + 2 * (ND * W + 3 * ND * (ND - 1) / 2);  // 4 per diagonal block + 2 per block (t, c), t = W + 3 s
+            constexpr int TOT = DLOADS + 2 * NT * ((NC == 4) ? 4 : 2) + (NC == 4 ? 0 : 2 * NT);  // prologue + the tile requested at the top of step 0
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TOT - 6 > 63 ? 63 : (TOT - 6 < 0 ? 0 : TOT - 6)) : "memory");
+        }
+        if (j == 1 && W != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NC == 4 ? 0 : 2 * NT) : "memory");  // all but the X tile requested at the top of this step
         if (j < 4) PSTAMP2();
         __syncthreads();  // B1: Inv_j and L(j, j) are published
         if (j < 4) PSTAMP2();
-        if (j == 0 && W == 3 && lane == 0) tk_old = atomicAdd(ticket, 1);  // every load of the input tile has landed; the reply is awaited at the end
+        if (j == 1 && W == 3 && lane == 0) tk_old = atomicAdd(ticket, 1);  // every load of the input tile has landed; the reply is awaited at the end
         d4_t ai = zero4();
         if constexpr (W != 0) ai = aop(&Inv[j * 16 * LIP], LIP);
         // one block (t, j) of an owned row tile: solve, publish, update the tile's diagonal block
@@ -303,25 +332,21 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
 #pragma unroll
             for (int q = 0; q < 4; ++q) dAt[s] = TR::mfma(nr[q], r[q], dAt[s]);
         };
-        if constexpr (W != 0) {
-            if (j + 1 < NC && (j + 1 - W) >= 0 && (j + 1 - W) % 3 == 0) {  // this wave owns row tile j+1: it is on the pivot chain
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int s = (j + 1 - W) / 3;
-                solve_block(s);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dAx[lane * 4 + q] = dAt[s][q];
-            }
-        }
-        if (j < 4) PSTAMP2();
-        __syncthreads();  // B2: block (j+1, j+1) is handed over
-        if (j < 1) PSTAMP2();
         if constexpr (W == 0) {
-            if (j + 1 < NC) {
+            if (j + 1 < NC) {  // block (j+1, j): solve, publish, and the diagonal block (j+1, j+1) of the next factorisation
+                const d4_t a0 = aop(&Inv[j * 16 * LIP], LIP);
+                const d4_t yr = ld4(&yx[lane * 4]);
+                dA = ld4(&dAx[lane * 4]);
+                d4_t r = zero4();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dA[r] = dAx[lane * 4 + r];
+                for (int q = 0; q < 4; ++q) r = TR::mfma(a0[q], yr[q], r);
+                st4(&Lp[(16 * (j + 1) + li) * LDP + 16 * j + 4 * lg], r);
+                const d4_t nr = neg4(r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dA = TR::mfma(nr[q], r[q], dA);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the store above has long landed: no wait on the chain)
+                if (lane == 0) __hip_atomic_fetch_add(pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (j < 1) PSTAMP2();
         } else {
             // the other owned row tiles below j+1: solve and publish their blocks (t, j), then tell the other owners
 #pragma unroll
@@ -348,8 +373,8 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
                 }
             }
             if (j + 1 < NC) {
-                // every L(c, j), c > j, must be published: three owners, one increment each per step
-                while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3 * (j + 1)) __builtin_amdgcn_s_sleep(1);
+                // every L(c, j), c > j, must be published: three owners and wave 0 (block (j+1, j)), one increment each per step
+                while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (j + 1)) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
                 for (int c = j + 1; c < NC; ++c) {
@@ -409,13 +434,14 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
     __shared__ __attribute__((aligned(16))) double Lp[16 * NC * (16 * NC + 2)];  // published blocks of L (natural rows); pre-update: the left tile
     __shared__ __attribute__((aligned(16))) double Inv[NC * 16 * 18];
     __shared__ __attribute__((aligned(16))) double dAx[64 * 4];                  // hand-over of the next diagonal block (symmetric layout)
+    __shared__ __attribute__((aligned(16))) double yx[64 * 4];                   // ... and of the raw block (j+1, j) (natural layout)
     __shared__ int writer_s, pub;
     const int w = threadIdx.x >> 6;  // wave-uniform: each wave runs the instance of its role
     if (threadIdx.x == 0) pub = 0;   // (the first barrier inside orders this before any increment)
-    if (w == 0) leaf_wave<XR, 0, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
-    else if (w == 1) leaf_wave<XR, 1, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
-    else if (w == 2) leaf_wave<XR, 2, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
-    else leaf_wave<XR, 3, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, &writer_s, &pub);
+    if (w == 0) leaf_wave<XR, 0, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    else if (w == 1) leaf_wave<XR, 1, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    else if (w == 2) leaf_wave<XR, 2, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    else leaf_wave<XR, 3, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
 }
 
 }  // namespace gpmi

@@ -140,6 +140,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  * names at gp_ctx_create):
  *   "nb"             outer panel width (multiple of 128; 0 = purely recursive)            default 2048
  *   "lookahead"      next panel on a second, high-priority stream (0/1)                   default 1
+ *   "lookahead_min_n" ... for matrices of at least this (padded) order                    default 24576
  *   "time_kernels"   bracket every MFMA GEMM launch with HIP events (gp_get_timings)      default 0
  *   "xcd_swizzle", "xcd_min_tiles"  XCD-aware super-tile workgroup order for large GEMM grids   default 0, 256
  *   "gemm_streamk"   persistent-grid GEMM with a stream-K tail on launches of <= sk_max_tiles tiles   default 1
