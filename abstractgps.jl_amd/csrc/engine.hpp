@@ -88,6 +88,7 @@ struct gp_ctx {
                            // most sk_max_tiles tiles: the few-tile in-panel GEMMs are cut along k over all CUs (−2…5 % at N <= 32 768)
     int num_cus = 256;
     long sk_max_tiles = 4096;  // stream-K only for launches of at most this many tiles (8 rounds): the persistent kernel is
+    long sk_min_k = 0;     // launches with a shorter k range take the plain tile kernel (experiment knob)
                            // ~5 % slower than hardware dispatch on large launches, where the tail does not matter anyway
     int sk_u1 = 0;         // stream-K for the U1 update of the look-ahead schedule (measured: no effect)
     int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there

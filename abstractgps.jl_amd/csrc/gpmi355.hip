@@ -236,7 +236,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         grid = dim3((unsigned)total, 1);
     }
     if (g.nbatch > 1) grid.z = (unsigned)g.nbatch;
-    if (!c->deterministic && (c->gemm_streamk || c->sk_scope > 0) && !g.beta0 && !g.ktri && g.nbatch <= 1 && g.P == 1 && g.Q == 1 && g.compact <= 1 &&
+    if (!c->deterministic && K >= c->sk_min_k && (c->gemm_streamk || c->sk_scope > 0) && !g.beta0 && !g.ktri && g.nbatch <= 1 && g.P == 1 && g.Q == 1 && g.compact <= 1 &&
         (g.compact == 1 ? (long)grid.x : tm * tn) <= c->sk_max_tiles) {
         // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
         const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
@@ -459,7 +459,7 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
     long nb = want_split ? c->cu_split_nb : c->nb;
     if (nb >= np) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
     nb = round_up(nb, 128);
-    bool la = c->lookahead != 0 && np >= c->lookahead_min_n;
+    bool la = c->lookahead != 0 && (np >= c->lookahead_min_n || want_split);  // (the CU-partitioned schedule IS a look-ahead: its two streams need the events)
     bool split = false;
     hipStream_t sM = c->sm, sP = la ? c->sp : c->sm;
     hipEvent_t ev_u1 = nullptr, ev_panel = nullptr;
@@ -1491,6 +1491,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
     else if (!strcmp(name, "sk_u1")) c->sk_u1 = v != 0;
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
+    else if (!strcmp(name, "sk_min_k")) c->sk_min_k = v;
     else if (!strcmp(name, "gemm_pad_lds")) {
         c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
         c->gemm_pad_user = true;

@@ -46,7 +46,7 @@ def local_lower_blocks(nblk, P, Q, p, q, r0, c0):
     return full, diag
 
 
-def model(N, P, Q, NB, depth=2):
+def model(N, P, Q, NB, depth=2, forward=False):
     nblk = math.ceil(N / NB)
     lcm = P * Q // math.gcd(P, Q)
     nblk = math.ceil(nblk / lcm) * lcm
@@ -77,9 +77,23 @@ def model(N, P, Q, NB, depth=2):
             msgs = 0
             rows_p = sum(1 for i in range(k + 1, nblk) if i % P == p) * NB
             cols_q = [j for j in range(k + 1, nblk) if j % Q == q]
+            a_fwd = 0.0
             if q != qk and rows_p:
-                per_link[(p, qk)] = per_link.get((p, qk), 0.0) + rows_p * NB * 8.0
-                msgs += 1
+                if forward and Q > 2:
+                    # A-operand forwarding ("up to Q−1 links at once"; NOT implemented in csrc/multi.hip): the owner column
+                    # sends a disjoint 1/(Q−1) slice of the row piece to each of the Q−1 peers of its process row, which then pass their
+                    # slice on to the other Q−2 peers — two dependent phases, each moving rows_p·NB·8/(Q−1) bytes per link
+                    sl = rows_p * NB * 8.0 / (Q - 1)
+                    per_link[(p, qk)] = per_link.get((p, qk), 0.0) + sl
+                    a_fwd = sl / LINK + MSG_LAT          # the second phase, behind the first
+                    for q2 in range(Q):
+                        if q2 != qk and q2 != q:
+                            link[((p, q2), (p, q))] = link.get(((p, q2), (p, q)), 0.0) + sl
+                            recv[(p, q)] += sl
+                    msgs += Q - 1
+                else:
+                    per_link[(p, qk)] = per_link.get((p, qk), 0.0) + rows_p * NB * 8.0
+                    msgs += 1
             for j in cols_q:
                 src = (j % P, qk)
                 if src == (p, q):
@@ -89,7 +103,7 @@ def model(N, P, Q, NB, depth=2):
             for src, b in per_link.items():
                 recv[(p, q)] += b
                 link[(src, (p, q))] = link.get((src, (p, q)), 0.0) + b
-            t = (max(per_link.values()) / LINK if per_link else 0.0) + (MSG_LAT if msgs else 0.0) + 1e-6 * msgs
+            t = (max(per_link.values()) / LINK if per_link else 0.0) + (MSG_LAT if msgs else 0.0) + 1e-6 * msgs + a_fwd
             worst = max(worst, t)
         return worst
 
@@ -134,19 +148,22 @@ def grids(R):
     return [(P, R // P) for P in range(1, R + 1) if R % P == 0]
 
 
-def best(N, R, nbs=(512, 1024, 2048)):
-    rows = [model(N, P, Q, nb) for (P, Q) in grids(R) for nb in nbs]
+def best(N, R, nbs=(512, 1024, 2048), forward=False):
+    rows = [model(N, P, Q, nb, forward=forward) for (P, Q) in grids(R) for nb in nbs]
     return min(rows, key=lambda r: r["t_ms"]), rows
 
 
 if __name__ == "__main__":
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
+    FWD = "forward" in sys.argv
+    if FWD:
+        print("A-operand forwarding PRICED (two-phase slice exchange inside a process row; not implemented in the driver)")
     one = model(N, 1, 1, 2048)
     print(f"calibration: 1x1, NB = 2048 -> {one['t_ms']:.0f} ms (measured through the in-library driver with one rank: 1451 ms, profiles/r2/multi_virtual_bench.txt)")
     print(f"N = {N}; single-GPU costs from tools/perf_model.py, link {LINK / 1e9:.0f} GB/s per direction — UNMEASURED ON HARDWARE")
     print(f"{'devices':>7} {'grid':>5} {'NB':>5} {'t ms':>8} {'bulk':>8} {'chain':>8} {'chain-bound':>11} {'imbalance':>9} {'recv GB':>8} {'link GB':>8} {'% peak':>7}")
     for R in (1, 2, 4, 8):
-        b, rows = best(N, R)
+        b, rows = best(N, R, forward=FWD)
         for r in sorted(rows, key=lambda r: r["t_ms"]):
             mark = " <- argmin" if r is b else ""
             print(f"{R:>7} {r['grid']:>5} {r['NB']:>5} {r['t_ms']:>8.1f} {r['bulk_ms']:>8.1f} {r['chain_ms']:>8.1f} {r['chain_bound_steps']:>5}/{r['nblk']:<5} "
