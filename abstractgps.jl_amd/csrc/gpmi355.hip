@@ -349,8 +349,16 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
     }
     const long h = split_half(n);
     RC(potrf_rec<T>(c, s, A, lda, j0, h, mtot, info_dev, gcol0, n_valid, logdet_dev));
-    RC(launch_gemm<T>(c, s, A + (j0 + h) * lda + (j0 + h), lda, A + (j0 + h) * lda + j0, lda,
-                      A + (j0 + h) * lda + j0, lda, mtot - j0 - h, n - h, h, plain_map(1, j0 + h, j0 + h)));
+    bool skinny = false;
+    if constexpr (std::is_same<T, double>::value) {
+        if (h == 128 && n - h == 128 && c->leaf_v2 && c->upd128) {  // the skinny update between two 128-column leaves (leaf.hip)
+            HIPCHK((hipError_t)launch_panel_upd128(s, (double*)(A + (j0 + h) * lda + (j0 + h)), lda, (const double*)(A + (j0 + h) * lda + j0), lda, mtot - j0 - h));
+            skinny = true;
+        }
+    }
+    if (!skinny)
+        RC(launch_gemm<T>(c, s, A + (j0 + h) * lda + (j0 + h), lda, A + (j0 + h) * lda + j0, lda,
+                          A + (j0 + h) * lda + j0, lda, mtot - j0 - h, n - h, h, plain_map(1, j0 + h, j0 + h)));
     RC(potrf_rec<T>(c, s, A, lda, j0 + h, n - h, mtot, info_dev, gcol0, n_valid, logdet_dev));
     return 0;
 }
@@ -1501,6 +1509,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
     else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
     else if (!strcmp(name, "leaf_cols")) c->leaf_cols = v == 64 ? 64 : 128;
+    else if (!strcmp(name, "upd128")) c->upd128 = v != 0;
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);

@@ -27,4 +27,10 @@ int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* in
     return (int32_t)hipGetLastError();  // hipError_t of the launch (0 = hipSuccess)
 }
 
+// C[m×128] −= P[m×128] · P[0:128, :]ᵀ on stream s (leaf.hpp panel_upd128_kernel); m >= 128
+int32_t launch_panel_upd128(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m) {
+    hipLaunchKernelGGL(panel_upd128_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, C, ldc, P, ldp, (int)m);
+    return (int32_t)hipGetLastError();
+}
+
 }  // namespace gpmi

@@ -444,4 +444,77 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
     else leaf_wave<XR, 3, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
 }
 
+// ------------------------------------------------------------------------------------------------
+// panel_upd128: the in-panel update between two 128-column leaves,  C[m×128] −= P[m×128] · P[0:128, :]ᵀ  (the next 128 columns of every
+//   row below get the product with the first 128 rows of the panel just factored — those rows ARE the diagonal block of the next leaf).
+//   As a 128×128-tile GEMM with K = 128 this launch took 27 µs for 4 µs of flops at N = 16 384 (a tile reads 256 KB through one CU, and
+//   the stream-K cut of its 8 k-steps pays 16 384 fp64 atomics per share); here a workgroup keeps the 128×128 operand in LDS (natural
+//   rows, like a leaf's published blocks) and each wave runs ONE 16-row tile through the leaf's register chain: 8 column-tile accumulators,
+//   for each 16-column slice of its own rows of P one 32-byte piece per lane and 8 × 4 MFMAs against the operand blocks.  64 rows per
+//   workgroup: 256 workgroups at 16 384 rows.  The whole 128×128 top block is updated (its upper triangle is scratch: leaves read and
+//   write the lower one only).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void panel_upd128_kernel(double* __restrict__ C, long ldc, const double* __restrict__ P, long ldp, int m) {
+    using TR = Tr<double>;
+    constexpr int LDB = 130;
+    __shared__ __attribute__((aligned(16))) double Bp[128 * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int pirow = 4 * (li & 3) + (li >> 2);
+    auto ld4 = [&](const double* p16) -> d4_t {
+        const d2_t* src = reinterpret_cast<const d2_t*>(p16);
+        const d2_t lo = src[0], hi = src[1];
+        d4_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+        return v;
+    };
+    auto st4 = [&](double* p16, const d4_t& v) {
+        d2_t lo, hi;
+        lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
+        d2_t* dst = reinterpret_cast<d2_t*>(p16);
+        dst[0] = lo;
+        dst[1] = hi;
+    };
+    const long row = (long)blockIdx.x * 64 + 16 * w + li;  // this lane's row of C / P
+    const bool ok = row < m;
+    // this wave's tile of C and its rows of P are requested first, the operand staging behind them
+    d4_t acc[8], a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (ok) {
+            acc[c] = ld4(C + row * ldc + 16 * c + 4 * lg);
+            a[c] = ld4(P + row * ldp + 16 * c + 4 * lg);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[c][q] = 0.0;
+                a[c][q] = 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // P[0:128, 0:128] -> LDS: 4 096 pieces of 32 bytes over 256 threads
+        const int e = tid + 256 * i, r = e >> 5, pc = e & 31;
+        st4(&Bp[r * LDB + 4 * pc], ld4(P + (long)r * ldp + 4 * pc));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        d4_t nb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const d4_t b = ld4(&Bp[(16 * c + pirow) * LDB + 16 * q + 4 * lg]);
+            nb[c][0] = -b[0]; nb[c][1] = -b[1]; nb[c][2] = -b[2]; nb[c][3] = -b[3];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = TR::mfma(nb[c][s], a[q][s], acc[c]);
+    }
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) st4(C + row * ldc + 16 * c + 4 * lg, acc[c]);
+    }
+}
+
 }  // namespace gpmi

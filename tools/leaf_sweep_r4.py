@@ -27,9 +27,11 @@ for name, n, d, seed, kern in cases:
     x, y = synth(n, d, seed)
     fx = agp.GP(kern, ctx=ctx)(agp.RowVecs(x), 0.01)
     ref = None
-    for tag, params in (("v1", {"leaf_v2": 0}), ("v2_c64", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 64}), ("v2_c128", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 128}),
-                        ("v2_c128_xr64", {"leaf_v2": 1, "leaf_xr": 64, "leaf_cols": 128}), ("v2_c128_xr128", {"leaf_v2": 1, "leaf_xr": 128, "leaf_cols": 128}),
-                        ("v2_c128_nb1024", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 128, "nb": 1024}), ("v2_c128_la0", {"leaf_v2": 1, "leaf_xr": 0, "leaf_cols": 128, "lookahead": 0})):
+    for tag, params in (("v1", {"leaf_v2": 0}), ("v2_c64", {"leaf_v2": 1, "leaf_cols": 64}), ("v2_c128_gemm", {"leaf_v2": 1, "leaf_cols": 128, "upd128": 0}),
+                        ("v2_c128", {"leaf_v2": 1, "leaf_cols": 128, "upd128": 1}), ("v2_c128_la1", {"leaf_v2": 1, "leaf_cols": 128, "upd128": 1, "lookahead_min_n": 0}),
+                        ("v2_c128_la0", {"leaf_v2": 1, "leaf_cols": 128, "upd128": 1, "lookahead": 0})):
+        ctx.set_param("lookahead_min_n", 24576)
+        ctx.set_param("upd128", 1)
         ctx.set_param("leaf_group", 128)
         ctx.set_param("nb", 2048)
         ctx.set_param("lookahead", 1)
@@ -54,3 +56,5 @@ ctx.set_param("leaf_v2", 1)
 ctx.set_param("leaf_xr", 0)
 ctx.set_param("leaf_cols", 128)
 ctx.set_param("lookahead", 1)
+ctx.set_param("lookahead_min_n", 24576)
+ctx.set_param("upd128", 1)
