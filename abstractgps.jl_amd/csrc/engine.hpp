@@ -65,12 +65,6 @@ struct gp_ctx {
     int device = 0;
     hipStream_t sm = nullptr;  // main stream (trailing updates, assembly, solves)
     hipStream_t sp = nullptr;  // panel stream (look-ahead)
-    hipStream_t sp_mask = nullptr, sm_mask = nullptr;  // CU-partitioned pair ("cu_split"): panel stream on mask_r CUs, main stream on the rest
-    int mask_r = 0;
-    int cu_split = 0;            // CUs owned by the panel stream during the overlapped part of the factorisation (multiple of 8; 0 = off)
-    long cu_split_nb = 512;      // panel width while the streams are partitioned (in-panel GEMMs <= 5 % of the flops)
-    long cu_split_tail = 8192;   // trailing rows below which the partition is dropped (the chain-bound tail runs on the whole machine)
-    long cu_split_max_n = 40000; // sizes above this keep the unpartitioned schedule (the update dwarfs the panel there)
     bool own_sm = false;
     std::mutex mu;
     long nb = 2048;        // outer panel width

@@ -115,8 +115,6 @@ void ctx_unref(gp_ctx* c) {
     if (c->ticket_dev) (void)hipFree(c->ticket_dev);
     if (c->w_ws) (void)hipFree(c->w_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
-    if (c->sp_mask) (void)hipStreamDestroy(c->sp_mask);
-    if (c->sm_mask) (void)hipStreamDestroy(c->sm_mask);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
     delete c;
@@ -207,7 +205,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
                                 : (g.ktri == 2 ? (double)M * (double)M * (double)M / 3.0 : 2.0 * (double)K * elems);
         rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
         rec.M = M; rec.N = N; rec.K = K;
-        rec.stream = (s == c->sp || (s == c->sp_mask && s));
+        rec.stream = (s == c->sp);
         HIPCHK(hipEventRecord(rec.a, s));
     }
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
@@ -241,7 +239,7 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         // persistent grid + stream-K tail (kernels.hpp gemm_nt_sk_kernel)
         const long nk = K / (128 / (long)sizeof(T));  // BK = 16 (f64) / 32 (f32)
         const long ntiles = g.compact == 1 ? (long)grid.x : tm * tn;
-        const long Gmax = 2L * (s == c->sm_mask && s ? c->num_cus - c->mask_r : (s == c->sp_mask && s ? c->mask_r : c->num_cus));
+        const long Gmax = 2L * c->num_cus;
         const long G = Gmax;  // fewer tiles than workgroups: every tile is cut along k
         const long R = ntiles - (ntiles / G) * G;
         // tail shares: never fewer workgroups than tail tiles; beyond that at least 16 k-steps per share
@@ -309,7 +307,7 @@ static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, lo
         HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
         HIPCHK(hipDeviceSynchronize());
     }
-    int* const tk = c->ticket_dev + ((s == c->sp || (s == c->sp_mask && s)) ? 32 : 0);
+    int* const tk = c->ticket_dev + (s == c->sp ? 32 : 0);
     if constexpr (std::is_same<T, double>::value) {
         if (c->leaf_v2) {  // register-resident leaf (leaf.hip: panel64v2_kernel)
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mrows, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, kpre,
@@ -336,7 +334,7 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
                 HIPCHK(hipMemset(c->ticket_dev, 0, sizeof(int) * 64));
                 HIPCHK(hipDeviceSynchronize());
             }
-            int* const tk = c->ticket_dev + ((s == c->sp || (s == c->sp_mask && s)) ? 32 : 0);
+            int* const tk = c->ticket_dev + (s == c->sp ? 32 : 0);
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mtot - j0 - 128, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, 0,
                                               c->leaf_xr, c->num_cus, 128));
             return 0;
@@ -432,73 +430,26 @@ static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* in
     return potrf_full_la<T>(c, A, lda, np, mtot, info_dev, n_valid, logdet_dev);
 }
 
-// CU-partitioned streams ("cu_split" = r > 0): the panel stream owns r CUs — mask bit i of hipExtStreamCreateWithCUMask is CU
-// i / 8 (SE (i/8) % 4, CU (i/8) / 4 of that SE) of XCC i % 8 (tools/cumask_probe.hip, profiles/r2/traces/cumask_probe.txt), so
-// bits [0, r) are r/8 CUs of every XCD spread over its shader engines — and the main stream the other 256 − r.  Kernels of the
-// two streams then never share a CU: the 64-column leaf chain (fp64 VALU, 111 KB of LDS per workgroup) runs at its own speed
-// beside the MFMA trailing update instead of waiting for both GEMM workgroups of a CU to retire.
-static int32_t ensure_cu_streams(gp_ctx* c) {
-    const int r = c->cu_split;
-    if (c->mask_r == r && c->sp_mask && c->sm_mask) return 0;
-    if (c->sp_mask) (void)hipStreamDestroy(c->sp_mask);
-    if (c->sm_mask) (void)hipStreamDestroy(c->sm_mask);
-    c->sp_mask = c->sm_mask = nullptr;
-    c->mask_r = 0;
-    const int nbits = c->num_cus;  // 256 on MI355X
-    const int words = (nbits + 31) / 32;
-    std::vector<uint32_t> mp((size_t)words, 0u), mm((size_t)words, 0u);
-    for (int i = 0; i < nbits; ++i) (i < r ? mp : mm)[(size_t)i / 32] |= 1u << (i % 32);
-    HIPCHK(hipExtStreamCreateWithCUMask(&c->sp_mask, (uint32_t)words, mp.data()));
-    HIPCHK(hipExtStreamCreateWithCUMask(&c->sm_mask, (uint32_t)words, mm.data()));
-    c->mask_r = r;
-    return 0;
-}
-
 // sched 0: right-looking over panels of width nb with a one-panel look-ahead: the whole next panel (recursive
 // Cholesky of its columns including every row below) is factored on the panel stream while the rest of the
-// trailing update still runs on the main stream.  With "cu_split" the two streams own disjoint CU sets while the trailing
-// matrix is larger than "cu_split_tail" rows (there the update is longer than the next panel's leaf chain and hides it); the
-// chain-bound tail of the factorisation runs panel by panel on the whole machine.
+// trailing update still runs on the main stream.  (A variant with the two streams on disjoint CU sets was built in round 3
+// and measured slower at every size in rounds 3 and 4 — profiles/r3/sweep_cusplit.jsonl, profiles/r4/nb_sweep.jsonl; it lives
+// in the history at f1ed70e.)
 template <typename T>
 static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
                              double* logdet_dev) {
-    const bool want_split = c->cu_split > 0 && c->lookahead != 0 && np <= c->cu_split_max_n && np > c->cu_split_tail &&
-                            c->cu_split % 8 == 0 && c->cu_split < c->num_cus;
-    long nb = want_split ? c->cu_split_nb : c->nb;
+    long nb = c->nb;
     if (nb >= np) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
     nb = round_up(nb, 128);
-    bool la = c->lookahead != 0 && (np >= c->lookahead_min_n || want_split);  // (the CU-partitioned schedule IS a look-ahead: its two streams need the events)
-    bool split = false;
+    const bool la = c->lookahead != 0 && np >= c->lookahead_min_n;
     hipStream_t sM = c->sm, sP = la ? c->sp : c->sm;
     hipEvent_t ev_u1 = nullptr, ev_panel = nullptr;
-    if (want_split) {
-        RC(ensure_cu_streams(c));
-        sM = c->sm_mask;
-        sP = c->sp_mask;
-        split = true;
-    }
     if (la) {  // the panel stream starts after everything queued so far on the main stream (assembly)
         RC(ctx_event(c, &ev_u1, false));
         HIPCHK(hipEventRecord(ev_u1, c->sm));
         HIPCHK(hipStreamWaitEvent(sP, ev_u1, 0));
-        if (split) HIPCHK(hipStreamWaitEvent(sM, ev_u1, 0));
     }
-    // back to the ctx streams (whole machine): everything queued on the two partitions precedes what follows on c->sm
-    auto join_split = [&]() -> int32_t {
-        hipEvent_t e1 = nullptr, e2 = nullptr;
-        RC(ctx_event(c, &e1, false));
-        RC(ctx_event(c, &e2, false));
-        HIPCHK(hipEventRecord(e1, sM));
-        HIPCHK(hipEventRecord(e2, sP));
-        HIPCHK(hipStreamWaitEvent(c->sm, e1, 0));
-        HIPCHK(hipStreamWaitEvent(c->sm, e2, 0));
-        sM = sP = c->sm;
-        split = false;
-        la = false;
-        return 0;
-    };
     for (long k = 0; k < np; k += nb) {
-        if (split && np - k <= c->cu_split_tail) RC(join_split());
         const long nbk = std::min(nb, np - k);
         RC(potrf_rec<T>(c, sP, A, lda, k, nbk, mtot, info_dev, 0, n_valid, logdet_dev));
         const long k1 = k + nbk;
@@ -529,7 +480,6 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
             RC(launch_gemm<T>(c, sM, A + k2 * lda + k2, lda, A + k2 * lda + k, lda, A + k2 * lda + k, lda,
                               mtot - k2, np - k2, nbk, plain_map(1, k2, k2)));
     }
-    if (split) RC(join_split());
     return 0;
 }
 
@@ -820,8 +770,6 @@ static int32_t fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
     if (rc != 0) {
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
-        if (c->sm_mask) (void)hipStreamSynchronize(c->sm_mask);
-        if (c->sp_mask) (void)hipStreamSynchronize(c->sp_mask);
         return rc;
     }
     if (out.info != 0 || !post) return out.info;
@@ -1474,8 +1422,6 @@ int32_t gp_ctx_destroy(gp_ctx* c) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->sm);
         (void)hipStreamSynchronize(c->sp);
-        if (c->sm_mask) (void)hipStreamSynchronize(c->sm_mask);
-        if (c->sp_mask) (void)hipStreamSynchronize(c->sp_mask);
         c->dead = true;
         multi = c->multi;
         c->multi = nullptr;
@@ -1517,10 +1463,6 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "vfe_sk")) c->vfe_sk = v != 0;
     else if (!strcmp(name, "vfe_overlap")) c->vfe_overlap = v != 0;
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
-    else if (!strcmp(name, "cu_split")) c->cu_split = (int)std::max<int64_t>(0, v / 8 * 8);
-    else if (!strcmp(name, "cu_split_nb")) c->cu_split_nb = std::max<int64_t>(128, round_up(v, 128));
-    else if (!strcmp(name, "cu_split_tail")) c->cu_split_tail = std::max<int64_t>(0, v);
-    else if (!strcmp(name, "cu_split_max_n")) c->cu_split_max_n = std::max<int64_t>(0, v);
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
              !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_dist_predict") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");

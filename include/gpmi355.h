@@ -154,6 +154,9 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    sweep — so two calls with the same inputs on the same ctx return the same BITS (tests/test_gpu_api.py).  The VFE
  *                    path, the gradient kernels and the multi-device backward sweep keep their atomics.  1-5 % slower at N <= 32 768.   default 0
  *   "leaf_v2", "leaf_xr"  fp64 leaves by the register-resident panel64v2_kernel (csrc/leaf.hpp) / rows of X per leaf workgroup (0 auto)   default 1, 0
+ *   "leaf_cols"      columns per register-resident leaf launch (64 or 128; 128 = one workgroup chain per 128 columns)   default 128
+ *   "upd128"         update between two 128-column leaves by panel_upd128_kernel (register chain) instead of the tile GEMM   default 1
+ *   "sk_min_k"       smallest inner dimension that may use the stream-K GEMM                default 0
  *   "leaf_group"     columns factored left-looking by consecutive fused leaves (64/128/256/512)   default 128
  *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one
@@ -162,10 +165,6 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
- *   "cu_split"       CU-partitioned look-ahead: the panel stream owns this many CUs (multiple of 8, spread over all XCDs and
- *                    shader engines through hipExtStreamCreateWithCUMask), the trailing update the rest, while more than
- *                    "cu_split_tail" rows remain; panels are "cu_split_nb" wide then; sizes above "cu_split_max_n" keep the
- *                    unpartitioned schedule                                                default 0 / 8192 / 512 / 40000
  *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Return every cached (free) device block of the ctx to the HIP allocator — e.g. after freeing an N = 65 536 posterior
