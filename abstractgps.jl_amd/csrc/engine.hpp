@@ -77,7 +77,11 @@ struct gp_ctx {
     int deterministic = 0; // 1: no floating-point atomics in the exact path (no stream-K tails, one thread per column in the backward sweep): bitwise repeatable
     int leaf_v2 = 1;       // fp64 leaves by panel64v2_kernel (register-resident leaf, round 4); 0: panel64_kernel
     int leaf_xr = 0;       // rows of X per leaf workgroup: 64 / 128; 0 = 64 while that gives at most two workgroups per CU, else 128
-    int upd128 = 1;        // the K = N = 128 in-panel update between two 128-column leaves by panel_upd128_kernel (leaf.hpp) instead of the tile GEMM
+    int upd128 = 1;        // the K = N = 128 in-panel update between two 128-column leaves by panel_updk_kernel (leaf.hpp) instead of the tile GEMM
+    long updk_max_k = 512;       // in-panel updates with 256 <= K = N <= this run through panel_updk_kernel (0: tile GEMM) ...
+    long updk_tall_k = 256;      // ... K above this only while at most updk_tall_m rows are below (the stream-K tile GEMM wins on tall K = 512 launches)
+    long updk_tall_m = 8192;
+    int updk_rt = 0;             // rows per workgroup / 16 of panel_updk_kernel (0 auto, 4, 2, 1)
     int leaf_cols = 128;   // columns per register-resident leaf launch: 128 (one launch per 128-column group, no in-leaf pre-update) or 64
     int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at
                            // most sk_max_tiles tiles: the few-tile in-panel GEMMs are cut along k over all CUs (−2…5 % at N <= 32 768)
@@ -239,7 +243,7 @@ int32_t eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const do
 // register-resident 64-column leaf (leaf.hip, its own translation unit): tile Cholesky + X L⁻ᵀ of the mrows rows below, fp64
 int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* info_dev, int col0, int n_valid, double* logdet_dev, int* ticket,
                        int kpre, int xr, int num_cus, int ncols);
-int32_t launch_panel_upd128(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m);
+int32_t launch_panel_updk(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m, long N, long K, int rt, int num_cus);
 // 2-D block copy by a kernel (16-B aligned rows, even cols): source may live on a peer device with peer access enabled
 int32_t eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols);
 }  // namespace gpmi

@@ -349,8 +349,12 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
     RC(potrf_rec<T>(c, s, A, lda, j0, h, mtot, info_dev, gcol0, n_valid, logdet_dev));
     bool skinny = false;
     if constexpr (std::is_same<T, double>::value) {
-        if (h == 128 && n - h == 128 && c->leaf_v2 && c->upd128) {  // the skinny update between two 128-column leaves (leaf.hip)
-            HIPCHK((hipError_t)launch_panel_upd128(s, (double*)(A + (j0 + h) * lda + (j0 + h)), lda, (const double*)(A + (j0 + h) * lda + j0), lda, mtot - j0 - h));
+        const long mrows = mtot - j0 - h;
+        const bool k128 = h == 128 && n - h == 128 && c->upd128;
+        const bool kmid = h >= 256 && h <= c->updk_max_k && h % 32 == 0 && (n - h) % 128 == 0 && n - h <= h && (h <= c->updk_tall_k || mrows <= c->updk_tall_m);
+        if (c->leaf_v2 && (k128 || kmid)) {  // the skinny in-panel updates through the register chain (leaf.hip panel_updk_kernel)
+            HIPCHK((hipError_t)launch_panel_updk(s, (double*)(A + (j0 + h) * lda + (j0 + h)), lda, (const double*)(A + (j0 + h) * lda + j0), lda, mrows, n - h, h,
+                                                 c->updk_rt, c->num_cus));
             skinny = true;
         }
     }
@@ -1455,6 +1459,10 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
     else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
     else if (!strcmp(name, "leaf_cols")) c->leaf_cols = v == 64 ? 64 : 128;
+    else if (!strcmp(name, "updk_max_k")) c->updk_max_k = std::max<int64_t>(0, v);
+    else if (!strcmp(name, "updk_rt")) c->updk_rt = (int)v;
+    else if (!strcmp(name, "updk_tall_k")) c->updk_tall_k = std::max<int64_t>(0, v);
+    else if (!strcmp(name, "updk_tall_m")) c->updk_tall_m = std::max<int64_t>(0, v);
     else if (!strcmp(name, "upd128")) c->upd128 = v != 0;
     else if (!strcmp(name, "leaf_group")) c->leaf_group = v < 128 ? 64 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "xcd_min_tiles")) c->xcd_min_tiles = v;

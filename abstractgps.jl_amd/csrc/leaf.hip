@@ -27,9 +27,18 @@ int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* in
     return (int32_t)hipGetLastError();  // hipError_t of the launch (0 = hipSuccess)
 }
 
-// C[m×128] −= P[m×128] · P[0:128, :]ᵀ on stream s (leaf.hpp panel_upd128_kernel); m >= 128
-int32_t launch_panel_upd128(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m) {
-    hipLaunchKernelGGL(panel_upd128_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, C, ldc, P, ldp, (int)m);
+// C[m×N] −= P[m×K] · P[0:N, 0:K]ᵀ on stream s (leaf.hpp panel_updk_kernel); N multiple of 128, K multiple of 32, m >= N.
+// rt = rows per workgroup / 16 (4, 2, 1; 0: the tallest tile that still gives one workgroup per CU)
+int32_t launch_panel_updk(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m, long N, long K, int rt, int num_cus) {
+    const long nby = N / 128;
+    if (rt != 1 && rt != 2 && rt != 4) {
+        const long want = num_cus;
+        rt = ((m + 63) / 64) * nby >= want ? 4 : (((m + 31) / 32) * nby >= want ? 2 : 1);
+    }
+    const dim3 grid((unsigned)((m + 16 * rt - 1) / (16 * rt)), (unsigned)nby);
+    if (rt == 4) hipLaunchKernelGGL(panel_updk_kernel<4>, grid, dim3(256), 0, s, C, ldc, P, ldp, (int)m, (int)K);
+    else if (rt == 2) hipLaunchKernelGGL(panel_updk_kernel<2>, grid, dim3(256), 0, s, C, ldc, P, ldp, (int)m, (int)K);
+    else hipLaunchKernelGGL(panel_updk_kernel<1>, grid, dim3(256), 0, s, C, ldc, P, ldp, (int)m, (int)K);
     return (int32_t)hipGetLastError();
 }
 

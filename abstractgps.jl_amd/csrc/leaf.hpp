@@ -445,20 +445,33 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// panel_upd128: the in-panel update between two 128-column leaves,  C[m×128] −= P[m×128] · P[0:128, :]ᵀ  (the next 128 columns of every
-//   row below get the product with the first 128 rows of the panel just factored — those rows ARE the diagonal block of the next leaf).
-//   As a 128×128-tile GEMM with K = 128 this launch took 27 µs for 4 µs of flops at N = 16 384 (a tile reads 256 KB through one CU, and
-//   the stream-K cut of its 8 k-steps pays 16 384 fp64 atomics per share); here a workgroup keeps the 128×128 operand in LDS (natural
-//   rows, like a leaf's published blocks) and each wave runs ONE 16-row tile through the leaf's register chain: 8 column-tile accumulators,
-//   for each 16-column slice of its own rows of P one 32-byte piece per lane and 8 × 4 MFMAs against the operand blocks.  64 rows per
-//   workgroup: 256 workgroups at 16 384 rows.  The whole 128×128 top block is updated (its upper triangle is scratch: leaves read and
-//   write the lower one only).
+// panel_updk: the in-panel updates of the recursion inside a panel,  C[m×N] −= P[m×K] · P[0:N, 0:K]ᵀ  with K = N = 128 / 256 / 512 (N a
+//   multiple of 128, K of 32): the next N columns of every row below get the product with the first N rows of the block column just
+//   factored — those rows hold the diagonal block of what is factored next.  The 128×128-tile GEMM runs these at 15 / 23 / 40 TF/s
+//   (profiles/r4/gemm_dump.txt: at most N/128 · m/128 tiles for 512 workgroup slots, so every tile is cut along k and pays a
+//   zero-accumulator prologue and 16 384 fp64 atomics per share; 27 µs per K = 128 launch at N = 16 384 for 4 µs of flops).  Here each
+//   wave runs 16 rows through the leaf's register chain (accumulators in the natural layout, one 32-byte piece of its own rows of P per
+//   16-column slice, MFMAs against the operand blocks), tiled 16·RT rows × 128 columns per workgroup: the 4 waves are RT row tiles × 4/RT
+//   column groups — RT = 4 for tall launches, 2 / 1 when 64-row workgroups would leave CUs empty (the launch is latency-bound then:
+//   K = 128, m = 4 096: 18.5 / 12.9 / 10.3 µs for RT = 4 / 2 / 1, tools/updk_bench.hip, profiles/r4/updk_bench.txt).  Grid
+//   m/(16·RT) × N/128, 2 workgroups per CU; the k range is streamed in chunks of 32 through a double-buffered LDS image of the operand
+//   rows (natural rows, stride 34): the next chunk travels global -> registers while the current one feeds the MFMAs, one barrier per
+//   chunk.  Tiles entirely above the diagonal of the top block are skipped; the rest of the top block's upper triangle is scratch
+//   (leaves read and write the lower one only).  (A single-stage K = N = 128 predecessor with the whole operand in LDS, panel_upd128,
+//   was 1–14 µs slower per launch at every m; in the history.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void panel_upd128_kernel(double* __restrict__ C, long ldc, const double* __restrict__ P, long ldp, int m) {
+template <int RT>
+__global__ __launch_bounds__(256, 2) void panel_updk_kernel(double* __restrict__ C, long ldc, const double* __restrict__ P, long ldp, int m,
+                                                            int K) {
     using TR = Tr<double>;
-    constexpr int LDB = 130;
-    __shared__ __attribute__((aligned(16))) double Bp[128 * LDB];
+    constexpr int KCH = 32, LDB = KCH + 2;
+    constexpr int CG = 4 / RT;    // column groups: the 4 waves are RT row tiles × CG column groups
+    constexpr int NCW = 8 / CG;   // 16-column blocks (accumulators) per wave
+    __shared__ __attribute__((aligned(16))) double Bp[2][128 * LDB];
+    const int n0 = 128 * (int)blockIdx.y;
+    if (n0 > 16 * RT * (int)blockIdx.x + 16 * RT - 1) return;  // above the diagonal of the top block (workgroup-uniform)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rt = w / CG, cg = w % CG;
     const int li = lane & 15, lg = lane >> 4;
     const int pirow = 4 * (li & 3) + (li >> 2);
     auto ld4 = [&](const double* p16) -> d4_t {
@@ -475,45 +488,79 @@ __global__ __launch_bounds__(256) void panel_upd128_kernel(double* __restrict__ 
         dst[0] = lo;
         dst[1] = hi;
     };
-    const long row = (long)blockIdx.x * 64 + 16 * w + li;  // this lane's row of C / P
+    const long row = (long)blockIdx.x * (16 * RT) + 16 * rt + li;  // this lane's row of C / P
     const bool ok = row < m;
-    // this wave's tile of C and its rows of P are requested first, the operand staging behind them
-    d4_t acc[8], a[8];
+    const double* const Prow = P + (ok ? row : 0) * ldp + 4 * lg;
+    double* const Crow = C + (ok ? row : 0) * ldc + n0 + 16 * NCW * cg + 4 * lg;
+    // operand staging map: piece e = tid + 256·i of the 128 × 32 chunk: row e >> 3, 32-byte piece e & 7
+    const double* Qsrc[4];
+    int qdst[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        if (ok) {
-            acc[c] = ld4(C + row * ldc + 16 * c + 4 * lg);
-            a[c] = ld4(P + row * ldp + 16 * c + 4 * lg);
-        } else {
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, r = e >> 3, pc = e & 7;
+        Qsrc[i] = P + (long)(n0 + r) * ldp + 4 * pc;
+        qdst[i] = r * LDB + 4 * pc;
+    }
+    d4_t acc[NCW], a[2], an[2], g[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[c][q] = 0.0;
-                a[c][q] = 0.0;
-            }
-        }
+    for (int i = 0; i < 4; ++i) g[i] = ld4(Qsrc[i]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a[q] = ld4(Prow + 16 * q);
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) {
+        if (ok) acc[c] = ld4(Crow + 16 * c);
+        else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[c][q] = 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {  // P[0:128, 0:128] -> LDS: 4 096 pieces of 32 bytes over 256 threads
-        const int e = tid + 256 * i, r = e >> 5, pc = e & 31;
-        st4(&Bp[r * LDB + 4 * pc], ld4(P + (long)r * ldp + 4 * pc));
-    }
+    for (int i = 0; i < 4; ++i) st4(&Bp[0][qdst[i]], g[i]);
+    // (everything requested so far is settled before the loop: a wait that is only needed by the first chunk would otherwise be paid,
+    //  as vmcnt(0) behind the loads of the NEXT chunk, by every chunk)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(a[q][0]), "+v"(a[q][1]), "+v"(a[q][2]), "+v"(a[q][3]));
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) asm volatile("" : "+v"(acc[c][0]), "+v"(acc[c][1]), "+v"(acc[c][2]), "+v"(acc[c][3]));
     __syncthreads();
+    const int nch = K / KCH;
+    const int brow = (16 * NCW * cg + pirow) * LDB + 4 * lg;
+    for (int kc = 0; kc < nch; ++kc) {
+        const int cur = kc & 1;
+        const bool more = kc + 1 < nch;
+        if (more) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        d4_t nb[8];
+            for (int i = 0; i < 4; ++i) g[i] = ld4(Qsrc[i] + (kc + 1) * KCH);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const d4_t b = ld4(&Bp[(16 * c + pirow) * LDB + 16 * q + 4 * lg]);
-            nb[c][0] = -b[0]; nb[c][1] = -b[1]; nb[c][2] = -b[2]; nb[c][3] = -b[3];
+            for (int q = 0; q < 2; ++q) an[q] = ld4(Prow + (kc + 1) * KCH + 16 * q);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int q = 0; q < 2; ++q) {
+            d4_t nb[NCW];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = TR::mfma(nb[c][s], a[q][s], acc[c]);
+            for (int c = 0; c < NCW; ++c) {
+                const d4_t b = ld4(&Bp[cur][brow + 16 * c * LDB + 16 * q]);
+                nb[c][0] = -b[0]; nb[c][1] = -b[1]; nb[c][2] = -b[2]; nb[c][3] = -b[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < NCW; ++c) acc[c] = TR::mfma(nb[c][s], a[q][s], acc[c]);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st4(&Bp[cur ^ 1][qdst[i]], g[i]);
+            // the rows of P for the next chunk have had the whole chunk to arrive: settle them HERE, so that no load is pending across the
+            // back edge (otherwise the first MFMA of the next chunk waits with vmcnt(0) behind the loads that chunk has just issued)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(an[q][0]), "+v"(an[q][1]), "+v"(an[q][2]), "+v"(an[q][3]));
+            a[0] = an[0];
+            a[1] = an[1];
+        }
+        __syncthreads();
     }
     if (ok) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) st4(C + row * ldc + 16 * c + 4 * lg, acc[c]);
+        for (int c = 0; c < NCW; ++c) st4(Crow + 16 * c, acc[c]);
     }
 }
 

@@ -155,7 +155,10 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    path, the gradient kernels and the multi-device backward sweep keep their atomics.  1-5 % slower at N <= 32 768.   default 0
  *   "leaf_v2", "leaf_xr"  fp64 leaves by the register-resident panel64v2_kernel (csrc/leaf.hpp) / rows of X per leaf workgroup (0 auto)   default 1, 0
  *   "leaf_cols"      columns per register-resident leaf launch (64 or 128; 128 = one workgroup chain per 128 columns)   default 128
- *   "upd128"         update between two 128-column leaves by panel_upd128_kernel (register chain) instead of the tile GEMM   default 1
+ *   "upd128", "updk_max_k"  in-panel updates C[m×N] −= P·P[0:N]ᵀ of the panel recursion by panel_updk_kernel (csrc/leaf.hpp: register chain, 16-row
+ *                    wave tiles) instead of the tile GEMM: K = N = 128 (on/off) and 256 <= K = N <= updk_max_k; K above "updk_tall_k" only
+ *                    while at most "updk_tall_m" rows are below                          default 1, 512, 256, 8192
+ *   "updk_rt"        rows per workgroup / 16 of that kernel (0 auto: tallest tile giving one workgroup per CU; 4, 2, 1)   default 0
  *   "sk_min_k"       smallest inner dimension that may use the stream-K GEMM                default 0
  *   "leaf_group"     columns factored left-looking by consecutive fused leaves (64/128/256/512)   default 128
  *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256

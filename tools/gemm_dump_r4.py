@@ -27,3 +27,8 @@ for M, N, K, ms, tf in recs:
 for K in sorted(byk):
     c, ms, fl = byk[K]
     print(f"  K={K:5d}: {c:4d} launches {ms:7.3f} ms  {fl / ms:6.1f} TF/s   ideal at 64 TF/s {fl / 64:7.3f} ms  loss {ms - fl / 64:6.3f} ms")
+print("  K = 2048 launches one by one (M, N, tiles on / below the diagonal, ms, TF/s):")
+for M, N, K, ms, tf in recs:
+    if int(K) >= 2048:
+        tiles = ms * tf * 1e9 / (2 * 128 * 128 * K)
+        print(f"    M={int(M):6d} N={int(N):6d} K={int(K):5d} tiles={tiles:7.0f} rounds={tiles / 512:5.2f} ms={ms:7.3f} TF/s={tf:5.1f}")

@@ -28,8 +28,11 @@ for name, n, d, seed, kern in cases:
     x, y = synth(n, d, seed)
     fx = agp.GP(kern, ctx=ctx)(agp.RowVecs(x), 0.01)
     ref = None
-    for tag, params in (("default", {}), ("nb1024", {"nb": 1024}), ("nb4096", {"nb": 4096}), ("nb1024_la", {"nb": 1024, "lookahead_min_n": 0}),
-                        ("lg256", {"leaf_group": 256})):
+    for tag, params in (("default", {}), ("gemm_only", {"updk_max_k": 0, "upd128": 0}), ("k128_only", {"updk_max_k": 0}), ("k256", {"updk_max_k": 256}),
+                        ("k512_all_m", {"updk_tall_m": 1 << 30}), ("rt4", {"updk_rt": 4}), ("rec", {"nb": 0})):
+        ctx.set_param("updk_max_k", 512)
+        ctx.set_param("updk_tall_m", 8192)
+        ctx.set_param("updk_rt", 0)
         ctx.set_param("lookahead_min_n", 24576)
         ctx.set_param("upd128", 1)
         ctx.set_param("leaf_group", 128)
@@ -58,3 +61,6 @@ ctx.set_param("leaf_cols", 128)
 ctx.set_param("lookahead", 1)
 ctx.set_param("lookahead_min_n", 24576)
 ctx.set_param("upd128", 1)
+ctx.set_param("updk_max_k", 512)
+ctx.set_param("updk_tall_m", 8192)
+ctx.set_param("updk_rt", 0)
