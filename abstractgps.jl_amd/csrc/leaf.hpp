@@ -460,6 +460,9 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
 //   (leaves read and write the lower one only).  (A single-stage K = N = 128 predecessor with the whole operand in LDS, panel_upd128,
 //   was 1–14 µs slower per launch at every m; in the history.)
 // ------------------------------------------------------------------------------------------------
+#ifndef GPMI_UPDK_ABL
+#define GPMI_UPDK_ABL 0  // ablation switches of tools/updk_bench.hip (timing experiments only; 0 in the product build)
+#endif
 template <int RT>
 __global__ __launch_bounds__(256, 2) void panel_updk_kernel(double* __restrict__ C, long ldc, const double* __restrict__ P, long ldp, int m,
                                                             int K) {
@@ -528,10 +531,16 @@ __global__ __launch_bounds__(256, 2) void panel_updk_kernel(double* __restrict__
         const int cur = kc & 1;
         const bool more = kc + 1 < nch;
         if (more) {
+#if !(GPMI_UPDK_ABL & 2)
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[i] = ld4(Qsrc[i] + (kc + 1) * KCH);
+#endif
+#if !(GPMI_UPDK_ABL & 1)
 #pragma unroll
             for (int q = 0; q < 2; ++q) an[q] = ld4(Prow + (kc + 1) * KCH + 16 * q);
+#else
+            an[0] = a[1]; an[1] = a[0];
+#endif
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -547,8 +556,10 @@ __global__ __launch_bounds__(256, 2) void panel_updk_kernel(double* __restrict__
                 for (int c = 0; c < NCW; ++c) acc[c] = TR::mfma(nb[c][s], a[q][s], acc[c]);
         }
         if (more) {
+#if !(GPMI_UPDK_ABL & 2)
 #pragma unroll
             for (int i = 0; i < 4; ++i) st4(&Bp[cur ^ 1][qdst[i]], g[i]);
+#endif
             // the rows of P for the next chunk have had the whole chunk to arrive: settle them HERE, so that no load is pending across the
             // back edge (otherwise the first MFMA of the next chunk waits with vmcnt(0) behind the loads that chunk has just issued)
 #pragma unroll
@@ -556,7 +567,9 @@ __global__ __launch_bounds__(256, 2) void panel_updk_kernel(double* __restrict__
             a[0] = an[0];
             a[1] = an[1];
         }
+#if !(GPMI_UPDK_ABL & 4)
         __syncthreads();
+#endif
     }
     if (ok) {
 #pragma unroll
