@@ -89,7 +89,6 @@ struct gp_ctx {
     long sk_max_tiles = 4096;  // stream-K only for launches of at most this many tiles (8 rounds): the persistent kernel is
     long sk_min_k = 0;     // launches with a shorter k range take the plain tile kernel (experiment knob)
                            // ~5 % slower than hardware dispatch on large launches, where the tail does not matter anyway
-    int sk_u1 = 0;         // stream-K for the U1 update of the look-ahead schedule (measured: no effect)
     int sk_scope = 0;      // > 0 inside single-stream entry points (predict / update / gradient): stream-K GEMM tails pay there
                            // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —

@@ -464,15 +464,8 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
         }
         if (k1 >= np) break;  // RHS rows were already solved inside potrf_rec
         const long nb1 = std::min(nb, np - k1);
-        // U1: next panel's columns, all rows below.  Nothing can run beside it (the panel waits for it, U2 is queued behind
-        // it), so its tail is not filled by another stream: stream-K variant (sk_u1)
-        {
-            if (c->sk_u1) ++c->sk_scope;
-            const int32_t rc_u1 = launch_gemm<T>(c, sM, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda,
-                                                 mtot - k1, nb1, nbk, plain_map(1, k1, k1));
-            if (c->sk_u1) --c->sk_scope;
-            RC(rc_u1);
-        }
+        // U1: next panel's columns, all rows below
+        RC(launch_gemm<T>(c, sM, A + k1 * lda + k1, lda, A + k1 * lda + k, lda, A + k1 * lda + k, lda, mtot - k1, nb1, nbk, plain_map(1, k1, k1)));
         if (la) {
             RC(ctx_event(c, &ev_u1, false));
             HIPCHK(hipEventRecord(ev_u1, sM));
@@ -1447,7 +1440,6 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
     else if (!strcmp(name, "xcd_swizzle")) c->xcd_swizzle = v != 0;
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
-    else if (!strcmp(name, "sk_u1")) c->sk_u1 = v != 0;
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
     else if (!strcmp(name, "sk_min_k")) c->sk_min_k = v;
     else if (!strcmp(name, "gemm_pad_lds")) {

@@ -168,6 +168,12 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
+ *   "sk_max_tiles"   largest launch (in 128×128 tiles) that takes the persistent stream-K GEMM    default 4096
+ *   "vfe_sk"         VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))   default 0
+ *   "copy_kernel"    multi-device: block copies by a kernel instead of hipMemcpy2DAsync            default 0
+ *   "multi_window"   multi-device: block steps a rank thread may queue ahead of its device         default 16
+ *   "multi_debug_sync", "multi_inject_fault"  multi-device diagnostics: host synchronisation points of the rank threads (bit mask) /
+ *                    hand the next fit's self-check a spoiled α once (tests/test_gpu_multi.py)      default 0, 0
  *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Return every cached (free) device block of the ctx to the HIP allocator — e.g. after freeing an N = 65 536 posterior

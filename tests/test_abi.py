@@ -63,3 +63,19 @@ def test_api_errors_mirror_reference(agp):
     k = 2.0 * agp.Matern32Kernel() @ agp.ScaleTransform(0.5)
     assert (k.kind, k.variance, k.transform.s) == (2, 2.0, 0.5)
     assert agp.with_lengthscale(agp.SqExponentialKernel(), 4.0).transform.s == 0.25
+
+
+def test_every_ctx_parameter_the_library_accepts_is_documented_in_the_header():
+    """gp_ctx_set_param's names (csrc/gpmi355.hip, csrc/multi.hip) against the parameter list of include/gpmi355.h: round 4 shipped three
+    tuning parameters for half a day that only the source knew about."""
+    import re
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    names = set()
+    for f in ("gpmi355.hip", "multi.hip"):
+        names |= set(re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', (root / "abstractgps.jl_amd" / "csrc" / f).read_text()))
+    assert len(names) >= 30, names
+    hdr = (root / "include" / "gpmi355.h").read_text()
+    missing = sorted(n for n in names if f'"{n}"' not in hdr)
+    assert not missing, f"ctx parameters without a line in include/gpmi355.h: {missing}"
