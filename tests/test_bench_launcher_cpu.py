@@ -41,3 +41,27 @@ def test_dry_launcher_single_process():
                        timeout=120, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["world"] == 1
+
+
+def test_comparator_is_bounded_and_never_takes_the_line_down(monkeypatch):
+    """The rocSOLVER yardstick runs in a child process with a hard time limit (one GPU box of round 4 needed more than five minutes to
+    load librocsolver.so and the whole bench timed out in it).  Without a device the child answers with an error object; with a child that
+    hangs, the parent reports the skip — in both cases a dict that goes into the JSON line."""
+    import importlib.util
+    import time
+
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.rocsolver_comparator(timeout_s=120.0)
+    assert isinstance(out, dict) and ("error" in out or "skipped" in out or any(k.startswith("N") for k in out)), out
+    # a child that never answers: sys.executable is replaced by a sleeper
+    sleeper = ROOT / "tests" / "_sleeper.py"
+    sleeper.write_text("import time\ntime.sleep(60)\n")
+    try:
+        monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(sleeper))
+        t0 = time.perf_counter()
+        out = bench.rocsolver_comparator(timeout_s=2.0)
+        assert "skipped" in out and time.perf_counter() - t0 < 20.0
+    finally:
+        sleeper.unlink()

@@ -198,6 +198,24 @@ def test_potrf_leaf_groups(lib, h, group):
         check(lib.gp_ctx_set_param(h, b"leaf_group", 128))
 
 
+@pytest.mark.parametrize("rt,maxk", [(1, 512), (2, 512), (4, 512), (0, 1024), (0, 0)])
+def test_potrf_in_panel_update_tiles(lib, h, rt, maxk):
+    """the in-panel updates C[m×N] −= P·P[0:N]ᵀ (K = N = 128 / 256 / 512) through panel_updk_kernel<RT> (csrc/leaf.hpp) with every workgroup
+    tile forced in turn (16 / 32 / 64 rows), with K = 1 024 admitted as well, and through the tile GEMM only (maxk = 0, upd128 = 0): same
+    contract as test_potrf_and_trsm on shapes with ragged row counts below the columns."""
+    from abstractgps_jl_amd._lib import check
+
+    for k, v in ((b"updk_rt", rt), (b"updk_max_k", maxk), (b"updk_tall_k", 1024 if maxk else 256), (b"upd128", 1 if maxk else 0)):
+        check(lib.gp_ctx_set_param(h, k, v))
+    try:
+        for n, extra in ((256, 0), (512, 136), (1024, 320), (2048, 200 * 128 + 64)):
+            test_potrf_and_trsm(lib, h, n, extra)
+        test_potrf_reports_first_bad_pivot(lib, h)
+    finally:
+        for k, v in ((b"updk_rt", 0), (b"updk_max_k", 512), (b"updk_tall_k", 256), (b"upd128", 1)):
+            check(lib.gp_ctx_set_param(h, k, v))
+
+
 @pytest.mark.parametrize("nbv", [128, 256, 512, 1024])
 def test_trsv_block_sizes(lib, h, nbv):
     """diagonal block of the vector solves (one workgroup) = 128 … 1024; the rest goes to the multi-CU update kernels"""
