@@ -202,13 +202,13 @@ def test_potrf_leaf_groups(lib, h, group):
 def test_potrf_in_panel_update_tiles(lib, h, rt, maxk):
     """the in-panel updates C[m×N] −= P·P[0:N]ᵀ (K = N = 128 / 256 / 512) through panel_updk_kernel<RT> (csrc/leaf.hpp) with every workgroup
     tile forced in turn (16 / 32 / 64 rows), with K = 1 024 admitted as well, and through the tile GEMM only (maxk = 0, upd128 = 0): same
-    contract as test_potrf_and_trsm on shapes with ragged row counts below the columns."""
+    contract as test_potrf_and_trsm, up to 27 712 rows below 2 048 columns."""
     from abstractgps_jl_amd._lib import check
 
     for k, v in ((b"updk_rt", rt), (b"updk_max_k", maxk), (b"updk_tall_k", 1024 if maxk else 256), (b"upd128", 1 if maxk else 0)):
         check(lib.gp_ctx_set_param(h, k, v))
     try:
-        for n, extra in ((256, 0), (512, 136), (1024, 320), (2048, 200 * 128 + 64)):
+        for n, extra in ((256, 0), (512, 192), (1024, 320), (2048, 200 * 128 + 64)):
             test_potrf_and_trsm(lib, h, n, extra)
         test_potrf_reports_first_bad_pivot(lib, h)
     finally:
