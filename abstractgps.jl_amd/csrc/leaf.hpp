@@ -1,4 +1,5 @@
-// leaf.hpp — the register-resident 64-column leaf of the blocked Cholesky (fp64), its own translation unit (leaf.hip):
+// leaf.hpp — the register-resident 64- / 128-column leaf of the blocked Cholesky (fp64) and the in-panel update kernel in the same style
+// (panel_updk_kernel, at the end), their own translation unit (leaf.hip):
 // it is compiled with -mllvm -amdgpu-mfma-vgpr-form so that the MFMA accumulators of the diagonal chain live in VGPRs — with the
 // default AGPR form every column of the 16×16 factorisation paid 16 v_accvgpr_read copies to get at two registers (≈ 100 of its
 // 400 cycles), and the flag is per translation unit (the GEMM kernels keep the AGPR form they were tuned with).
@@ -29,12 +30,17 @@ namespace gpmi {
 //                              64 lanes instead of ≈ 60 fp64 VALU on 16 lanes.
 //   Roles: wave 0 runs the diagonal chain (P3 of block j).  Waves 1–3 own the other row tiles: wave w the rows 16w..16w+15 of the
 //   diagonal tile (blocks (w, c), c < w, natural; block (w, w) symmetric) and XR/16 row tiles of X spread over the three.
-//   Step j: wave 0 factors block (j, j), publishes Inv_j                                 | barrier B1
-//           owners: X_j ← X_j Inv_jᵀ (stored to global at once), D(t, j) ← D(t, j) Inv_jᵀ published as L(t, j), D(t, t) −= L(t, j) L(t, j)ᵀ;
-//                   the owner of row tile j+1 goes first and hands block (j+1, j+1) to wave 0  | barrier B2
-//           wave 0 factors block (j+1, j+1)  ∥  owners: X_c −= X_j L(c, j)ᵀ, D(t, c) −= D(t, j) L(c, j)ᵀ for c > j
+//   Step j (ONE workgroup barrier per step):
+//           wave 0 factors block (j, j) and publishes Inv_j, L(j, j); the owner of row tile j+1 has meanwhile brought its blocks (j+1, j)
+//           and (j+1, j+1) up to date with the columns before j (left-looking) and leaves them RAW in LDS (yx, dAx)        | barrier B1
+//           wave 0: block (j+1, j) ← raw · Inv_jᵀ, published as L(j+1, j); block (j+1, j+1) −= L(j+1, j) L(j+1, j)ᵀ; goes straight on with
+//                   the factorisation of block j+1 — the pivot chain never waits for another wave's arithmetic
+//           owners: X_j ← X_j Inv_jᵀ (stored to global at once), D(t, j) ← D(t, j) Inv_jᵀ published as L(t, j) for t > j+1; they meet at a
+//                   counter in LDS (`pub`: 4 increments per step, wave 0's included) before the right-looking updates D(t, c) −= …, c > j,
+//                   that read the blocks the others published.  X is updated left-looking (x[t][j] −= Σ_{c<j} x[t][c] L(j, c)ᵀ right
+//                   before its solve), so X tiles are loaded lazily, two steps ahead of their use.
 //   Loads: every wave loads exactly what it owns straight into registers (32-byte pieces); wave 0 needs 4 doubles per lane before the
-//   first pivot.  LDS holds only the published factor blocks (45 KB instead of 111 KB), so several leaves fit on a CU.
+//   first pivot.  LDS holds only the published factor blocks (46 KB for 64 columns instead of 111 KB; 152 KB for the 128-column leaf).
 //   kpre > 0 (left-looking entry, as in panel64_kernel): the kpre tiles to the left are applied first, L_k staged in LDS, the left
 //   tile's rows of this workgroup loaded in natural layout and used as the B operands of P1 / both operands of P2.
 // ------------------------------------------------------------------------------------------------
@@ -45,10 +51,9 @@ namespace gpmi {
 // instead of 62–70) — and the independent accumulators of a phase are updated slice by slice, back to back.
 // Ownership: row tile t ≥ 1 of the diagonal tile belongs to wave 1 + (t − 1) mod 3 (blocks (t, c), c < t, natural; block (t, t)
 // symmetric); the XR/16 row tiles of X are spread over waves 1..3.
-// Synchronisation per step j: B1 (Inv_j published by wave 0) — the owner of row tile j+1 solves its block (j+1, j), updates block
-// (j+1, j+1) and hands it over — B2 (wave 0 goes on with block j+1; nobody waits for the other row tiles here).  The other row tiles'
-// blocks (t, j) are solved and published AFTER B2; the owners meet at a counter in LDS (`pub`: one increment per owner and step) before
-// the updates that read them — wave 0 takes no part in that, so the pivot chain waits only for the one block it needs.
+// Synchronisation per step j: ONE workgroup barrier B1 (Inv_j published by wave 0; the raw blocks (j+1, j), (j+1, j+1) left in LDS by their
+// owner), after which wave 0 solves and updates the hand-over block itself and goes on; the owners' other blocks (t, j) are solved and
+// published after B1 and the owners meet at the LDS counter `pub` (release / acquire fences around it) before the updates that read them.
 // All four instances execute the same workgroup barriers.
 template <int XR, int W, int NC>
 __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0, int n_valid,
