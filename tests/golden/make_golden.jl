@@ -1,6 +1,7 @@
 # make_golden.jl — reference-side golden vectors for the logpdf / posterior / VFE path.
 #
-#   julia --project=<env with AbstractGPs 0.5.x> tests/golden/make_golden.jl
+#   julia --project=tests/golden -e 'using Pkg; Pkg.instantiate()'      (tests/golden/Project.toml: AbstractGPs 0.5.24)
+#   julia --project=tests/golden tests/golden/make_golden.jl
 #
 # Reads tests/golden/julia_inputs/<case>.gpb (written by tests/golden/export_julia_inputs.py: the inputs of the committed
 # fixtures, bit for bit) and runs the REAL AbstractGPs.jl on them:
