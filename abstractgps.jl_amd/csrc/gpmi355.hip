@@ -1465,7 +1465,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
-             !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_dist_predict") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
+             !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_dist_predict") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk") || !strcmp(name, "multi_leaf_cols")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
 }

@@ -1405,7 +1405,11 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
         for (auto& rk : m->ranks) (void)gp_ctx_set_param(rk.c, "gemm_streamk", v);
         return 0;
     }
-    if (!strcmp(name, "gemm_streamk")) return 1;  // the main ctx only (everything that runs on devices[0] alone)
+    if (!strcmp(name, "multi_leaf_cols")) {  // columns per register-resident leaf inside the rank contexts (64: co-resident with the bulk update; 128)
+        for (auto& rk : m->ranks) (void)gp_ctx_set_param(rk.c, "leaf_cols", v);
+        return 0;
+    }
+    if (!strcmp(name, "gemm_streamk") || !strcmp(name, "leaf_cols")) return 1;  // the main ctx only (everything that runs on devices[0] alone)
     // every other parameter also goes to the rank contexts (kernel variants, timing switches)
     for (auto& rk : m->ranks) (void)gp_ctx_set_param(rk.c, name, v);
     return 1;
@@ -1458,6 +1462,12 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
         // stream of the LOWEST priority unless GPMI_COMM_PRIO=1 (the first-fit item of round 2).
         const char* ske = getenv("GPMI_MULTI_SK");
         (void)gp_ctx_set_param(rk.c, "gemm_streamk", (ske && ske[0] == '1') ? 1 : 0);
+        // 64-column leaves in the rank contexts ("multi_leaf_cols"): the diagonal block of the look-ahead panel is factored on the panel stream
+        // WHILE the bulk update runs on the main stream.  The 128-column leaf needs 152 KB of LDS, i.e. an empty CU, and a running tile GEMM
+        // refills every workgroup slot it frees: each of a block's leaves would wait for the end of a GEMM launch (measured on one GPU,
+        // profiles/r4/traces/c3_la1_summary.txt: the first leaf of a panel "runs" for the whole 25 ms of the update beside it) — more launch
+        // boundaries than the look-ahead depth covers.  The 64-column leaf (46 KB, 226 VGPRs) fits beside one GEMM workgroup and starts at once.
+        (void)gp_ctx_set_param(rk.c, "leaf_cols", 64);
         int plo = 0, phi = 0;
         const char* pe = getenv("GPMI_COMM_PRIO");
         if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess ||

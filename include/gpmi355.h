@@ -171,6 +171,8 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "sk_max_tiles"   largest launch (in 128×128 tiles) that takes the persistent stream-K GEMM    default 4096
  *   "vfe_sk"         VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))   default 0
  *   "copy_kernel"    multi-device: block copies by a kernel instead of hipMemcpy2DAsync            default 0
+ *   "multi_leaf_cols"  multi-device: columns per register-resident leaf inside the rank contexts — 64 (46 KB of LDS: starts beside the bulk
+ *                    update) rather than the single-device 128 (152 KB: waits for an empty CU, i.e. for the end of a GEMM launch)   default 64
  *   "multi_window"   multi-device: block steps a rank thread may queue ahead of its device         default 16
  *   "multi_debug_sync", "multi_inject_fault"  multi-device diagnostics: host synchronisation points of the rank threads (bit mask) /
  *                    hand the next fit's self-check a spoiled α once (tests/test_gpu_multi.py)      default 0, 0
