@@ -1,7 +1,12 @@
 """GPU parity tests proper: the HIP path (through the C ABI / the API mirror) against the CPU oracle
 and the committed golden fixtures on the same seeded inputs.  Tolerances (fp64):
 K entries abs <= 1e-14·σ_k²; logpdf rel <= 1e-10; α rel(2-norm) <= 1e-8; predictive mean abs <= 1e-8,
-var abs <= 1e-9.  fp32: logpdf/ELBO rel <= 1e-4 against the fp64 oracle."""
+var abs <= 1e-9.  fp32: logpdf/ELBO rel <= 1e-4 against the fp64 oracle.
+
+What the two comparisons are: the committed fixtures tests/golden/*.npz were WRITTEN BY THE ORACLE (tests/golden/make_golden.py imports
+oracle.gp_oracle), so "golden and oracle" is one source seen twice — a regression pin of the oracle's past output plus the oracle's present
+output, not two independent references.  The independent pins live in tests/test_oracle.py (MvNormal, 60-digit mpmath, scikit-learn's
+GaussianProcessRegressor) and, once a maintainer has run tests/golden/make_golden.jl, in tests/test_julia_golden.py (the real AbstractGPs.jl)."""
 import glob
 from pathlib import Path
 
@@ -50,6 +55,7 @@ def test_kernelmatrix_vs_oracle(agp, path):
 
 @pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
 def test_logpdf_posterior_vs_golden_and_oracle(agp, path):
+    """device against the oracle's committed output (fixture) and the oracle's present output — one source twice, see the module docstring"""
     g, f, fx, of, ofx = _golden(agp, path)
     lp = agp.logpdf(fx, g["y"])
     assert isinstance(lp, np.float64)
