@@ -28,6 +28,8 @@ import perf_model as pm  # noqa: E402
 LINK = 64e9         # B/s per xGMI link and direction that a large transfer sustains (MI355X: 153.6 GB/s per link bidirectional peak)
 MSG_LAT = 8e-6      # per point-to-point message (group launch + link latency)
 TRSM_RATE = 45e12   # MFMA TRSM of a tall block against an NB×NB factor (recursion of GEMMs + 64-wide leaves)
+CORES = 1.0         # slow-down of the diagonal block's leaf chain when it runs BESIDE the bulk update (round 4, one GPU: a 64-column leaf that shares CUs
+                    # with the tile GEMM runs ≈ 5× slower, profiles/r4/traces/c3_c64_summary.txt; `python tools/grid_model.py cores=5` prices that)
 
 
 def local_lower_blocks(nblk, P, Q, p, q, r0, c0):
@@ -61,7 +63,7 @@ def model(N, P, Q, NB, depth=2, forward=False):
 
     def panel_time(k):
         m = nblk - k - 1
-        t = pm.panel(NB, NB)                                   # diagonal block on its owner
+        t = pm.panel(NB, NB) * CORES                           # diagonal block on its owner (beside the bulk update: CORES)
         if P > 1:
             t += 8.0 * NB * NB / LINK + MSG_LAT                # L_kk to the column peers (P−1 links at once)
         rows = math.ceil(m / P) * NB
@@ -156,6 +158,10 @@ def best(N, R, nbs=(512, 1024, 2048), forward=False):
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
     FWD = "forward" in sys.argv
+    for a in sys.argv[1:]:
+        if a.startswith("cores="):
+            CORES = float(a.split("=")[1])
+            print(f"diagonal-block chain priced {CORES:g}x slower (co-resident with the bulk update)")
     if FWD:
         print("A-operand forwarding PRICED (two-phase slice exchange inside a process row; not implemented in the driver)")
     one = model(N, 1, 1, 2048)
