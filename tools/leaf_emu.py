@@ -1,0 +1,111 @@
+"""Lane-by-lane NumPy emulation of v_mfma_f64_16x16x4_f64 and of the register layouts csrc/leaf.hpp builds on it (no GPU needed).
+
+MFMA f64 16×16×4 on a 64-lane wave, lane l = (li, lg) = (l & 15, l >> 4):
+    A operand (16×4):  lane holds A[i = li][k = lg]
+    B operand (4×16):  lane holds B[k = lg][j = li]
+    accumulator (16×16, 4 registers per lane): register r of lane (li, lg) is element (row lg + 4r, column li)
+Layouts of a 16×16 block T in leaf.hpp:
+    natural    n[s] = T[li][4·lg + s]   (one 32-byte piece of row li per lane)
+    symmetric  a[r] = A[lg + 4r][li]    (the accumulator layout itself)
+π(i) = 4·(i mod 4) + i div 4.
+
+Checked here against plain matrix arithmetic:
+    P1   acc = Σ_s mfma(±M[π(li)][4lg + s], n_T[s], acc)  with acc natural(T')  gives  natural(T' ± T·Mᵀ)
+    P2   acc = Σ_s mfma(−n_L[s], n_L[s], acc)            with acc symmetric(A)  gives  symmetric(A − L·Lᵀ)
+    UPD  panel_updk_kernel: acc[c] = Σ_{q, s} mfma(−Q[16c + π(li)][16q + 4lg + s], P[row li][16q + 4lg + s], acc[c])  with acc[c][r] = C[row li][16c + 4lg + r]
+         gives C − P·Qᵀ on the wave's 16 rows.
+Run:  python tools/leaf_emu.py   (prints the three maximum deviations; tests/test_leaf_emu.py asserts them)."""
+import numpy as np
+
+LANES = np.arange(64)
+LI, LG = LANES & 15, LANES >> 4
+
+
+def pi(i):
+    return 4 * (i % 4) + i // 4
+
+
+def mfma(a, b, acc):
+    """a, b: per-lane operand values (64,), acc: per-lane accumulator registers (64, 4) -> new accumulator registers"""
+    A = np.zeros((16, 4))
+    B = np.zeros((4, 16))
+    A[LI, LG] = a          # lane (li, lg) -> A[i = li][k = lg]
+    B[LG, LI] = b          # lane (li, lg) -> B[k = lg][j = li]
+    D = A @ B
+    out = acc.copy()
+    for r in range(4):
+        out[:, r] += D[LG + 4 * r, LI]   # register r of lane (li, lg) = element (lg + 4r, li)
+    return out
+
+
+def natural(T):
+    """(64, 4): n[s] of every lane"""
+    return np.stack([T[LI, 4 * LG + s] for s in range(4)], axis=1)
+
+
+def from_natural(n):
+    T = np.zeros((16, 16))
+    for s in range(4):
+        T[LI, 4 * LG + s] = n[:, s]
+    return T
+
+
+def symmetric(A):
+    return np.stack([A[LG + 4 * r, LI] for r in range(4)], axis=1)
+
+
+def from_symmetric(a):
+    A = np.zeros((16, 16))
+    for r in range(4):
+        A[LG + 4 * r, LI] = a[:, r]
+    return A
+
+
+def check_p1(rng, sign=-1.0):
+    T, M, Tp = rng.standard_normal((3, 16, 16))
+    acc = natural(Tp)
+    nT = natural(T)
+    for s in range(4):
+        acc = mfma(sign * M[pi(LI), 4 * LG + s], nT[:, s], acc)
+    return np.max(np.abs(from_natural(acc) - (Tp + sign * T @ M.T)))
+
+
+def check_p2(rng):
+    L = np.tril(rng.standard_normal((16, 16)))
+    A = rng.standard_normal((16, 16))
+    acc = symmetric(A)
+    nL = natural(L)
+    for s in range(4):
+        acc = mfma(-nL[:, s], nL[:, s], acc)
+    return np.max(np.abs(from_symmetric(acc) - (A - L @ L.T)))
+
+
+def check_updk(rng, K=64, N=128):
+    """one wave's 16 rows of C[16 × N] −= P[16 × K] · Q[N × K]ᵀ as the kernel issues it (chunks of 32 columns = 2 slices of 16)"""
+    P = rng.standard_normal((16, K))
+    Q = rng.standard_normal((N, K))
+    C = rng.standard_normal((16, N))
+    acc = [np.stack([C[LI, 16 * c + 4 * LG + r] for r in range(4)], axis=1) for c in range(N // 16)]
+    for q in range(K // 16):
+        for s in range(4):
+            a = P[LI, 16 * q + 4 * LG + s]
+            for c in range(N // 16):
+                acc[c] = mfma(-Q[16 * c + pi(LI), 16 * q + 4 * LG + s], a, acc[c])
+    out = np.zeros_like(C)
+    for c in range(N // 16):
+        for r in range(4):
+            out[LI, 16 * c + 4 * LG + r] = acc[c][:, r]
+    return np.max(np.abs(out - (C - P @ Q.T)))
+
+
+def main():
+    rng = np.random.default_rng(7)
+    res = {"P1 (T' - T M^T, natural in / natural out)": check_p1(rng, -1.0), "P1 (+)": check_p1(rng, 1.0),
+           "P2 (A - L L^T, symmetric accumulator)": check_p2(rng), "UPD (panel_updk wave tile)": check_updk(rng)}
+    for k, v in res.items():
+        print(f"{k}: max |deviation| = {v:.2e}")
+    return res
+
+
+if __name__ == "__main__":
+    main()
