@@ -12,6 +12,7 @@ Layouts of a 16×16 block T in leaf.hpp:
 Checked here against plain matrix arithmetic:
     P1   acc = Σ_s mfma(±M[π(li)][4lg + s], n_T[s], acc)  with acc natural(T')  gives  natural(T' ± T·Mᵀ)
     P2   acc = Σ_s mfma(−n_L[s], n_L[s], acc)            with acc symmetric(A)  gives  symmetric(A − L·Lᵀ)
+    P3   the 16×16 factorisation on the accumulator with the inverse riding (see check_p3)
     UPD  panel_updk_kernel: acc[c] = Σ_{q, s} mfma(−Q[16c + π(li)][16q + 4lg + s], P[row li][16q + 4lg + s], acc[c])  with acc[c][r] = C[row li][16c + 4lg + r]
          gives C − P·Qᵀ on the wave's 16 rows.
 Run:  python tools/leaf_emu.py   (prints the three maximum deviations; tests/test_leaf_emu.py asserts them)."""
@@ -98,10 +99,51 @@ def check_updk(rng, K=64, N=128):
     return np.max(np.abs(out - (C - P @ Q.T)))
 
 
+def check_p3(rng):
+    """P3 of leaf.hpp: the 16×16 Cholesky column by column on the accumulator (symmetric layout), every column's rank-1 update ONE MFMA whose
+    K-slot operand is the scaled column masked to its lane group, the pivot of column c+1 formed early from the values before the update
+    (A[c+1][c+1] − L[c+1][c]²), and the identity riding transposed in a second accumulator so that L⁻¹ falls out without extra work.
+    Returns the deviations of L and of Inv = L⁻¹ from numpy."""
+    G = rng.standard_normal((16, 16))
+    A = G @ G.T + 16 * np.eye(16)
+    accA = symmetric(A)
+    accW = symmetric(np.eye(16))
+    Ls = np.zeros((64, 4))
+    Ws = np.zeros((64, 4))
+    bcast = lambda v, lane: v[lane]
+    sel = np.where(LG == 0, 1.0 / np.sqrt(bcast(accA[:, 0], 0)), 0.0)
+    for c in range(16):
+        k, p = c & 3, c >> 2
+        pa = accA[:, p] * sel            # lane (i, k): L[i][c]; zero outside lane group k
+        if c < 15:
+            c1 = c + 1
+            k1, p1 = c1 & 3, c1 >> 2
+            l = bcast(pa, 16 * k + c1)                    # L[c+1][c]
+            dnext = bcast(accA[:, p1], 16 * k1 + c1)      # A[c+1][c+1] before this column's update
+            accA = mfma(-pa, pa, accA)
+        pw = accW[:, p] * sel            # lane (i, k): (L⁻ᵀ)[i][c]
+        Ls[:, p] = np.where(LG == k, pa, Ls[:, p])
+        Ws[:, p] = np.where(LG == k, pw, Ws[:, p])
+        if c < 15:
+            sel = np.where(LG == k1, 1.0 / np.sqrt(dnext - l * l), 0.0)
+            accW = mfma(-pa, pw, accW)
+    L = np.zeros((16, 16))
+    Inv = np.zeros((16, 16))
+    for r in range(4):
+        col = LG + 4 * r
+        L[LI, col] = np.where(LI >= col, Ls[:, r], 0.0)   # Ls[r] of lane (li, lg) = L[li][lg + 4r]
+        Inv[col, LI] = Ws[:, r]                           # Ws[r] = (L⁻ᵀ)[li][lg + 4r] = Inv[lg + 4r][li]
+    Lref = np.linalg.cholesky(A)
+    return np.max(np.abs(L - Lref)), np.max(np.abs(np.tril(Inv) - np.linalg.inv(Lref)))
+
+
 def main():
     rng = np.random.default_rng(7)
     res = {"P1 (T' - T M^T, natural in / natural out)": check_p1(rng, -1.0), "P1 (+)": check_p1(rng, 1.0),
            "P2 (A - L L^T, symmetric accumulator)": check_p2(rng), "UPD (panel_updk wave tile)": check_updk(rng)}
+    dl, di = check_p3(rng)
+    res["P3 (16x16 Cholesky by rank-1 MFMA updates): L"] = dl
+    res["P3: Inv = L^-1 riding transposed"] = di
     for k, v in res.items():
         print(f"{k}: max |deviation| = {v:.2e}")
     return res
