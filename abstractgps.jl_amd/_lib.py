@@ -51,6 +51,7 @@ PROTOTYPES = {
     "gp_multi_solve_trace_ex": (i32, [i32, i32, i32, i32, C.c_char_p]),
     "gp_ctx_destroy": (i32, [vp]),
     "gp_ctx_set_param": (i32, [vp, C.c_char_p, i64]),
+    "gp_ctx_get_param": (i32, [vp, C.c_char_p, C.POINTER(i64)]),
     "gp_get_timings": (i32, [vp, C.POINTER(gp_timings)]),
     "gp_last_error": (C.c_char_p, []),
     "gp_abi_version": (i32, []),
@@ -121,7 +122,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.gp_abi_version() != 3:
+    if lib.gp_abi_version() != 4:
         raise ImportError("libgpmi355.so ABI version mismatch")
     _lib = lib
     return lib

@@ -15,6 +15,7 @@ gp_posterior_logpdf / gp_posterior_rand / gp_vfe_logpdf / gp_vfe_rand).
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import Mapping
 import math
 import threading
 import weakref
@@ -232,6 +233,11 @@ class Context:
 
     def set_param(self, name: str, value: int) -> None:
         check(self.lib.gp_ctx_set_param(self.handle, name.encode(), int(value)))
+
+    def get_param(self, name: str) -> int:
+        v = C.c_int64()
+        check(self.lib.gp_ctx_get_param(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def timings(self) -> dict:
         t = gp_timings()
@@ -825,16 +831,21 @@ def _vfe_call(approx, fx: FiniteGP, y, want_post: bool):
     return (h if want_post else None), obj[0], ctx, dt, pz.n
 
 
-class _VfeData:
-    """Lazy view of an ApproxPosteriorGP's device-resident cache (field names of src/sparse_approximations.jl:73, ASCII)."""
+class _VfeData(Mapping):
+    """Lazy read-only Mapping over an ApproxPosteriorGP's device-resident cache (field names of src/sparse_approximations.jl:73, ASCII):
+    iteration, len, keys / items / values / get behave like the plain dict this property once returned; every read of a field fetches it
+    from the device (nothing is cached on the host)."""
 
     _FIELDS = ("alpha", "m_eps", "U", "Lam_U", "b_y")
 
     def __init__(self, post):
         self._post = post
 
-    def keys(self):
-        return self._FIELDS
+    def __iter__(self):
+        return iter(self._FIELDS)
+
+    def __len__(self):
+        return len(self._FIELDS)
 
     def __contains__(self, k):
         return k in self._FIELDS

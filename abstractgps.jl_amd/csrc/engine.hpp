@@ -32,6 +32,7 @@ struct GridMap {
     int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
     long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
     int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
+    int nt;          // kmat: interior tiles written with nontemporal stores
 };
 }  // namespace gpmi
 
@@ -93,6 +94,9 @@ struct gp_ctx {
                            // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
+    long gemm_pad_f32 = 20480; // the fp32 default of the above (0: two workgroups per CU)
+    int gemm_pipe = 1;     // k loop of the MFMA GEMMs software-pipelined across the step boundary (kernels.hpp gemm_kloop_pipe; 0: the round-2 loop)
+    int kmat_nt = 0;       // Gram tiles written with nontemporal stores (global_store ... nt): the matrix is next read by the factorisation, tiles later
     bool gemm_pad_set = false;
     bool gemm_pad_user = false;  // "gemm_pad_lds" was set explicitly (otherwise: 0 for fp64, 20480 for fp32)
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
@@ -266,3 +270,4 @@ int32_t multi_update(gp_post* old, const gp_points* x2, const gp_noise* noise2, 
                      double* logpdf_out);
 void multi_post_release(gp_post* post);
 int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v);  // 1 = not a multi parameter
+int32_t multi_get_param(gp_ctx* c, const char* name, int64_t* out);  // 1 = not a multi parameter

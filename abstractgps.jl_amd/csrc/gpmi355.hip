@@ -245,22 +245,28 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         // tail shares: never fewer workgroups than tail tiles; beyond that at least 16 k-steps per share
         long G2 = std::min(G, std::max(R, R * nk / 16));
         if (R == 0) G2 = 0;
-        hipLaunchKernelGGL((gemm_nt_sk_kernel<T>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
-                           (int)K, g, ntiles, (int)G2);
+        if (c->gemm_pipe)
+            hipLaunchKernelGGL((gemm_nt_sk_kernel<T, 1>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                               (int)K, g, ntiles, (int)G2);
+        else
+            hipLaunchKernelGGL((gemm_nt_sk_kernel<T, 0>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
+                               (int)K, g, ntiles, (int)G2);
     } else {
         // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
         // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
         // request of 20 KiB on top of the 64 KiB static image pins that.  "gemm_pad_lds" overrides both.
-        const long pad = c->gemm_pad_user ? c->gemm_pad_lds : (sizeof(T) == 4 ? 20480 : 0);
+        const long pad = c->gemm_pad_user ? c->gemm_pad_lds : (sizeof(T) == 4 ? c->gemm_pad_f32 : 0);
         if (pad > 0 && !c->gemm_pad_set) {
-            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
-            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+            HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<float, float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
             c->gemm_pad_set = true;
         }
-        hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT>), grid, dim3(256), (size_t)pad, s, C, ldc, A, lda, B, ldb,
-                           (int)M, (int)N, (int)K, g);
+        if (c->gemm_pipe)
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT, 1>), grid, dim3(256), (size_t)pad, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, g);
+        else
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<T, CT, 0>), grid, dim3(256), (size_t)pad, s, C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, g);
     }
     HIPCHK(hipGetLastError());
     if (timed) {
@@ -286,6 +292,7 @@ GridMap gpmi::plain_map(int lower, long row0, long col0) {
     g.nbatch = 1;
     g.cstride = 0;
     g.ktri_off = 0;
+    g.nt = 0;
     return g;
 }
 
@@ -645,6 +652,7 @@ static void scale_points(const gp_kernel* k, const gp_points* x, long ldx, std::
 template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k, const T* xs_dev, long ldx, int d,
                                                   const T* noise_dev, long n, long np, T* A, long ld) {
     GridMap g = plain_map(1, 0, 0);
+    g.nt = c->kmat_nt;
     dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
     hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, A, ld, xs_dev, ldx, xs_dev, ldx, d, k->kind,
                        (T)k->variance, noise_dev, n, n, 1, g, (const T*)nullptr, (const T*)nullptr);
@@ -1442,6 +1450,9 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "gemm_streamk")) c->gemm_streamk = v != 0;
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
     else if (!strcmp(name, "sk_min_k")) c->sk_min_k = v;
+    else if (!strcmp(name, "gemm_pipe")) c->gemm_pipe = v != 0;
+    else if (!strcmp(name, "kmat_nt")) c->kmat_nt = v != 0;
+    else if (!strcmp(name, "gemm_pad_f32")) c->gemm_pad_f32 = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "gemm_pad_lds")) {
         c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
         c->gemm_pad_user = true;
@@ -1468,6 +1479,29 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
              !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_dist_predict") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk") || !strcmp(name, "multi_leaf_cols")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");
     else return set_arg_err(2, "unknown parameter");
     return 0;
+}
+
+int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (!name) return set_arg_err(2, "name is NULL");
+    if (!out) return set_arg_err(3, "out is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    if (c->multi && multi_get_param(c, name, out) == 0) return 0;
+    const struct { const char* n; int64_t v; } tab[] = {
+        {"nb", c->nb}, {"lookahead", c->lookahead}, {"lookahead_min_n", c->lookahead_min_n}, {"time_kernels", c->time_kernels},
+        {"xcd_swizzle", c->xcd_swizzle}, {"xcd_min_tiles", c->xcd_min_tiles}, {"gemm_streamk", c->gemm_streamk},
+        {"sk_max_tiles", c->sk_max_tiles}, {"sk_min_k", c->sk_min_k}, {"gemm_pipe", c->gemm_pipe}, {"gemm_pad_f32", c->gemm_pad_f32},
+        {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb}, {"deterministic", c->deterministic},
+        {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
+        {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
+        {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
+        {"kmat_nt", c->kmat_nt}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
+    for (const auto& e : tab)
+        if (!strcmp(name, e.n)) {
+            *out = e.v;
+            return 0;
+        }
+    return set_arg_err(2, "unknown parameter");
 }
 
 int32_t gp_ctx_trim(gp_ctx* c) {
@@ -2253,6 +2287,9 @@ int32_t gpd_potrf(gp_ctx* c, double* a, int64_t lda, int64_t m, int64_t n, int32
                   int64_t n_valid, double* logdet_dev) {
     if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
     if (n % 64 || m % 64 || m < n) return set_arg_err(4, "m, n must be multiples of 64 with m >= n");
+    // the register-resident leaf and the in-panel update kernel move rows as 16-byte pieces (leaf.hpp ld4 / st4)
+    if (((uintptr_t)a & 15) != 0) return set_arg_err(2, "a must be 16-byte aligned");
+    if (lda % 2 != 0 || lda < n) return set_arg_err(3, "lda must be even and >= n");
     std::lock_guard<std::mutex> l(c->mu);
     HIPCHK(hipSetDevice(c->device));
     return potrf_rec<double>(c, c->sm, a, lda, 0, n, m, info_dev, col0, n_valid, logdet_dev);

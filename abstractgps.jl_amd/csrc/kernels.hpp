@@ -89,7 +89,74 @@ __device__ __forceinline__ long glob_idx(long loc, long nb, int P, int p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename T, typename CT = T>
+// The k loop of both MFMA GEMM kernels, software-pipelined across the step boundary (round 5; PIPE = 1).
+//   The round-2 loop (PIPE = 0, kept for A/B measurements: ctx parameter "gemm_pipe") issues, after the barrier that ends step s, the
+//   8 operand DMAs of step s+2 (≈ 60 scalar / address instructions), then the first 8 ds_read_b128 of step s+1, and only then its
+//   first MFMA: with one wave per SIMD (fp32) the matrix pipe idles for the DMA issue + the LDS latency of four waves reading 32 KB at
+//   once — ≈ 400–500 of a step's 4 096 MFMA cycles; with two workgroups per CU (fp64) whenever both sit at that point.
+//   Here a step is two halves of 16·VEC MFMAs whose fragments are ALREADY in registers when the half begins:
+//       half 0 (fragments h = 0 of buffer cur, read during the previous half)   ‖ ds_read of the h = 1 fragments of cur
+//       s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      — buffer cur^1 (step s+1) is complete, nobody reads cur any more
+//       half 1 (fragments h = 1)   ‖ the 8 DMAs of step s+2 into cur, one per group of MFMAs ‖ ds_read of the h = 0 fragments of cur^1
+//   so that the only thing the matrix pipe ever waits for is the barrier itself.  Two LDS buffers as before; the DMA of step s+2 has a
+//   whole step to land.  Register cost: none (a[2][4], b[2][4] were live across the step before; now a0/b0 and a1/b1 alternate).
+//   dma_one(j, buf, kt): operand DMA j (0–3: A rows 8·(4j+w).., 4–7: B) of k-step kt into buffer buf.
+template <typename T, typename DmaOne>
+__device__ __forceinline__ void gemm_kloop_pipe(typename Tr<T>::acc_t (&acc)[4][4], const typename Tr<T>::chunk_t (*As)[128 * 8],
+                                                const typename Tr<T>::chunk_t (*Bs)[128 * 8], int fa, int fb, int lg, int sw, int k0,
+                                                int k1, DmaOne dma_one) {
+    using TR = Tr<T>;
+    using chunk_t = typename TR::chunk_t;
+    constexpr int VEC = TR::VEC;
+    const int sl0 = lg ^ sw, sl1 = (4 + lg) ^ sw;
+    chunk_t a0[4], b0[4], a1[4], b1[4];
+    {
+        const int kn = (k0 + 1 < k1) ? k0 + 1 : k0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma_one(j, 1, kn);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        a0[t] = As[0][fa + t * 128 + sl0];
+        b0[t] = Bs[0][fb + t * 128 + sl0];
+    }
+    auto mfma_group = [&](const chunk_t (&a)[4], const chunk_t (&b)[4], int g) {  // MFMAs [g·2·VEC, (g+1)·2·VEC) of a half, order (v, mt, nt)
+#pragma unroll
+        for (int j = 0; j < 2 * VEC; ++j) {
+            const int idx = g * 2 * VEC + j, v = idx >> 4, mt = (idx >> 2) & 3, nt = idx & 3;
+            acc[mt][nt] = TR::mfma(a[mt][v], b[nt][v], acc[mt][nt]);
+        }
+    };
+    for (int kt = k0; kt < k1; ++kt) {
+        const int cur = (kt - k0) & 1;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < 4) {
+                a1[g] = As[cur][fa + g * 128 + sl1];
+                b1[g] = Bs[cur][fb + g * 128 + sl1];
+            }
+            mfma_group(a0, b0, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int kn = (kt + 2 < k1) ? kt + 2 : k1 - 1;  // past the end: a harmless re-fetch of the last step (keeps the loop branch-free)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            dma_one(g, cur, kn);
+            if (g < 4) {
+                a0[g] = As[cur ^ 1][fa + g * 128 + sl0];
+                b0[g] = Bs[cur ^ 1][fb + g * 128 + sl0];
+            }
+            mfma_group(a1, b1, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing this workgroup's LDS when it is handed on
+}
+
+template <typename T, typename CT = T, int PIPE = 1>
 __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, const T* A, long lda, const T* B, long ldb, int M,
                                                               int N, int K, GridMap g) {
     using TR = Tr<T>;
@@ -192,6 +259,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     if (g.ktri == 1) nk = min(nk, (g.ktri_off + m0 + 128) / BK);
     dma_wait_barrier();
 
+    if constexpr (PIPE) {
+        gemm_kloop_pipe<T>(acc, As, Bs, fa, fb, lg, sw, kt0, nk, [&](int j, int buf, long kt) {
+            const int i = j & 3;
+            if (j < 4) dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+            else dma1(Bg[i] + kt * BK, ldsB + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+        });
+    } else
     for (int kt = kt0; kt < nk; ++kt) {
         const int cur = (kt - kt0) & 1;
 #if GPMI_ABL & 16  // ablation (fp32 only): no operand DMA inside the loop
@@ -262,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
 //   its R·nk k-steps are dealt out evenly to G2 workgroups, each accumulating its share of one (or two) tiles from zero
 //   and adding it to C with hardware fp64/fp32 atomics.  Tiles of complete rounds never see atomics.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int PIPE = 1>
 __global__ __launch_bounds__(256, 2) void gemm_nt_sk_kernel(T* C, long ldc, const T* A, long lda, const T* B, long ldb, int M, int N,
                                                              int K, GridMap g, long ntiles, int G2) {
     using TR = Tr<T>;
@@ -371,6 +445,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sk_kernel(T* C, long ldc, cons
                     for (int r = 0; r < 4; ++r) acc[mt][nt][r] = T(0);
         }
         dma_wait_barrier();
+        if constexpr (PIPE) {
+            gemm_kloop_pipe<T>(acc, As, Bs, fa, fb, lg, sw, k0, k1, [&](int j, int buf, long kt) {
+                const int i = j & 3;
+                if (j < 4) dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+                else dma1(Bg[i] + kt * BK, ldsB + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
+            });
+        } else
         for (int kt = k0; kt < k1; ++kt) {
             const int cur = (kt - k0) & 1;
             dma(cur ^ 1, (kt + 1 < k1) ? kt + 1 : kt);
@@ -490,7 +571,9 @@ __device__ __forceinline__ void kmat_body(T (*xi)[128], T (*xj)[128], T* __restr
             pair_t o;
             o.x = variance * kappa<T>(KIND, acc0[rr]);
             o.y = variance * kappa<T>(KIND, acc1[rr]);
-            *reinterpret_cast<pair_t*>(out + (long)(m0 + w + 4 * rr) * ld + n0 + 2 * lane) = o;
+            pair_t* const dst = reinterpret_cast<pair_t*>(out + (long)(m0 + w + 4 * rr) * ld + n0 + 2 * lane);
+            if (g.nt) __builtin_nontemporal_store(o, dst);
+            else *dst = o;
         }
         return;
     }

@@ -1415,6 +1415,28 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
     return 1;
 }
 
+// read-back of the multi-device parameters (gp_ctx_get_param on a multi-device ctx); 1 = not a multi parameter
+int32_t multi_get_param(gp_ctx* c, const char* name, int64_t* out) {
+    gp_multi* m = c->multi;
+    if (!m) return 1;
+    int64_t rk_sk = 0, rk_lc = 0;
+    if (!m->ranks.empty() && m->ranks[0].c) {
+        rk_sk = m->ranks[0].c->gemm_streamk;
+        rk_lc = m->ranks[0].c->leaf_cols;
+    }
+    const struct { const char* n; int64_t v; } tab[] = {
+        {"lookahead_depth", m->depth}, {"copy_kernel", m->copy_kernel}, {"multi_debug_sync", m->debug_sync}, {"multi_check", m->check},
+        {"multi_dist_predict", m->dist_predict}, {"multi_inject_fault", m->inject_fault}, {"multi_verify", m->verify},
+        {"multi_window", (int64_t)m->window}, {"multi_timeout_s", (int64_t)m->timeout_s}, {"dist_nb", (int64_t)m->nb},
+        {"multi_gemm_streamk", rk_sk}, {"multi_leaf_cols", rk_lc}};
+    for (const auto& e : tab)
+        if (!strcmp(name, e.n)) {
+            *out = e.v;
+            return 0;
+        }
+    return 1;
+}
+
 // drop the cached device blocks of the rank contexts (gp_ctx_trim on a multi-device ctx)
 void multi_trim(gp_ctx* c) {
     gp_multi* m = c->multi;
@@ -2488,13 +2510,18 @@ int32_t multi_gather(gp_post* post) {
 extern "C" int32_t gp_rccl_selftest(int32_t device, int64_t count, double* max_abs_err_out) {
     if (count < 1) return set_err_text(-2, "count must be >= 1");
     MCHK(hipSetDevice(device));
-    std::lock_guard<std::mutex> l(g_rccl_mu);
-    if (!g_rccl.load()) return set_err_text(-1996, "RCCL is unavailable: " + g_rccl.err);
     ncclComm_t_ comm = nullptr;
     const int dev = device;
-    int nrc = g_rccl.CommInitAll(&comm, 1, &dev);
-    if (nrc != 0) return set_err_text(-1998, std::string("ncclCommInitAll(1): ") + g_rccl.GetErrorString(nrc));
-    ++g_rccl.live;
+    int nrc = 0;
+    {   // the global lock covers the loader, communicator creation and the live counter only: while `live` > 0 the loader refuses to switch
+        // libraries, so the entry points used below stay valid without it — a concurrent gp_ctx_create_multi / gp_ctx_destroy is not held
+        // up by this test's allocations, transfer and copies
+        std::lock_guard<std::mutex> l(g_rccl_mu);
+        if (!g_rccl.load()) return set_err_text(-1996, "RCCL is unavailable: " + g_rccl.err);
+        nrc = g_rccl.CommInitAll(&comm, 1, &dev);
+        if (nrc != 0) return set_err_text(-1998, std::string("ncclCommInitAll(1): ") + g_rccl.GetErrorString(nrc));
+        ++g_rccl.live;
+    }
     double *a = nullptr, *b = nullptr;
     hipStream_t st = nullptr;
     int32_t rc = [&]() -> int32_t {
@@ -2527,7 +2554,10 @@ extern "C" int32_t gp_rccl_selftest(int32_t device, int64_t count, double* max_a
     if (st) (void)hipStreamDestroy(st);
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
-    (void)g_rccl.CommDestroy(comm);
-    --g_rccl.live;
+    {
+        std::lock_guard<std::mutex> l(g_rccl_mu);
+        (void)g_rccl.CommDestroy(comm);
+        --g_rccl.live;
+    }
     return rc;
 }

@@ -1,5 +1,5 @@
 # HipGPs.jl — Julia host shim: keeps the AbstractGP / FiniteGP / PosteriorGP surface of AbstractGPs.jl
-# and routes the logpdf / posterior hot path through `ccall` into libgpmi355.so (include/gpmi355.h, ABI v3).
+# and routes the logpdf / posterior hot path through `ccall` into libgpmi355.so (include/gpmi355.h, ABI v4).
 #
 # NOT EXECUTED in the build container (Julia is not installed there — SURVEY.md §0 F3); it is the
 # reference-side binding a maintainer adds (INTEGRATION.md).  abstractgps.jl_amd/api.py is its ctypes
@@ -91,6 +91,11 @@ const _default_ctx = Ref{Union{Nothing,HipContext}}(nothing)
 default_context() = something(_default_ctx[], (_default_ctx[] = HipContext(0)))
 set_param!(c::HipContext, name::AbstractString, v::Integer) =
     check(ccall((:gp_ctx_set_param, libgpmi355), Int32, (Ptr{Cvoid}, Cstring, Int64), c.handle, name, v))
+function get_param(c::HipContext, name::AbstractString)
+    v = Ref{Int64}(0)
+    check(ccall((:gp_ctx_get_param, libgpmi355), Int32, (Ptr{Cvoid}, Cstring, Ref{Int64}), c.handle, name, v))
+    return v[]
+end
 trim!(c::HipContext) = check(ccall((:gp_ctx_trim, libgpmi355), Int32, (Ptr{Cvoid},), c.handle))
 # multi-device contexts: fit attempts, repetitions after a failed self-check, forward solves on the distributed factor
 function multi_stats(c::HipContext)
@@ -518,24 +523,44 @@ function approx_posterior(approx, prior, h::Base.RefValue{Ptr{Cvoid}}, ::Type{T}
     finalizer(hh -> ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), hh[]), h)
     return HipApproxPosteriorGP(approx, prior, h, T, Float64(obj), x, Σy)
 end
-# `post.data` — the cache NamedTuple of the reference (src/sparse_approximations.jl:73), read field by field by its tests
+# `post.data` — the cache of the reference (src/sparse_approximations.jl:73), read field by field by its tests
 # (test/sparse_approximations.jl:48-55, 76-83): m_ε, Λ_ε (a LinearAlgebra.Cholesky, so Λ_ε.U works), U, α, b_y from the device
 # (gp_vfe_get, gp_vfe_get_factors, gp_vfe_get_by), x and Σy from the host side.  B_εf (M×N) is never materialised and is not a field.
-function Base.getproperty(f::HipApproxPosteriorGP, s::Symbol)
-    s === :data || return getfield(f, s)
-    h, T = getfield(f, :handle), getfield(f, :T)
-    m = Int(ccall((:gp_vfe_m, libgpmi355), Int64, (Ptr{Cvoid},), h[]))
-    n = Int(ccall((:gp_vfe_n, libgpmi355), Int64, (Ptr{Cvoid},), h[]))
-    α = Vector{T}(undef, m); m_ε = Vector{T}(undef, m)
-    U = Matrix{T}(undef, m, m); ΛU = Matrix{T}(undef, m, m)
-    b_y = Vector{T}(undef, n)
-    GC.@preserve f α m_ε U ΛU b_y begin
-        check(ccall((:gp_vfe_get, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], α, m_ε))
-        check(ccall((:gp_vfe_get_factors, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], U, ΛU))
-        check(ccall((:gp_vfe_get_by, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), h[], b_y))
-    end
-    return (m_ε=m_ε, Λ_ε=Cholesky(ΛU, 'U', 0), U=UpperTriangular(U), α=α, b_y=b_y, x=getfield(f, :x), Σy=getfield(f, :Σy))
+# The view is LAZY: `post.data` costs nothing, `post.data.α` moves M numbers, `post.data.U` one M×M factor — a NamedTuple built on every
+# access would download both factors and the N-vector b_y each time (256 MB per `post.data.α` at M = 4 096, N = 262 144).
+struct HipVfeCache{Tf}
+    f::Tf
 end
+Base.propertynames(::HipVfeCache) = (:m_ε, :Λ_ε, :U, :α, :b_y, :x, :Σy)
+function Base.getproperty(c::HipVfeCache, s::Symbol)
+    f = getfield(c, :f)
+    h, T = getfield(f, :handle), getfield(f, :T)
+    s === :x && return getfield(f, :x)
+    s === :Σy && return getfield(f, :Σy)
+    m = Int(ccall((:gp_vfe_m, libgpmi355), Int64, (Ptr{Cvoid},), h[]))
+    if s === :α || s === :m_ε
+        v = Vector{T}(undef, m)
+        GC.@preserve f v begin
+            p = convert(Ptr{Cvoid}, pointer(v))
+            check(ccall((:gp_vfe_get, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], s === :α ? p : C_NULL, s === :m_ε ? p : C_NULL))
+        end
+        return v
+    elseif s === :U || s === :Λ_ε
+        A = Matrix{T}(undef, m, m)
+        GC.@preserve f A begin
+            p = convert(Ptr{Cvoid}, pointer(A))
+            check(ccall((:gp_vfe_get_factors, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], s === :U ? p : C_NULL, s === :Λ_ε ? p : C_NULL))
+        end
+        return s === :U ? UpperTriangular(A) : Cholesky(A, 'U', 0)
+    elseif s === :b_y
+        n = Int(ccall((:gp_vfe_n, libgpmi355), Int64, (Ptr{Cvoid},), h[]))
+        b_y = Vector{T}(undef, n)
+        GC.@preserve f b_y check(ccall((:gp_vfe_get_by, libgpmi355), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), h[], b_y))
+        return b_y
+    end
+    throw(ArgumentError("the VFE cache has no field $s (fields: $(propertynames(c)); B_εf is never materialised)"))
+end
+Base.getproperty(f::HipApproxPosteriorGP, s::Symbol) = s === :data ? HipVfeCache(f) : getfield(f, s)
 Base.propertynames(::HipApproxPosteriorGP) = (:approx, :prior, :data, :objective)
 
 # FiniteGP API of the two posterior types on the device

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GPMI355_ABI_VERSION 3
+#define GPMI355_ABI_VERSION 4
 
 typedef struct gp_ctx gp_ctx;   /* device + streams + workspace                          */
 typedef struct gp_post gp_post; /* PosteriorGP state: device-resident factor, alpha, x   */
@@ -151,7 +151,8 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    vector sweep still adds four partial products per column with atomics)
  *   "deterministic"  1: the exact path (gp_logpdf, gp_logpdf_terms, gp_posterior_fit and every method of its posterior) uses no
  *                    floating-point atomics — no stream-K tails whatever "gemm_streamk" says, one thread per column in the backward
- *                    sweep — so two calls with the same inputs on the same ctx return the same BITS (tests/test_gpu_api.py).  The VFE
+ *                    sweep — so two calls with the same inputs on the same ctx return the same BITS (tests/test_gpu_api.py; the leaf's one
+ *                    Σ log L_ii add per launch is issued by a single thread and the leaves of a fit are totally ordered, so its order is fixed).  The VFE
  *                    path, the gradient kernels and the multi-device backward sweep keep their atomics.  1-5 % slower at N <= 32 768.   default 0
  *   "leaf_v2", "leaf_xr"  fp64 leaves by the register-resident panel64v2_kernel (csrc/leaf.hpp) / rows of X per leaf workgroup (0 auto)   default 1, 0
  *   "leaf_cols"      columns per register-resident leaf launch (64 or 128; 128 = one workgroup chain per 128 columns)   default 128
@@ -164,6 +165,10 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one
  *                    large launch, 4-7 % slower over a whole factorisation; fp32: 5 % faster)   default 0 (fp64) / 20480 (fp32)
+ *   "gemm_pad_f32"   the fp32 default of "gemm_pad_lds" (0: two fp32 GEMM workgroups per CU)   default 20480
+ *   "gemm_pipe"      k loop of the MFMA GEMMs software-pipelined across the step boundary (csrc/kernels.hpp gemm_kloop_pipe: the fragments of
+ *                    the next half-step are in registers before the barrier, operand DMA issued between MFMAs); 0 = the round-2 loop   default 1
+ *   "kmat_nt"        Gram tiles written with nontemporal stores                             default 0
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32
  *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
@@ -177,7 +182,18 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "multi_debug_sync", "multi_inject_fault"  multi-device diagnostics: host synchronisation points of the rank threads (bit mask) /
  *                    hand the next fit's self-check a spoiled α once (tests/test_gpu_multi.py)      default 0, 0
  *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
+/* The defaults above, machine-readable (single-device parameters; gp_ctx_get_param reads the same names): the test-suite asserts before
+ * every GPU test that the shared default context still has exactly these values, so that no test can leave a non-production setting
+ * behind for the tests that follow it (tests/conftest.py). */
+#define GPMI355_PARAM_DEFAULTS                                                                                                   \
+    "nb=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
+    "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=20480,gemm_pad_lds=0,trsv_nb=256,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
+    "updk_max_k=512,updk_rt=0,updk_tall_k=256,updk_tall_m=8192,upd128=1,leaf_group=128,ldpad=32,vfe_ks=2048,vfe_sk=0,"          \
+    "vfe_overlap=1,vfe_chunk=16384,kmat_nt=0,pool_cap_mb=98304"
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
+/* Read a parameter back (same names; "gemm_pad_lds" reads 0 until it has been set explicitly).  Used by the test-suite to assert that
+ * every GPU test starts from the documented defaults. */
+int32_t gp_ctx_get_param(gp_ctx* ctx, const char* name, int64_t* value_out);
 /* Return every cached (free) device block of the ctx to the HIP allocator — e.g. after freeing an N = 65 536 posterior
  * (34 GB) when another allocator in the process needs the memory. */
 int32_t gp_ctx_trim(gp_ctx* ctx);
@@ -313,7 +329,7 @@ int32_t gp_vfe_free(gp_vfe* post);
  * device-resident data.  All pointers below are DEVICE pointers (fp64), row-major with the given leading dimension, i.e.
  * a row-major lower factor L — memory-identical to Julia's column-major C.U.  Work is issued on the
  * ctx main stream and NOT synchronised (gpd_sync, or order it against your own stream work).
- * m, n multiples of 128; k multiple of 16 (gemm) / 64 (trsm, potrf). */
+ * m, n multiples of 64 (gpd_trsv: np multiple of 128); k multiple of 16 (gemm). */
 
 /* Fill local tiles of K + Σy.  rows: global indices row0 + i (i < m) mapped through the block-cyclic
  * map (global tile-row of local 128-tile t is ((t / tb) * P + p) * tb + t % tb); same for columns with
@@ -330,7 +346,8 @@ int32_t gpd_assemble(gp_ctx* ctx, const gp_kernel* k, const double* x_dev, int64
                      int64_t m_loc, int64_t n_loc);
 /* In-place lower Cholesky of the n×n diagonal block at a (rows/cols [0,n)), and of the m-n rows
  * below it (X ← X L⁻ᵀ) when m > n.  info_dev: device int32, set to (col0 + failing column, 1-based)
- * on the first non-positive pivot.  logdet_dev += Σ log L_ii over columns col0+i < n_valid. */
+ * on the first non-positive pivot.  logdet_dev += Σ log L_ii over columns col0+i < n_valid.
+ * m, n multiples of 64; `a` 16-byte aligned and lda even (the leaf kernels move rows as 16-byte pieces): anything else is refused (−2 / −3). */
 int32_t gpd_potrf(gp_ctx* ctx, double* a, int64_t lda, int64_t m, int64_t n, int32_t* info_dev, int32_t col0,
                   int64_t n_valid, double* logdet_dev);
 /* X (m×n) ← X · L⁻ᵀ with L the n×n lower factor (row-major, ldl). */

@@ -63,3 +63,53 @@ def agp():
 @pytest.fixture(scope="session")
 def ctx(agp):
     return agp.default_context(0)
+
+
+def documented_defaults() -> dict:
+    """GPMI355_PARAM_DEFAULTS of include/gpmi355.h: name -> documented default of every single-device ctx parameter."""
+    import re
+
+    txt = (ROOT / "include" / "gpmi355.h").read_text()
+    m = re.search(r"#define GPMI355_PARAM_DEFAULTS(.*?)\nint32_t gp_ctx_set_param", txt, flags=re.S)
+    assert m, "GPMI355_PARAM_DEFAULTS not found in include/gpmi355.h"
+    body = "".join(re.findall(r'"([^"]*)"', m.group(1)))
+    return {kv.split("=")[0]: int(kv.split("=")[1]) for kv in body.split(",") if kv}
+
+
+@pytest.fixture(autouse=True)
+def _default_context_has_production_defaults(request):
+    """Before every GPU test: every tunable of the SHARED default context reads back its documented default (include/gpmi355.h).  Round 4
+    ran half of the suite with `gemm_streamk = 0` because one test's clean-up left it so; a test that needs another setting uses its own
+    Context or restores what it changed — and this fixture fails the NEXT test loudly if it does not."""
+    if "gpu" not in request.keywords or not _have_gpu():
+        yield
+        return
+    import abstractgps_jl_amd as m
+
+    c = m.default_context(0)
+
+    def drift():
+        return {k: (c.get_param(k), v) for k, v in documented_defaults().items() if c.get_param(k) != v}
+
+    bad = drift()
+    assert not bad, f"default context left with non-default parameters by an earlier test (name: (value, documented default)): {bad}"
+    yield
+    bad = drift()
+    assert not bad, f"{request.node.name} left non-default parameters on the shared default context: {bad}"
+
+
+@pytest.fixture
+def exact_mode(request, agp):
+    """Parametrised 'default' / 'no_atomics': the second runs the test with gemm_streamk = 0 and deterministic = 1 on the default context
+    (hardware-dispatched GEMMs only, no floating-point atomics anywhere in the exact path) and restores the defaults afterwards — the
+    non-default path covered on purpose, not by a leaked setting."""
+    mode = getattr(request, "param", "default")
+    c = agp.default_context(0)
+    if mode == "no_atomics":
+        c.set_param("gemm_streamk", 0)
+        c.set_param("deterministic", 1)
+    try:
+        yield mode
+    finally:
+        c.set_param("gemm_streamk", 1)
+        c.set_param("deterministic", 0)

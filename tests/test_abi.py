@@ -13,7 +13,7 @@ def test_exports_every_declared_symbol(agp):
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert set(declared) == set(agp._lib.PROTOTYPES), set(declared) ^ set(agp._lib.PROTOTYPES)
-    assert lib.gp_abi_version() == 3
+    assert lib.gp_abi_version() == 4
 
 
 def test_dead_handles_are_rejected_not_ub(agp):
@@ -79,3 +79,25 @@ def test_every_ctx_parameter_the_library_accepts_is_documented_in_the_header():
     hdr = (root / "include" / "gpmi355.h").read_text()
     missing = sorted(n for n in names if f'"{n}"' not in hdr)
     assert not missing, f"ctx parameters without a line in include/gpmi355.h: {missing}"
+
+
+def test_param_defaults_macro_covers_every_single_device_parameter():
+    """GPMI355_PARAM_DEFAULTS (include/gpmi355.h) — what tests/conftest.py asserts on the default context before every GPU test — names every
+    parameter gp_ctx_set_param accepts on a single-device ctx, and nothing else; a parameter added to the source without a documented,
+    machine-readable default fails here (CPU) instead of escaping the fixture."""
+    import re
+    from pathlib import Path
+
+    from tests.conftest import documented_defaults
+
+    root = Path(__file__).resolve().parent.parent
+    src = (root / "abstractgps.jl_amd" / "csrc" / "gpmi355.hip").read_text()
+    body = src[src.index("int32_t gp_ctx_set_param("):src.index("int32_t gp_ctx_get_param(")]
+    accepted = set(re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', body))
+    multi_only = set(re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', body[body.index('!strcmp(name, "lookahead_depth")'):]))  # the branch that refuses them on a single-device ctx
+    single = accepted - multi_only
+    dflt = documented_defaults()
+    assert set(dflt) == single, (sorted(single - set(dflt)), sorted(set(dflt) - single))
+    getter = src[src.index("int32_t gp_ctx_get_param("):src.index("int32_t gp_ctx_trim(")]
+    readable = set(re.findall(r'\{"([a-z0-9_]+)",', getter))
+    assert readable == single, (sorted(single - readable), sorted(readable - single))

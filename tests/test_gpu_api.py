@@ -478,17 +478,22 @@ def test_gradient_for_inputs_of_any_dimension(agp, d, ard):
 
 
 def test_deterministic_mode_is_bitwise_repeatable(agp):
-    """ctx parameter "deterministic" = 1: no floating-point atomics in the exact path (no stream-K tails, one thread per column in the
-    backward sweep) — two fits on the same inputs return the same BITS (logpdf, α, the whole factor, predictive mean / variance), with
-    the look-ahead on (several panels) and without; and the result still meets the oracle tolerances."""
+    """ctx parameter "deterministic" = 1: no floating-point atomics with a scheduling-dependent order in the exact path (no stream-K tails, one
+    thread per column in the backward sweep; the one `atomicAdd` left is the leaf's Σ log L_ii, executed by ONE thread per leaf launch, and the
+    leaves of a fit are totally ordered by stream order / events, so the order of those additions is fixed) — two fits on the same inputs return
+    the same BITS (logpdf, α, the whole factor, predictive mean / variance).  Three schedules: one stream with two and with one outer panel
+    (N = 3 000 is below "lookahead_min_n", so these never use the panel stream), and the two-stream look-ahead FORCED on (lookahead_min_n = 0,
+    512-column panels: five panels on the panel stream beside the trailing updates); the result still meets the oracle tolerances."""
     n, d = 3000, 3
     x, y = o.synth_inputs(n, d, 77)
     ref_lp, ref_post = o.logpdf_and_posterior(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y)
     ctx = agp.Context(0)
     ctx.set_param("deterministic", 1)
     try:
-        for nb in (1024, 2048):
+        for nb, la_min in ((1024, 24576), (2048, 24576), (512, 0)):
             ctx.set_param("nb", nb)
+            ctx.set_param("lookahead", 1)
+            ctx.set_param("lookahead_min_n", la_min)
             f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
             runs = []
             for _ in range(3):

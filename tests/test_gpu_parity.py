@@ -117,21 +117,23 @@ def test_mid_size_parity(agp, n, d, kind, layout):
 
 
 def test_variants_agree(agp):
-    """Panel widths, look-ahead on/off, recursive-only, XCD-aware workgroup order, stream-K tails: same answer."""
+    """Panel widths, look-ahead on/off, recursive-only, XCD-aware workgroup order, stream-K tails on / off, the round-2 GEMM k loop: same answer."""
     x, y = o.synth_inputs(3000, 3, 9)
     f = agp.GP(agp.SqExponentialKernel())
     ctx = agp.default_context()
     vals = []
 
-    def reset():  # (stream-K tails stay off for the tests that follow in this process: hardware-dispatched GEMMs, no atomics in the update)
+    def reset():  # back to the documented defaults (include/gpmi355.h); tests/conftest.py asserts it before and after every GPU test
         ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("xcd_swizzle", 0)
-        ctx.set_param("xcd_min_tiles", 256), ctx.set_param("gemm_streamk", 0), ctx.set_param("leaf_group", 128)
+        ctx.set_param("xcd_min_tiles", 256), ctx.set_param("gemm_streamk", 1), ctx.set_param("leaf_group", 128)
+        ctx.set_param("gemm_pipe", 1)
 
     try:
-        for nb, la, extra in [(2048, 1, {"gemm_streamk": 1}), (1024, 0, {}), (0, 0, {}), (1024, 1, {"gemm_streamk": 1}), (512, 0, {}),
-                              (512, 1, {"xcd_swizzle": 1, "xcd_min_tiles": 4}),
-                              (512, 0, {"xcd_swizzle": 1, "xcd_min_tiles": 4, "gemm_streamk": 1}), (0, 0, {"gemm_streamk": 1}),
-                              (1024, 1, {"leaf_group": 64}), (1024, 1, {"leaf_group": 256, "gemm_streamk": 1})]:
+        for nb, la, extra in [(2048, 1, {}), (1024, 0, {"gemm_streamk": 0}), (0, 0, {"gemm_streamk": 0}), (1024, 1, {}), (512, 0, {"gemm_streamk": 0}),
+                              (512, 1, {"xcd_swizzle": 1, "xcd_min_tiles": 4, "gemm_streamk": 0}),
+                              (512, 0, {"xcd_swizzle": 1, "xcd_min_tiles": 4}), (0, 0, {}),
+                              (1024, 1, {"leaf_group": 64, "gemm_streamk": 0}), (1024, 1, {"leaf_group": 256}),
+                              (1024, 0, {"gemm_pipe": 0}), (512, 1, {"gemm_pipe": 0, "gemm_streamk": 0})]:
             ctx.set_param("nb", nb), ctx.set_param("lookahead", la)
             for kname, kval in extra.items():
                 ctx.set_param(kname, kval)
@@ -287,10 +289,12 @@ def test_logpdf_grad_vs_oracle(agp, kind, okind):
         np.testing.assert_allclose(g["y"], go["y"], rtol=0, atol=1e-8 * np.abs(go["y"]).max())
 
 
+@pytest.mark.parametrize("exact_mode", ["default", "no_atomics"], indirect=True)
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 1025])
-def test_tile_boundary_sizes(agp, n):
+def test_tile_boundary_sizes(agp, n, exact_mode):
     """ragged sizes around every tile boundary (64-wide leaves, 128-wide tiles, identity padding), custom mean function,
-    matrix-valued Y, cross-covariance of the posterior."""
+    matrix-valued Y, cross-covariance of the posterior — in the production configuration (stream-K GEMM tails with fp64 atomics: what
+    every launch of these sizes takes) and, on purpose, without any floating-point atomics (gemm_streamk = 0, deterministic = 1)."""
     rng = np.random.default_rng(n)
     X = rng.standard_normal((n, 2))
     Y = rng.standard_normal((n, 3))

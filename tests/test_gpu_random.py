@@ -51,4 +51,13 @@ def _case(agp, rng):
 
 @pytest.mark.parametrize("seed", range(NCASES))
 def test_random_configuration(agp, seed):
+    """production configuration of the default context (tests/conftest.py asserts that it IS the documented default): stream-K GEMM tails
+    with fp64 atomics, atomics in the backward sweep"""
+    _case(agp, np.random.default_rng(1000 + seed))
+
+
+@pytest.mark.parametrize("exact_mode", ["no_atomics"], indirect=True)
+@pytest.mark.parametrize("seed", range(0, NCASES, 3))
+def test_random_configuration_without_atomics(agp, seed, exact_mode):
+    """the same cases with gemm_streamk = 0 and deterministic = 1: hardware-dispatched GEMMs, no floating-point atomics in the exact path"""
     _case(agp, np.random.default_rng(1000 + seed))

@@ -144,8 +144,12 @@ def test_shim_data_property_mirrors_the_reference_cache_fields():
     """src/sparse_approximations.jl:73: cache = (m_ε, Λ_ε, U, α, b_y, B_εf, x, Σy); test/sparse_approximations.jl:48-55 reads
     m_ε, Λ_ε.U, U, α, b_y.  B_εf (M×N) is deliberately not materialised."""
     src = SHIM.read_text()
-    m = re.search(r"return \(m_ε=.*?\)\n", src)
-    assert m, "HipApproxPosteriorGP.data NamedTuple not found"
-    for field in ("m_ε=", "Λ_ε=Cholesky(", "U=", "α=", "b_y=", "x=", "Σy="):
-        assert field in m.group(0), field
+    m = re.search(r"Base\.propertynames\(::HipVfeCache\) = \((.*?)\)\n", src)
+    assert m, "the lazy cache view HipVfeCache is not there"
+    assert [f.strip() for f in m.group(1).split(",")] == [":m_ε", ":Λ_ε", ":U", ":α", ":b_y", ":x", ":Σy"]
+    body = src[src.index("function Base.getproperty(c::HipVfeCache"):src.index("Base.getproperty(f::HipApproxPosteriorGP")]
+    for field in (":α", ":m_ε", ":U", ":Λ_ε", ":b_y", ":x", ":Σy"):  # every advertised field is served, each by the call that owns it
+        assert f"s === {field}" in body, field
+    assert "Cholesky(A, 'U', 0)" in body and "UpperTriangular(A)" in body
+    assert "s === :data ? HipVfeCache(f)" in src  # `post.data` itself moves nothing
     assert "LinearAlgebra.logdet(C::DeviceCholesky)" in src
