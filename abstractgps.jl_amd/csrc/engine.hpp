@@ -28,6 +28,7 @@ struct GridMap {
     int tm;          // number of tile rows (modes 2, 3)
     int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
     int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
+                     // 3: B is lower triangular (N×N, K = N): the k loop of COLUMN tile n0 stops at column n0 + 128 (column tiles rotated by the row tile)
                      // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
     int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
     long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
@@ -96,6 +97,8 @@ struct gp_ctx {
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
     long gemm_pad_f32 = 20480; // the fp32 default of the above (0: two workgroups per CU)
     int gemm_pipe = 1;     // k loop of the MFMA GEMMs software-pipelined across the step boundary (kernels.hpp gemm_kloop_pipe; 0: the round-2 loop)
+    long dib_nb = 2048;    // forward solves X L⁻ᵀ against a RESIDENT factor (predictions, covariances, sequential updates, the gradient's L⁻ᵀ): sub-blocks of at
+                           // most this many columns are solved by ONE triangular-k GEMM with the explicit inverse of the diagonal block (0: the recursion down to 64)
     int kmat_nt = 0;       // Gram tiles written with nontemporal stores (global_store ... nt): the matrix is next read by the factorisation, tiles later
     bool gemm_pad_set = false;
     bool gemm_pad_user = false;  // "gemm_pad_lds" was set explicitly (otherwise: 0 for fp64, 20480 for fp32)
@@ -220,6 +223,9 @@ struct gp_post {
     void* alpha;
     size_t alpha_bytes;  // [np]
     double logdet_half;  // Σ log L_ii
+    void* dib = nullptr;      // −inv(L_bb) of the factor's diagonal blocks (lower, row-major [np + 128][dib_ldw]; rows of block (j0, n) at j0), built on the
+    size_t dib_bytes = 0;     // first forward solve against the resident factor and kept with it ("dib_nb"; gpmi355.hip dib_build)
+    long dib_nbi = 0, dib_ldw = 0;
     gp_multi_post* pieces = nullptr;  // multi-device fit: the factor still lives as block-cyclic pieces (A == nullptr until gathered)
 };
 

@@ -202,7 +202,8 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
         if (g.nbatch > 1) elems *= g.nbatch;
         rec.flops = g.ktri == 1 ? (double)N * (double)M * (double)(2 * g.ktri_off + M + 128)
-                                : (g.ktri == 2 ? (double)M * (double)M * (double)M / 3.0 : 2.0 * (double)K * elems);
+                                : (g.ktri == 2 ? (double)M * (double)M * (double)M / 3.0
+                                               : (g.ktri == 3 ? (double)M * (double)N * (double)(N + 128) : 2.0 * (double)K * elems));
         rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
         rec.M = M; rec.N = N; rec.K = K;
         rec.stream = (s == c->sp);
@@ -399,34 +400,131 @@ static int32_t launch_trsm64(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, c
     return 0;
 }
 
-// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n, M multiples of 64): left half; X_right −= X_left · L_21ᵀ (MFMA GEMM);
-// right half; 64-wide leaves by trsm64_mfma.
+// Inverse diagonal blocks ("DIB") of a resident factor.  A forward solve X ← X L⁻ᵀ by recursion ends in N/64 latency-bound leaf launches
+// and as many few-tile GEMMs (C4, 4 096 test points: 2 047 launches; the levels below 2 048 columns hold 3 % of the flops and a third of
+// the time).  With W_b = −inv(L_bb) of every diagonal block (j0, n <= nbi) at hand, the leaf of the recursion at that size is ONE
+// triangular-k MFMA GEMM  S = −X_b W_bᵀ = X_b L_bb⁻ᵀ  (B operand lower triangular: GridMap::ktri = 3) into a scratch panel that is copied
+// back; everything above it stays the recursion's large-K GEMMs.  The blocks are the leaves the recursion itself reaches (dib_ranges).
+template <typename T> struct DibArgs {
+    const T* W = nullptr;  // −inv(L_bb), rows shifted along with L (block (j0, n): rows [j0, j0 + n), columns [0, n))
+    long ldw = 0, nbi = 0;
+    T* S = nullptr;        // scratch panel, at least (rows + 128) × lds
+    long lds = 0;
+};
+static void dib_ranges(long j0, long n, long nbi, std::vector<std::pair<long, long>>& out) {
+    if (n <= nbi) {
+        out.push_back({j0, n});
+        return;
+    }
+    const long h = split_half(n);
+    dib_ranges(j0, h, nbi, out);
+    dib_ranges(j0 + h, n - h, nbi, out);
+}
+// S = −X W_bᵀ (M × n), then X ← S
 template <typename T>
-static int32_t trsm_rec_v(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
+static int32_t dib_apply(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, long n, const DibArgs<T>& dib) {
+    if (M <= 0) return 0;
+    GridMap g = plain_map(0, 0, 0);
+    g.beta0 = 1;
+    g.ktri = 3;
+    RC(launch_gemm<T>(c, s, dib.S, dib.lds, X, ldx, dib.W, dib.ldw, M, n, n, g));
+    HIPCHK(hipMemcpy2DAsync(X, sizeof(T) * ldx, dib.S, sizeof(T) * dib.lds, sizeof(T) * n, M, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// X[M×n] ← X · L⁻ᵀ with L the n×n row-major lower factor (n, M multiples of 64): left half; X_right −= X_left · L_21ᵀ (MFMA GEMM);
+// right half; leaves: the explicit inverse block (dib, n <= nbi) or 64-wide trsm64_mfma.
+template <typename T>
+static int32_t trsm_rec_v(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n, DibArgs<T> dib = DibArgs<T>()) {
+    if (dib.W && n <= dib.nbi) return dib_apply<T>(c, s, X, ldx, M, n, dib);
     if (n <= 64) return launch_trsm64<T>(c, s, X, ldx, M, L, ldl);
     const long h = split_half(n);
-    RC(trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, h));
+    RC(trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, h, dib));
     RC(launch_gemm<T>(c, s, X + h, ldx, X, ldx, L + h * ldl, ldl, M, n - h, h, plain_map(0, 0, 0)));
-    RC(trsm_rec_v<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h));
+    if (dib.W) dib.W += h * dib.ldw;
+    RC(trsm_rec_v<T>(c, s, X + h, ldx, M, L + h * ldl + h, ldl, n - h, dib));
     return 0;
 }
 // W ← W L⁻ᵀ for W that is upper triangular on entry AND exit (W = I gives L⁻ᵀ): columns [j0, j0+n) only ever have
 // non-zeros in rows [0, j0+n), so every step is restricted to those rows — N³/3 flops instead of the N³ of the general
-// solve.  Same recursion as trsm_rec_v.
+// solve.  Same recursion as trsm_rec_v.  With dib (W indexed by GLOBAL row here): the diagonal blocks of X already hold L_bb⁻ᵀ (written
+// by dib_build), a leaf only multiplies the rows above its block.
 template <typename T>
-static int32_t trsm_upper_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, const T* L, long ldl, long j0, long n) {
+static int32_t trsm_upper_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, const T* L, long ldl, long j0, long n, DibArgs<T> dib = DibArgs<T>()) {
+    if (dib.W && n <= dib.nbi) {
+        DibArgs<T> d2 = dib;
+        d2.W = dib.W + j0 * dib.ldw;
+        return dib_apply<T>(c, s, X + j0, ldx, j0, n, d2);
+    }
     if (n <= 64) return launch_trsm64<T>(c, s, X + j0, ldx, j0 + 64, L + j0 * ldl + j0, ldl);
     const long h = split_half(n);
-    RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0, h));
+    RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0, h, dib));
     RC(launch_gemm<T>(c, s, X + j0 + h, ldx, X + j0, ldx, L + (j0 + h) * ldl + j0, ldl, j0 + h, n - h, h, plain_map(0, 0, 0)));
-    RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0 + h, n - h));
+    RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0 + h, n - h, dib));
     return 0;
 }
 
 template <typename T>
-static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n) {
+static int32_t trsm_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* L, long ldl, long n, DibArgs<T> dib = DibArgs<T>()) {
     if (M <= 0) return 0;
-    return trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, n);
+    return trsm_rec_v<T>(c, s, X, ldx, M, L, ldl, n, dib);
+}
+
+// W (rows [0, np + 128) × ldw, zero on entry is NOT required) ← −inv(L_bb) for every block of dib_ranges(0, np, nbi); Iw: scratch of the same
+// shape.  Per block: Iw_b = I, Iw_b ← Iw_b L_bb⁻ᵀ (upper; the restricted-row recursion above, without dib), W_b = −Iw_bᵀ.  up != nullptr:
+// the upper blocks L_bb⁻ᵀ are also written onto the diagonal of `up` (the gradient's L⁻ᵀ).
+template <typename T>
+static int32_t dib_build(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, long nbi, T* W, long ldw, T* Iw, T* up, long ldu) {
+    std::vector<std::pair<long, long>> blocks;
+    dib_ranges(0, np, nbi, blocks);
+    HIPCHK(hipMemsetAsync(Iw, 0, sizeof(T) * (size_t)(np + 128) * ldw, s));
+    HIPCHK(hipMemsetAsync(W, 0, sizeof(T) * (size_t)(np + 128) * ldw, s));
+    for (const auto& b : blocks) {
+        const long j0 = b.first, n = b.second;
+        T* Ib = Iw + j0 * ldw;
+        hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, Ib, ldw, n);
+        HIPCHK(hipGetLastError());
+        RC(trsm_upper_rec<T>(c, s, Ib, ldw, L + j0 * ldl + j0, ldl, 0, n));
+        hipLaunchKernelGGL(transpose_scale_kernel<T>, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, s, (const T*)Ib, ldw,
+                           W + j0 * ldw, ldw, n, T(-1));
+        HIPCHK(hipGetLastError());
+        if (up) HIPCHK(hipMemcpy2DAsync(up + j0 * ldu + j0, sizeof(T) * ldu, Ib, sizeof(T) * ldw, sizeof(T) * n, n, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+// The forward solve against the factor of a posterior handle: builds the handle's inverse blocks on first use (kept until the handle is freed)
+// and runs the recursion with them.  X: M × np (+ 128 slack rows).
+template <typename T>
+static int32_t trsm_post(gp_post* post, hipStream_t s, T* X, long ldx, long M, DevBufs& bufs) {
+    gp_ctx* c = post->ctx;
+    const long np = post->np, ld = post->ld;
+    const T* A = (const T*)post->A;
+    if (M <= 0) return 0;
+    if (c->dib_nb < 128 || np < c->dib_nb) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
+    const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
+    const size_t wb = sizeof(T) * (size_t)(np + 128) * ldw;
+    if (!post->dib || post->dib_nbi != nbi) {
+        if (post->dib) ctx_release(c, post->dib, post->dib_bytes);
+        post->dib = nullptr;
+        void* w = nullptr;
+        void* iw = nullptr;
+        RC(ctx_alloc(c, wb, &w));
+        int32_t rc = bufs.get(wb, &iw);
+        if (rc == 0) rc = dib_build<T>(c, s, A, ld, np, nbi, (T*)w, ldw, (T*)iw, (T*)nullptr, 0);
+        if (rc != 0) {
+            (void)hipStreamSynchronize(s);
+            ctx_release(c, w, wb);
+            return rc;
+        }
+        post->dib = w; post->dib_bytes = wb; post->dib_nbi = nbi; post->dib_ldw = ldw;
+    }
+    void* S_v = nullptr;
+    const long lds = nbi + c->ldpad;
+    RC(bufs.get(sizeof(T) * (size_t)(M + 128) * lds, &S_v));
+    DibArgs<T> dib;
+    dib.W = (const T*)post->dib; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = lds;
+    return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np, dib);
 }
 
 // Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows): right-looking over panels of width nb with a
@@ -850,7 +948,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
                                    (const T*)post->xs, np, d, post->kind, (T)post->variance, (const T*)nullptr, ns, n,
                                    0, g, (const T*)nullptr, (const T*)nullptr);
                 HIPCHK(hipGetLastError());
-                RC(trsm_rec<T>(c, c->sm, X, ldx, rows, A, ld, np));
+                RC(trsm_post<T>(post, c->sm, X, ldx, rows, bufs));
                 if (what & 2) {
                     hipLaunchKernelGGL(rowsumsq_kernel<T>, dim3((unsigned)rows), dim3(256), 0, c->sm, X, ldx, np,
                                        c->scal_dev + 8);
@@ -928,9 +1026,24 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         HIPCHK(hipMemcpyAsync(sc_v, sc_h.data(), sc_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(W_v, 0, M_b, s));
         HIPCHK(hipMemsetAsync(Ci_v, 0, M_b, s));
-        hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
-        HIPCHK(hipGetLastError());
-        RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np));                 // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
+        if (c->dib_nb >= 128 && np >= c->dib_nb) {
+            // L⁻ᵀ with the inverse diagonal blocks: dib_build writes L_bb⁻ᵀ onto W's diagonal and −L_bb⁻¹ into Wn; the recursion's leaves then
+            // multiply the rows above each block by one triangular-k GEMM (instead of 2·nbi/64 latency-bound launches per block over all rows above)
+            const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
+            const size_t wb = sizeof(T) * (size_t)(np + 128) * ldw;
+            void *Wn_v = 0, *Iw_v = 0, *S_v = 0;
+            RC(bufs.get(wb, &Wn_v));
+            RC(bufs.get(wb, &Iw_v));
+            RC(bufs.get(wb, &S_v));
+            RC(dib_build<T>(c, s, (const T*)post.A, ld, np, nbi, (T*)Wn_v, ldw, (T*)Iw_v, W, ld));
+            DibArgs<T> dib;
+            dib.W = (const T*)Wn_v; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = ldw;
+            RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np, dib));
+        } else {
+            hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
+            HIPCHK(hipGetLastError());
+            RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np));             // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
+        }
         {
             GridMap gw = plain_map(1, 0, 0);
             gw.ktri = 2;                                                                   // W upper: k starts at the row tile
@@ -1058,7 +1171,7 @@ static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* no
                                k.kind, (T)k.variance, (const T*)nullptr, n2, n1, 0, g, (const T*)nullptr, (const T*)nullptr);
             HIPCHK(hipGetLastError());
         }
-        RC(trsm_rec<T>(c, s, X, ldx, n2p, A1, ld1, np1));
+        RC(trsm_post<T>(old, s, X, ldx, n2p, bufs));
         // S = C22 − U12ᵀ U12 (lower), chol(S) = U22ᵀ                                                       :40
         {
             GridMap g = plain_map(1, 0, 0);
@@ -1217,7 +1330,7 @@ static int32_t post_joint(gp_post* post, const gp_points* xs, const void* pm, co
                            post->kind, (T)post->variance, (const T*)nullptr, ns, n, 0, g, (const T*)nullptr, (const T*)nullptr);
         HIPCHK(hipGetLastError());
     }
-    RC(trsm_rec<T>(c, s, X, ldx, nsp, (const T*)post->A, ld, np));                                             // V ᵀ = K_*x L⁻ᵀ
+    RC(trsm_post<T>(post, s, X, ldx, nsp, bufs));                                                              // V ᵀ = K_*x L⁻ᵀ
     {
         GridMap g = plain_map(1, 0, 0);
         dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
@@ -1452,6 +1565,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "sk_min_k")) c->sk_min_k = v;
     else if (!strcmp(name, "gemm_pipe")) c->gemm_pipe = v != 0;
     else if (!strcmp(name, "kmat_nt")) c->kmat_nt = v != 0;
+    else if (!strcmp(name, "dib_nb")) c->dib_nb = v <= 0 ? 0 : std::min<int64_t>(round_up(std::max<int64_t>(v, 128), 128), 8192);
     else if (!strcmp(name, "gemm_pad_f32")) c->gemm_pad_f32 = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "gemm_pad_lds")) {
         c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
@@ -1495,7 +1609,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
-        {"kmat_nt", c->kmat_nt}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
+        {"kmat_nt", c->kmat_nt}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {
             *out = e.v;
@@ -1862,6 +1976,7 @@ int32_t gp_posterior_free(gp_post* post) {
         ctx_release(c, post->A, post->A_bytes);
         ctx_release(c, post->xs, post->xs_bytes);
         ctx_release(c, post->alpha, post->alpha_bytes);
+        if (post->dib) ctx_release(c, post->dib, post->dib_bytes);
         delete post;
     }
     ctx_unref(c);

@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
         if (!xcd_tile(g, (int)blockIdx.x, bi, bj)) return;
     } else if (g.ktri == 1) {
         bi = (int)gridDim.y - 1 - bi;  // triangular k range: the long row tiles are dispatched first
+    } else if (g.ktri == 3) {
+        // B lower triangular: the k range grows with the COLUMN tile.  Workgroup b runs on XCD b % 8 and blockIdx.x is the fastest index, so
+        // without the rotation XCD x would only ever see column tiles x, x + 8, ... (XCD 7: the longest k ranges of every row) — the
+        // imbalance measured in round 4 (34 -> 57 TF/s on the explicit-inverse panel product); rotating by the row tile deals them evenly.
+        bj = (bj + bi) % (int)gridDim.x;
     }
     if (g.nbatch > 1) {
         C += (long)blockIdx.z * g.cstride;
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     const int fa = (wr * 64 + li) * 8, fb = (wc * 64 + li) * 8;
     int nk = K / BK;
     if (g.ktri == 1) nk = min(nk, (g.ktri_off + m0 + 128) / BK);
+    if (g.ktri == 3) nk = min(nk, (n0 + 128) / BK);
     dma_wait_barrier();
 
     if constexpr (PIPE) {
@@ -1733,6 +1739,20 @@ __global__ __launch_bounds__(256) void add_lower_to_f64_kernel(const T* __restri
     if (j <= i && j < n) dst[i * ldd + j] += (double)src[i * lds + j];
 }
 // dst = srcᵀ (n×n, 32×32 LDS tiles)
+// dst[j][i] = scale · src[i][j] for an n×n block (n multiple of 32): 32×32 tiles through LDS; the inverse diagonal blocks of a factor
+// (L_bb⁻ᵀ upper, row-major -> −L_bb⁻¹ lower, row-major: the B operand of the triangular-k GEMM that replaces a TRSM leaf)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long n, T scale) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long i0 = (long)blockIdx.y * 32, j0 = (long)blockIdx.x * 32;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = (i0 + r < n && j0 + tx < n) ? src[(i0 + r) * lds_ + j0 + tx] : T(0);
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (j0 + r < n && i0 + tx < n) dst[(j0 + r) * ldd + i0 + tx] = scale * tile[tx][r];
+}
 __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst,
                                                             long ldd, long n) {
     __shared__ double t[32][33];

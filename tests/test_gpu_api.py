@@ -509,3 +509,49 @@ def test_deterministic_mode_is_bitwise_repeatable(agp):
             assert np.linalg.norm(runs[0][1] - ref_post.alpha) / np.linalg.norm(ref_post.alpha) <= 1e-8
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("dib_nb", [0, 512, 2048])
+def test_forward_solves_with_inverse_diagonal_blocks(agp, dib_nb):
+    """"dib_nb": forward solves against a resident factor end in one triangular-k GEMM per column block with the explicit inverse of the
+    diagonal block (0: the recursion down to 64-column leaves).  N = 4 500 (padded 4 608: ragged blocks at both widths), every consumer of the
+    solve — predictive variance / covariance / cross-covariance, held-out logpdf, sequential conditioning on 700 new points (and a prediction
+    from the updated posterior: its own, new, blocks), value + gradient — against the oracle at the single-GPU tolerances, twice (the second
+    pass reuses the cached blocks)."""
+    rng = np.random.default_rng(41)
+    n, n2, d = 4500, 700, 3
+    X = rng.standard_normal((n + n2, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n + n2)
+    ctx = agp.Context(0)
+    ctx.set_param("dib_nb", dib_nb)
+    try:
+        f = agp.GP(0.2, 1.4 * agp.Matern52Kernel() @ agp.ScaleTransform(0.8), ctx=ctx)
+        of = o.GP(o.Kernel(o.MATERN52, 1.4, 0.8), 0.2)
+        post = agp.posterior(f(agp.RowVecs(X[:n]), 0.05), y[:n])
+        opost = o.posterior(o.FiniteGP(of, X[:n], 0.05), y[:n])
+        xs, zs = rng.standard_normal((300, d)), rng.standard_normal((150, d))
+        for _ in range(2):
+            m, v = post.mean_and_var(agp.RowVecs(xs))
+            mo, vo = opost.mean_and_var(xs)
+            np.testing.assert_allclose(m, mo, atol=1e-8)
+            np.testing.assert_allclose(v, vo, atol=1e-9)
+            np.testing.assert_allclose(post.cov(agp.RowVecs(xs[:200])), opost.cov(xs[:200]), atol=1e-9)
+            np.testing.assert_allclose(post.cov(agp.RowVecs(xs[:140]), agp.RowVecs(zs)), opost.cov(xs[:140], zs), atol=1e-9)
+            ys = rng.standard_normal(300)
+            assert agp.logpdf(post(agp.RowVecs(xs), 0.1), ys) == pytest.approx(float(o.logpdf(o.FiniteGP(opost, xs, 0.1), ys)), rel=1e-9)
+        p2 = agp.posterior(post(agp.RowVecs(X[n:]), 0.05), y[n:])
+        op2 = o.posterior(o.FiniteGP(opost, X[n:], 0.05), y[n:])
+        np.testing.assert_allclose(p2.data.alpha, op2.alpha, rtol=0, atol=1e-8 * np.abs(op2.alpha).max())
+        m, v = p2.mean_and_var(agp.RowVecs(xs))
+        mo, vo = op2.mean_and_var(xs)
+        np.testing.assert_allclose(m, mo, atol=1e-8)
+        np.testing.assert_allclose(v, vo, atol=1e-9)
+        fx, ofx = f(agp.RowVecs(X[:n]), 0.05), o.FiniteGP(of, X[:n], 0.05)
+        lp, g = agp.logpdf_and_grad(fx, y[:n])
+        go = o.logpdf_grad(ofx, y[:n])
+        assert lp == pytest.approx(float(o.logpdf(ofx, y[:n])), rel=1e-10)
+        assert g["variance"] == pytest.approx(go["variance"], rel=1e-7)
+        np.testing.assert_allclose(g["scale"], go["scale"], rtol=1e-6, atol=1e-9)
+        assert g["noise"] == pytest.approx(go["noise"], rel=1e-7)
+    finally:
+        ctx.close()

@@ -11,11 +11,13 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import abstractgps_jl_amd as agp  # noqa: E402
 
-reps, params = 3, {}
+reps, params, mfma_ref = 3, {}, 0
 for a in sys.argv[1:]:
     k, v = a.split("=")
     if k == "reps":
         reps = int(v)
+    elif k == "mfma_ref":
+        mfma_ref = int(v)
     else:
         params[k] = int(v)
 n, m, d = 262144, 4096, 3
@@ -38,5 +40,11 @@ for _ in range(reps):
     elbo = float(post.objective)
     del post
 flops = 2.0 * n * m * m + 2.0 * m**3 / 3
+if mfma_ref:  # the pure-MFMA reference kernel inside the same profiled process (normalises SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE)
+    import ctypes as C
+
+    v = C.c_double()
+    ctx.lib.gp_bench_mfma_f32(ctx.handle, 0, 20000, C.byref(v))
+    ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, C.byref(v))
 print(json.dumps({"config": "C5", "params": params, "fit_ms": [round(t, 2) for t in ts], "best_ms": min(ts), "frac_fp32": flops / (min(ts) * 1e-3) / 157.3e12,
                   "phases_last": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()}, "elbo": elbo}), flush=True)

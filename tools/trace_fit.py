@@ -12,6 +12,7 @@ import abstractgps_jl_amd as agp  # noqa: E402
 
 n = int(sys.argv[1])
 params = dict(a.split("=") for a in sys.argv[2:])
+mfma_ref = int(params.pop("mfma_ref", 0))
 rng = np.random.default_rng(2)
 X = rng.standard_normal((n, 3))
 y = np.sin(X.sum(axis=1)) + 0.1 * rng.standard_normal(n)
@@ -25,3 +26,8 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     post.data.C.free()
     print(f"fit {rep}: {dt * 1e3:.3f} ms", flush=True)
+if mfma_ref:  # the pure-MFMA reference kernel inside the same profiled process (normalises SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE)
+    import ctypes as C
+
+    v = C.c_double()
+    ctx.lib.gp_bench_mfma_f64(ctx.handle, 20000, C.byref(v))
