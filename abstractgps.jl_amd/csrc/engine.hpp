@@ -29,10 +29,11 @@ struct GridMap {
     int beta0;       // 1: C is overwritten with −A·Bᵀ (no preload of C)
     int ktri;        // 1: A is lower triangular (M×M, K = M): the k loop of row tile m0 stops at column m0 + 128
                      // 3: B is lower triangular (N×N, K = N): the k loop of COLUMN tile n0 stops at column n0 + 128 (column tiles rotated by the row tile)
-                     // 2: A is upper triangular: the k loop of row tile m0 starts at column m0
+                     // 2: A is upper triangular from row ktri_off on: the k loop of row tile m0 starts at column max(0, m0 − ktri_off)
     int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
     long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
     int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
+                     // ktri == 2: rows [0, ktri_off) of A are dense, the upper-triangular block starts at row ktri_off (row tile m0 > ktri_off starts at column m0 − ktri_off)
     int nt;          // kmat: interior tiles written with nontemporal stores
 };
 }  // namespace gpmi

@@ -202,7 +202,8 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
         double elems = (g.lower && g.P == 1 && g.Q == 1) ? lower_count(M, N, g.row0, g.col0) : (double)M * (double)N;
         if (g.nbatch > 1) elems *= g.nbatch;
         rec.flops = g.ktri == 1 ? (double)N * (double)M * (double)(2 * g.ktri_off + M + 128)
-                                : (g.ktri == 2 ? (double)M * (double)M * (double)M / 3.0
+                                : (g.ktri == 2 ? (g.ktri_off > 0 ? 2.0 * (double)g.ktri_off * (double)N * (double)K + (double)N * (double)K * (double)K
+                                                                 : (double)M * (double)M * (double)M / 3.0)
                                                : (g.ktri == 3 ? (double)M * (double)N * (double)(N + 128) : 2.0 * (double)K * elems));
         rec.bytes = 2.0 * sizeof(CT) * elems + sizeof(T) * (double)K * (double)(M + N);
         rec.M = M; rec.N = N; rec.K = K;
@@ -459,7 +460,17 @@ static int32_t trsm_upper_rec(gp_ctx* c, hipStream_t s, T* X, long ldx, const T*
     if (n <= 64) return launch_trsm64<T>(c, s, X + j0, ldx, j0 + 64, L + j0 * ldl + j0, ldl);
     const long h = split_half(n);
     RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0, h, dib));
-    RC(launch_gemm<T>(c, s, X + j0 + h, ldx, X + j0, ldx, L + (j0 + h) * ldl + j0, ldl, j0 + h, n - h, h, plain_map(0, 0, 0)));
+    {
+        // A = X[0 : j0+h, j0 : j0+h]: rows below j0 hold the h×h UPPER-triangular block just solved — its leading zeros are skipped on launches
+        // large enough for the hardware-dispatched kernel (until round 5 this product ran over the whole k range: N³/2 flops for L⁻ᵀ instead
+        // of N³/3; the few-tile launches keep the full range and their stream-K cut)
+        GridMap g = plain_map(0, 0, 0);
+        if (h >= 512 && ((j0 + h) / 128) * ((n - h + 127) / 128) > c->sk_max_tiles / 8) {
+            g.ktri = 2;
+            g.ktri_off = (int)j0;
+        }
+        RC(launch_gemm<T>(c, s, X + j0 + h, ldx, X + j0, ldx, L + (j0 + h) * ldl + j0, ldl, j0 + h, n - h, h, g));
+    }
     RC(trsm_upper_rec<T>(c, s, X, ldx, L, ldl, j0 + h, n - h, dib));
     return 0;
 }
@@ -1026,24 +1037,11 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         HIPCHK(hipMemcpyAsync(sc_v, sc_h.data(), sc_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(W_v, 0, M_b, s));
         HIPCHK(hipMemsetAsync(Ci_v, 0, M_b, s));
-        if (c->dib_nb >= 128 && np >= c->dib_nb) {
-            // L⁻ᵀ with the inverse diagonal blocks: dib_build writes L_bb⁻ᵀ onto W's diagonal and −L_bb⁻¹ into Wn; the recursion's leaves then
-            // multiply the rows above each block by one triangular-k GEMM (instead of 2·nbi/64 latency-bound launches per block over all rows above)
-            const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
-            const size_t wb = sizeof(T) * (size_t)(np + 128) * ldw;
-            void *Wn_v = 0, *Iw_v = 0, *S_v = 0;
-            RC(bufs.get(wb, &Wn_v));
-            RC(bufs.get(wb, &Iw_v));
-            RC(bufs.get(wb, &S_v));
-            RC(dib_build<T>(c, s, (const T*)post.A, ld, np, nbi, (T*)Wn_v, ldw, (T*)Iw_v, W, ld));
-            DibArgs<T> dib;
-            dib.W = (const T*)Wn_v; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = ldw;
-            RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np, dib));
-        } else {
-            hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
-            HIPCHK(hipGetLastError());
-            RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np));             // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
-        }
+        // (the inverse-diagonal-block leaves of the predictive solves do not pay here — measured: C2 93.0 -> 95.6 ms, C4 4.71 -> 4.72 s: for the
+        //  identity right-hand side the serial chain that builds the blocks costs what the leaves it replaces cost)
+        hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
+        HIPCHK(hipGetLastError());
+        RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np));                 // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
         {
             GridMap gw = plain_map(1, 0, 0);
             gw.ktri = 2;                                                                   // W upper: k starts at the row tile

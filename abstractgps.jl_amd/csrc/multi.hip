@@ -37,6 +37,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -282,6 +285,63 @@ struct MRank {
     double t_ms = 0;
 };
 
+// R persistent rank threads owned by a multi-device context: a fit, a solve pass, a verification pass or an update hands every rank its
+// closure (run(fn): fn(r) on thread r) and waits for all of them.  Until round 5 every such pass created and joined R std::threads
+// (irrelevant at C4, measurable at C2-sized fits and in optimiser loops: the round-4 review's item 14).  Errors stay per thread
+// (gp_last_error is thread-local; the closures copy the text into their rank's record before they return, as before).
+class RankPool {
+  public:
+    explicit RankPool(int R) : n_(R) {
+        for (int r = 0; r < R; ++r) th_.emplace_back([this, r]() { loop(r); });
+    }
+    RankPool(const RankPool&) = delete;
+    ~RankPool() {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            stop_ = true;
+        }
+        cv_start_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(const std::function<void(int)>& fn) {
+        std::unique_lock<std::mutex> l(mu_);
+        fn_ = &fn;
+        left_ = n_;
+        ++gen_;
+        cv_start_.notify_all();
+        cv_done_.wait(l, [&] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void loop(int r) {
+        long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_start_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                fn = fn_;
+            }
+            (*fn)(r);
+            {
+                std::lock_guard<std::mutex> l(mu_);
+                if (--left_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_start_, cv_done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    long gen_ = 0;
+    int left_ = 0;
+    bool stop_ = false;
+};
+
 struct gp_multi {
     int P = 1, Q = 1, R = 1;
     long nb = 1024;
@@ -303,6 +363,11 @@ struct gp_multi {
     double timeout_s = 600;  // a rank thread that waits longer than this for a peer or for its own streams fails the fit
     std::string comm_note;
     Trace* tr = nullptr;  // schedule trace of the running fit
+    std::unique_ptr<RankPool> pool;  // the rank threads (created with the ranks; dry-run traces on a stack gp_multi spawn their own)
+    void run_ranks(const std::function<void(int)>& fn) {
+        if (!pool) pool.reset(new RankPool(R));
+        pool->run(fn);
+    }
 };
 
 struct gp_multi_post {
@@ -1734,9 +1799,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         std::vector<double> Ka((size_t)n, 0.0);
         std::vector<int32_t> vrc((size_t)R, 0);
         {
-            std::vector<std::thread> th;
-            for (int r = 0; r < R; ++r)
-                th.emplace_back([&, r]() {
+            M->run_ranks([&](int r) {
                     MRank& rk = M->ranks[r];
                     std::lock_guard<std::mutex> l(rk.c->mu);
                     vrc[r] = [&]() -> int32_t {
@@ -1748,8 +1811,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
                         MCHK(hipStreamSynchronize(rk.c->sm));
                         return 0;
                     }();
-                });
-            for (auto& t : th) t.join();
+            });
         }
         (void)hipSetDevice(c->device);
         for (int r = 0; r < R; ++r)
@@ -1784,9 +1846,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
         auto t0 = std::chrono::steady_clock::now();
         {
-            std::vector<std::thread> th;
-            for (int r = 0; r < R; ++r)
-                th.emplace_back([&, r]() {
+            M->run_ranks([&](int r) {
                     MRank& rk = M->ranks[r];
                     std::lock_guard<std::mutex> l(rk.c->mu);
                     rk.rc = fit_rank(M, &rk, dm, false, k->kind, k->variance, xs_h.data(), noise_h.data(), rhs_h.data(), ncols, want_alpha, keep,
@@ -1800,8 +1860,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
                             (void)hipStreamSynchronize(rk.sc);
                         }
                     }
-                });
-            for (auto& t : th) t.join();
+            });
         }
         wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         (void)hipSetDevice(c->device);
@@ -2034,9 +2093,7 @@ int32_t run_solve(gp_ctx* c, SolveDims sd, const std::vector<gp_multi_post::Piec
     std::vector<std::unique_ptr<DevBufs>> bufs((size_t)R);
     for (int r = 0; r < R; ++r) bufs[r].reset(new DevBufs(M->ranks[r].c));
     {
-        std::vector<std::thread> th;
-        for (int r = 0; r < R; ++r)
-            th.emplace_back([&, r]() {
+        M->run_ranks([&](int r) {
                 MRank& rk = M->ranks[r];
                 std::lock_guard<std::mutex> l(rk.c->mu);
                 rk.rc = solve_rank(M, &rk, sd, false, &pieces[r], kind, variance, x_h, xs_h, rhs_h, part[r].data(), want_cov ? cpart[r].data() : nullptr,
@@ -2046,8 +2103,7 @@ int32_t run_solve(gp_ctx* c, SolveDims sd, const std::vector<gp_multi_post::Piec
                     M->abort.store(1);
                     if (rk.rc != -1992) (void)hipStreamSynchronize(rk.c->sm);
                 }
-            });
-        for (auto& t : th) t.join();
+        });
     }
     M->tr = nullptr;
     if (tr.f) fclose(tr.f);
@@ -2149,9 +2205,7 @@ int32_t multi_factor_mul(gp_post* post, const double* xi, int ncols, double* out
     std::vector<int32_t> rcs((size_t)R, 0);
     std::vector<std::string> errs((size_t)R);
     {
-        std::vector<std::thread> th;
-        for (int r = 0; r < R; ++r)
-            th.emplace_back([&, r]() {
+        M->run_ranks([&](int r) {
                 MRank& rk = M->ranks[r];
                 std::lock_guard<std::mutex> l(rk.c->mu);
                 rcs[r] = [&]() -> int32_t {
@@ -2177,8 +2231,7 @@ int32_t multi_factor_mul(gp_post* post, const double* xi, int ncols, double* out
                     return 0;
                 }();
                 if (rcs[r] != 0) errs[r] = gp_last_error();
-            });
-        for (auto& t : th) t.join();
+        });
     }
     (void)hipSetDevice(c->device);
     for (int r = 0; r < R; ++r)
