@@ -85,6 +85,7 @@ struct gp_ctx {
     long updk_tall_k = 256;      // ... K above this only while at most updk_tall_m rows are below (the stream-K tile GEMM wins on tall K = 512 launches)
     long updk_tall_m = 8192;
     int updk_rt = 0;             // rows per workgroup / 16 of panel_updk_kernel (0 auto, 4, 2, 1)
+    int leaf_rank4 = 0;    // 16×16 factorisation of the register-resident leaf by rank-4 MFMA updates (6 MFMAs + 24 row moves per block; leaf.hpp) instead of rank-1
     int leaf_cols = 128;   // columns per register-resident leaf launch: 128 (one launch per 128-column group, no in-leaf pre-update) or 64
     int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at
                            // most sk_max_tiles tiles: the few-tile in-panel GEMMs are cut along k over all CUs (−2…5 % at N <= 32 768)
@@ -96,7 +97,8 @@ struct gp_ctx {
                            // (inside the factorisation the look-ahead stream already fills the tail of every trailing update)
     long gemm_pad_lds = 0; // extra dynamic LDS per GEMM workgroup: 20480 limits residency to ONE workgroup per CU (same speed —
                            // tools/overlap_probe.hip — and leaves room for concurrently running RCCL / copy kernels)
-    long gemm_pad_f32 = 20480; // the fp32 default of the above (0: two workgroups per CU)
+    long gemm_pad_f32 = 0;  // the fp32 default of the above: 0 = two workgroups per CU (1 % faster at C5 since the k loop is pipelined — 81.3 against 82.3 ms,
+                            // two A/B pairs on one box, profiles/r5/sweep3.jsonl; with the round-2 loop one workgroup per CU was 5 % faster: 20480 restores it)
     int gemm_pipe = 1;     // k loop of the MFMA GEMMs software-pipelined across the step boundary (kernels.hpp gemm_kloop_pipe; 0: the round-2 loop)
     long dib_nb = 2048;    // forward solves X L⁻ᵀ against a RESIDENT factor (predictions, covariances, sequential updates, the gradient's L⁻ᵀ): sub-blocks of at
                            // most this many columns are solved by ONE triangular-k GEMM with the explicit inverse of the diagonal block (0: the recursion down to 64)
@@ -252,7 +254,7 @@ int32_t eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const do
                  long n, const double* alpha, double* out, long nrows);
 // register-resident 64-column leaf (leaf.hip, its own translation unit): tile Cholesky + X L⁻ᵀ of the mrows rows below, fp64
 int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* info_dev, int col0, int n_valid, double* logdet_dev, int* ticket,
-                       int kpre, int xr, int num_cus, int ncols);
+                       int kpre, int xr, int num_cus, int ncols, int rank4);
 int32_t launch_panel_updk(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m, long N, long K, int rt, int num_cus);
 // 2-D block copy by a kernel (16-B aligned rows, even cols): source may live on a peer device with peer access enabled
 int32_t eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols);

@@ -254,9 +254,8 @@ static int32_t launch_gemm(gp_ctx* c, hipStream_t s, CT* C, long ldc, const T* A
             hipLaunchKernelGGL((gemm_nt_sk_kernel<T, 0>), dim3((unsigned)G), dim3(256), 0, s, (T*)C, ldc, A, lda, B, ldb, (int)M, (int)N,
                                (int)K, g, ntiles, (int)G2);
     } else {
-        // residency: two workgroups per CU for fp64 (measured best over a whole factorisation), ONE for fp32 — the fp32 MFMA
-        // GEMMs of the VFE path run 5 % faster with one 4-wave workgroup per CU (profiles/r2/sweep_c5.jsonl); a dynamic-LDS
-        // request of 20 KiB on top of the 64 KiB static image pins that.  "gemm_pad_lds" overrides both.
+        // residency: two workgroups per CU (fp64: measured best over a whole factorisation; fp32: since the pipelined k loop, "gemm_pad_f32");
+        // a dynamic-LDS request of 20 KiB on top of the 64 KiB static image pins ONE per CU.  "gemm_pad_lds" overrides both.
         const long pad = c->gemm_pad_user ? c->gemm_pad_lds : (sizeof(T) == 4 ? c->gemm_pad_f32 : 0);
         if (pad > 0 && !c->gemm_pad_set) {
             HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<double, double, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
@@ -320,7 +319,7 @@ static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, lo
     if constexpr (std::is_same<T, double>::value) {
         if (c->leaf_v2) {  // register-resident leaf (leaf.hip: panel64v2_kernel)
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mrows, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, kpre,
-                                              c->leaf_xr, c->num_cus, 64));
+                                              c->leaf_xr, c->num_cus, 64, c->leaf_rank4));
             return 0;
         }
     }
@@ -345,7 +344,7 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
             }
             int* const tk = c->ticket_dev + (s == c->sp ? 32 : 0);
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mtot - j0 - 128, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, 0,
-                                              c->leaf_xr, c->num_cus, 128));
+                                              c->leaf_xr, c->num_cus, 128, c->leaf_rank4));
             return 0;
         }
     }
@@ -1574,6 +1573,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
     else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
     else if (!strcmp(name, "leaf_cols")) c->leaf_cols = v == 64 ? 64 : 128;
+    else if (!strcmp(name, "leaf_rank4")) c->leaf_rank4 = v != 0;
     else if (!strcmp(name, "updk_max_k")) c->updk_max_k = std::max<int64_t>(0, v);
     else if (!strcmp(name, "updk_rt")) c->updk_rt = (int)v;
     else if (!strcmp(name, "updk_tall_k")) c->updk_tall_k = std::max<int64_t>(0, v);
@@ -1604,7 +1604,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"xcd_swizzle", c->xcd_swizzle}, {"xcd_min_tiles", c->xcd_min_tiles}, {"gemm_streamk", c->gemm_streamk},
         {"sk_max_tiles", c->sk_max_tiles}, {"sk_min_k", c->sk_min_k}, {"gemm_pipe", c->gemm_pipe}, {"gemm_pad_f32", c->gemm_pad_f32},
         {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb}, {"deterministic", c->deterministic},
-        {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
+        {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"leaf_rank4", c->leaf_rank4}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
         {"kmat_nt", c->kmat_nt}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};

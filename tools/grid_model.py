@@ -28,6 +28,16 @@ import perf_model as pm  # noqa: E402
 LINK = 64e9         # B/s per xGMI link and direction that a large transfer sustains (MI355X: 153.6 GB/s per link bidirectional peak)
 MSG_LAT = 8e-6      # per point-to-point message (group launch + link latency)
 TRSM_RATE = 45e12   # MFMA TRSM of a tall block against an NB×NB factor (recursion of GEMMs + 64-wide leaves)
+# Round 5: the diagonal block's chain MEASURED through the library's own entry points on one MI355X (tools/cumask_chain_probe.py,
+# profiles/r5/cumask_chain_probe.jsonl; ms per NB×NB block, the bulk update = one rank's share of a C4 step on an 8×1 grid running beside it):
+#   standalone  nothing else on the device (64-column leaves of the rank contexts)
+#   unmasked    on a high-priority stream beside the update, no CU mask — what the driver does today: 64-column leaves, 6–10× slower
+#               (the 128-column leaf waits for the END of the update: 12.8 / 6.2 ms)
+#   masked16    chain on a stream masked to 16 CUs (2 per XCD) with 128-column leaves, the update on the other 240: the update runs 4 % slower
+# `python tools/grid_model.py chain=unmasked` / `chain=masked16` price the fit with these instead of the model's stand-alone chain × CORES.
+CHAIN_MS = {"standalone": {512: 0.179, 1024: 0.358}, "unmasked": {512: 1.023, 1024: 3.590}, "masked16": {512: 0.174, 1024: 0.456}}
+BULK_SLOW = {"standalone": 1.0, "unmasked": 1.0, "masked16": 1.04}
+CHAIN = None        # None: pm.panel(NB, NB) × CORES (the rounds 2–4 model)
 CORES = 1.0         # slow-down of the diagonal block's leaf chain when it runs BESIDE the bulk update (round 4, one GPU: a 64-column leaf that shares CUs
                     # with the tile GEMM runs ≈ 5× slower, profiles/r4/traces/c3_c64_summary.txt; `python tools/grid_model.py cores=5` prices that)
 
@@ -63,7 +73,11 @@ def model(N, P, Q, NB, depth=2, forward=False):
 
     def panel_time(k):
         m = nblk - k - 1
-        t = pm.panel(NB, NB) * CORES                           # diagonal block on its owner (beside the bulk update: CORES)
+        if CHAIN is None:
+            t = pm.panel(NB, NB) * CORES                       # diagonal block on its owner (beside the bulk update: CORES)
+        else:                                                  # measured (NB = 2 048 was not: scaled from 1 024 by the model's own ratio)
+            tab = CHAIN_MS[CHAIN]
+            t = tab[NB] * 1e-3 if NB in tab else tab[1024] * 1e-3 * pm.panel(NB, NB) / pm.panel(1024, 1024)
         if P > 1:
             t += 8.0 * NB * NB / LINK + MSG_LAT                # L_kk to the column peers (P−1 links at once)
         rows = math.ceil(m / P) * NB
@@ -121,6 +135,8 @@ def model(N, P, Q, NB, depth=2, forward=False):
             tiles = (full + diag) * (NB // 128) ** 2
             fill = tiles / (math.ceil(tiles / 512) * 512)
             t = pm.LAUNCH + max(fl / (pm.PEAK * fill), NB / 16 * pm.STEP_ALONE)
+            if CHAIN is not None:
+                t *= BULK_SLOW[CHAIN]
             worst = max(worst, t)
         return worst
 
@@ -162,6 +178,9 @@ if __name__ == "__main__":
         if a.startswith("cores="):
             CORES = float(a.split("=")[1])
             print(f"diagonal-block chain priced {CORES:g}x slower (co-resident with the bulk update)")
+        if a.startswith("chain="):
+            CHAIN = a.split("=")[1]
+            print(f"diagonal-block chain: MEASURED durations '{CHAIN}' {CHAIN_MS[CHAIN]} ms (tools/cumask_chain_probe.py), bulk update x{BULK_SLOW[CHAIN]}")
     if FWD:
         print("A-operand forwarding PRICED (two-phase slice exchange inside a process row; not implemented in the driver)")
     one = model(N, 1, 1, 2048)
