@@ -34,7 +34,6 @@ struct GridMap {
     long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
     int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
                      // ktri == 2: rows [0, ktri_off) of A are dense, the upper-triangular block starts at row ktri_off (row tile m0 > ktri_off starts at column m0 − ktri_off)
-    int nt;          // kmat: interior tiles written with nontemporal stores
 };
 }  // namespace gpmi
 
@@ -85,7 +84,6 @@ struct gp_ctx {
     long updk_tall_k = 256;      // ... K above this only while at most updk_tall_m rows are below (the stream-K tile GEMM wins on tall K = 512 launches)
     long updk_tall_m = 8192;
     int updk_rt = 0;             // rows per workgroup / 16 of panel_updk_kernel (0 auto, 4, 2, 1)
-    int leaf_rank4 = 0;    // 16×16 factorisation of the register-resident leaf by rank-4 MFMA updates (6 MFMAs + 24 row moves per block; leaf.hpp) instead of rank-1
     int leaf_cols = 128;   // columns per register-resident leaf launch: 128 (one launch per 128-column group, no in-leaf pre-update) or 64
     int gemm_streamk = 1;  // persistent-grid GEMM with a stream-K tail for single-GPU maps (gemm_nt_sk_kernel) on launches of at
                            // most sk_max_tiles tiles: the few-tile in-panel GEMMs are cut along k over all CUs (−2…5 % at N <= 32 768)
@@ -102,7 +100,6 @@ struct gp_ctx {
     int gemm_pipe = 1;     // k loop of the MFMA GEMMs software-pipelined across the step boundary (kernels.hpp gemm_kloop_pipe; 0: the round-2 loop)
     long dib_nb = 2048;    // forward solves X L⁻ᵀ against a RESIDENT factor (predictions, covariances, sequential updates, the gradient's L⁻ᵀ): sub-blocks of at
                            // most this many columns are solved by ONE triangular-k GEMM with the explicit inverse of the diagonal block (0: the recursion down to 64)
-    int kmat_nt = 0;       // Gram tiles written with nontemporal stores (global_store ... nt): the matrix is next read by the factorisation, tiles later
     bool gemm_pad_set = false;
     bool gemm_pad_user = false;  // "gemm_pad_lds" was set explicitly (otherwise: 0 for fp64, 20480 for fp32)
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
@@ -254,7 +251,7 @@ int32_t eng_kvec(gp_ctx* c, hipStream_t s, const double* xs, long ldxs, const do
                  long n, const double* alpha, double* out, long nrows);
 // register-resident 64-column leaf (leaf.hip, its own translation unit): tile Cholesky + X L⁻ᵀ of the mrows rows below, fp64
 int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* info_dev, int col0, int n_valid, double* logdet_dev, int* ticket,
-                       int kpre, int xr, int num_cus, int ncols, int rank4);
+                       int kpre, int xr, int num_cus, int ncols);
 int32_t launch_panel_updk(hipStream_t s, double* C, long ldc, const double* P, long ldp, long m, long N, long K, int rt, int num_cus);
 // 2-D block copy by a kernel (16-B aligned rows, even cols): source may live on a peer device with peer access enabled
 int32_t eng_copy2d(gp_ctx* c, hipStream_t s, double* dst, long dld, const double* src, long sld, long rows, long cols);

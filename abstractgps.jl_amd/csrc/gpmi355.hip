@@ -293,7 +293,6 @@ GridMap gpmi::plain_map(int lower, long row0, long col0) {
     g.nbatch = 1;
     g.cstride = 0;
     g.ktri_off = 0;
-    g.nt = 0;
     return g;
 }
 
@@ -319,7 +318,7 @@ static int32_t launch_leaf(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, lo
     if constexpr (std::is_same<T, double>::value) {
         if (c->leaf_v2) {  // register-resident leaf (leaf.hip: panel64v2_kernel)
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mrows, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, kpre,
-                                              c->leaf_xr, c->num_cus, 64, c->leaf_rank4));
+                                              c->leaf_xr, c->num_cus, 64));
             return 0;
         }
     }
@@ -344,7 +343,7 @@ static int32_t potrf_rec(gp_ctx* c, hipStream_t s, T* A, long lda, long j0, long
             }
             int* const tk = c->ticket_dev + (s == c->sp ? 32 : 0);
             HIPCHK((hipError_t)launch_leaf_v2(s, (double*)(A + j0 * lda + j0), lda, mtot - j0 - 128, info_dev, (int)(gcol0 + j0), (int)n_valid, logdet_dev, tk, 0,
-                                              c->leaf_xr, c->num_cus, 128, c->leaf_rank4));
+                                              c->leaf_xr, c->num_cus, 128));
             return 0;
         }
     }
@@ -760,7 +759,6 @@ static void scale_points(const gp_kernel* k, const gp_points* x, long ldx, std::
 template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k, const T* xs_dev, long ldx, int d,
                                                   const T* noise_dev, long n, long np, T* A, long ld) {
     GridMap g = plain_map(1, 0, 0);
-    g.nt = c->kmat_nt;
     dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
     hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, A, ld, xs_dev, ldx, xs_dev, ldx, d, k->kind,
                        (T)k->variance, noise_dev, n, n, 1, g, (const T*)nullptr, (const T*)nullptr);
@@ -1034,8 +1032,10 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         T* Ci = (T*)Ci_v;
         HIPCHK(hipMemsetAsync(g_v, 0, g_b, s));
         HIPCHK(hipMemcpyAsync(sc_v, sc_h.data(), sc_b, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemsetAsync(W_v, 0, M_b, s));
-        HIPCHK(hipMemsetAsync(Ci_v, 0, M_b, s));
+        // W is written in full by identity_kernel and Ci by the product below (beta0: C is overwritten, not read): only the 128 slack rows the
+        // GEMM over-reads need defined values (until round 5 both N×N blocks were zeroed first: 2 × 34 GB of writes at C4)
+        HIPCHK(hipMemsetAsync(W + np * ld, 0, sizeof(T) * (size_t)128 * ld, s));
+        HIPCHK(hipMemsetAsync(Ci + np * ld, 0, sizeof(T) * (size_t)128 * ld, s));
         // (the inverse-diagonal-block leaves of the predictive solves do not pay here — measured: C2 93.0 -> 95.6 ms, C4 4.71 -> 4.72 s: for the
         //  identity right-hand side the serial chain that builds the blocks costs what the leaves it replaces cost)
         hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
@@ -1044,6 +1044,7 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         {
             GridMap gw = plain_map(1, 0, 0);
             gw.ktri = 2;                                                                   // W upper: k starts at the row tile
+            gw.beta0 = 1;                                                                  // Ci is overwritten (its upper tiles are never read)
             RC(launch_gemm<T>(c, s, Ci, ld, W, ld, W, ld, np, np, np, gw));                // Ci = −W Wᵀ = −C⁻¹ (lower)
         }
         // fold the sign: the kernels below read +C⁻¹
@@ -1561,7 +1562,6 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
     else if (!strcmp(name, "sk_min_k")) c->sk_min_k = v;
     else if (!strcmp(name, "gemm_pipe")) c->gemm_pipe = v != 0;
-    else if (!strcmp(name, "kmat_nt")) c->kmat_nt = v != 0;
     else if (!strcmp(name, "dib_nb")) c->dib_nb = v <= 0 ? 0 : std::min<int64_t>(round_up(std::max<int64_t>(v, 128), 128), 8192);
     else if (!strcmp(name, "gemm_pad_f32")) c->gemm_pad_f32 = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "gemm_pad_lds")) {
@@ -1573,7 +1573,6 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
     else if (!strcmp(name, "leaf_xr")) c->leaf_xr = v == 64 ? 64 : (v == 128 ? 128 : 0);
     else if (!strcmp(name, "leaf_cols")) c->leaf_cols = v == 64 ? 64 : 128;
-    else if (!strcmp(name, "leaf_rank4")) c->leaf_rank4 = v != 0;
     else if (!strcmp(name, "updk_max_k")) c->updk_max_k = std::max<int64_t>(0, v);
     else if (!strcmp(name, "updk_rt")) c->updk_rt = (int)v;
     else if (!strcmp(name, "updk_tall_k")) c->updk_tall_k = std::max<int64_t>(0, v);
@@ -1604,10 +1603,10 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"xcd_swizzle", c->xcd_swizzle}, {"xcd_min_tiles", c->xcd_min_tiles}, {"gemm_streamk", c->gemm_streamk},
         {"sk_max_tiles", c->sk_max_tiles}, {"sk_min_k", c->sk_min_k}, {"gemm_pipe", c->gemm_pipe}, {"gemm_pad_f32", c->gemm_pad_f32},
         {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb}, {"deterministic", c->deterministic},
-        {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"leaf_rank4", c->leaf_rank4}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
+        {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
-        {"kmat_nt", c->kmat_nt}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
+        {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {
             *out = e.v;

@@ -10,25 +10,20 @@ namespace gpmi {
 // the rows below the 128×128 tile).  xr: rows of X per workgroup (64 / 128); 0 = 64 while that gives at most two (ncols = 64) / one
 // (ncols = 128: 150 KB of LDS per workgroup) workgroups per CU, else 128.
 int32_t launch_leaf_v2(hipStream_t s, double* Ajj, long lda, long mrows, int* info_dev, int col0, int n_valid, double* logdet_dev, int* ticket,
-                       int kpre, int xr, int num_cus, int ncols, int rank4) {
+                       int kpre, int xr, int num_cus, int ncols) {
     const bool wide = ncols == 128;
     const bool xr64 = xr == 64 || (xr == 0 && mrows <= 64L * (wide ? 1 : 2) * num_cus);
     const unsigned nb = (unsigned)std::max(1L, (mrows + (xr64 ? 63 : 127)) / (xr64 ? 64 : 128));
-    const dim3 g(nb), b(256);
-#define GPMI_LEAF_LAUNCH(XR_, NC_, KP_)                                                                                                                      \
-    do {                                                                                                                                                     \
-        if (rank4) hipLaunchKernelGGL((panel64v2_kernel<XR_, NC_, 1>), g, b, 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, KP_);  \
-        else hipLaunchKernelGGL((panel64v2_kernel<XR_, NC_, 0>), g, b, 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, KP_);        \
-    } while (0)
     if (wide) {
-        if (xr64) GPMI_LEAF_LAUNCH(64, 8, 0);
-        else GPMI_LEAF_LAUNCH(128, 8, 0);
+        if (xr64)
+            hipLaunchKernelGGL((panel64v2_kernel<64, 8>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, 0);
+        else
+            hipLaunchKernelGGL((panel64v2_kernel<128, 8>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, 0);
     } else if (xr64) {
-        GPMI_LEAF_LAUNCH(64, 4, kpre);
+        hipLaunchKernelGGL((panel64v2_kernel<64, 4>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
     } else {
-        GPMI_LEAF_LAUNCH(128, 4, kpre);
+        hipLaunchKernelGGL((panel64v2_kernel<128, 4>), dim3(nb), dim3(256), 0, s, Ajj, lda, (int)mrows, info_dev, col0, n_valid, logdet_dev, ticket, kpre);
     }
-#undef GPMI_LEAF_LAUNCH
     return (int32_t)hipGetLastError();  // hipError_t of the launch (0 = hipSuccess)
 }
 

@@ -55,26 +55,7 @@ namespace gpmi {
 // owner), after which wave 0 solves and updates the hand-over block itself and goes on; the owners' other blocks (t, j) are solved and
 // published after B1 and the owners meet at the LDS counter `pub` (release / acquire fences around it) before the updates that read them.
 // All four instances execute the same workgroup barriers.
-#ifndef GPMI_LEAF_R4_DEFAULT
-#define GPMI_LEAF_R4_DEFAULT 0  // tools/leaf_check.hip / leaf_stamps.hip instantiate the kernel without the last argument: -DGPMI_LEAF_R4_DEFAULT=1 builds them on the rank-4 chain
-#endif
-// a 16-lane row (lane group j) of a per-lane fp64 value into every lane group: v_permlane16_swap (odd rows of the first operand <-> even rows of the
-// second) and v_permlane32_swap (upper half of the first <-> lower half of the second) of gfx950, two per dword; j is a compile-time constant after
-// unrolling.  85 cycles on a dependent chain (tools/lat_probe3.hip).
-__device__ __forceinline__ double row_to_all(double v, int j) {
-    typedef unsigned u2_t_ __attribute__((ext_vector_type(2)));
-    const unsigned long b = __builtin_bit_cast(unsigned long, v);
-    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-    const u2_t_ a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // a[0] = rows {0,0,2,2}, a[1] = rows {1,1,3,3}
-    const u2_t_ c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const unsigned al = (j & 1) ? a[1] : a[0], ch = (j & 1) ? c[1] : c[0];
-    const u2_t_ e = __builtin_amdgcn_permlane32_swap(al, al, false, false);  // e[0] = its rows {0,0,0,0}, e[1] = its rows {2,2,2,2}
-    const u2_t_ f = __builtin_amdgcn_permlane32_swap(ch, ch, false, false);
-    const unsigned rl = (j & 2) ? e[1] : e[0], rh = (j & 2) ? f[1] : f[0];
-    return __builtin_bit_cast(double, ((unsigned long)rh << 32) | (unsigned long)rl);
-}
-
-template <int XR, int W, int NC, int R4 = GPMI_LEAF_R4_DEFAULT>
+template <int XR, int W, int NC>
 __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0, int n_valid,
                                           double* __restrict__ logdet_acc, int* __restrict__ ticket, int kpre, double* __restrict__ Lp,
                                           double* __restrict__ Inv, double* __restrict__ dAx, double* __restrict__ yx,
@@ -243,42 +224,6 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
                 Ls[r] = 0.0;
                 Ws[r] = 0.0;
             }
-            if constexpr (R4 != 0) {
-                // Rank-4 form of P3 ("leaf_rank4", round 5; arithmetic verified lane by lane in tools/leaf_emu.py: check_p3_rank4).  Register p of the four
-                // lane groups holds the rows 4p..4p+3 of the Schur complement — exactly the four K slots of ONE MFMA — so a sub-block of four
-                // columns is finished on the VALU first (row jj scaled by 1/√pivot; rows jj+1..3 of the sub-block minus their projection on it,
-                // which needs row jj in the OTHER lane groups: a 16-lane row move, and the group's own multiplier by v_readlane) and then a single
-                // MFMA applies the rank-4 update to the block, a second one to the transposed identity riding along: 6 MFMAs per 16×16 block
-                // instead of 30, 24 row moves.  Same result registers (Ls, Ws) as the rank-1 loop below.
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    double ra = accA[p], rw = accW[p];  // lane (li, k): rows 4p + k of A and of Wᵀ
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int c = 4 * p + jj;
-                        const double ri = fast_rsqrt<double>(lane_bcast<double>(ra, 16 * jj + c));  // pivot A[c][c]: lane (c, jj)
-                        ra = (lg == jj) ? ra * ri : ra;  // lane (i, jj): L[i][c]
-                        rw = (lg == jj) ? rw * ri : rw;  // lane (i, jj): (L⁻ᵀ)[i][c]
-                        if (jj < 3) {
-                            const double la = row_to_all(ra, jj), lw = row_to_all(rw, jj);
-                            double mult = 0.0;
-#pragma unroll
-                            for (int k = jj + 1; k < 4; ++k) {
-                                const double mk = lane_bcast<double>(la, 4 * p + k);  // L[4p + k][c]
-                                mult = (lg == k) ? mk : mult;
-                            }
-                            ra = (lg > jj) ? fma(-mult, la, ra) : ra;
-                            rw = (lg > jj) ? fma(-mult, lw, rw) : rw;
-                        }
-                    }
-                    Ls[p] = ra;
-                    Ws[p] = rw;
-                    if (p < 3) {
-                        accA = TR::mfma(-ra, ra, accA);
-                        accW = TR::mfma(-ra, rw, accW);
-                    }
-                }
-            } else {
             double sel;
             {
                 const double piv = lane_bcast<double>(accA[0], 0);
@@ -311,7 +256,6 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            }  // rank-1 form
             // Ls[r] of lane (li, lg) = L[li][lg + 4r] (garbage above the diagonal), Ws[r] = (L⁻ᵀ)[li][lg + 4r] = Inv[lg + 4r][li]
             double dg = 1.0;
 #pragma unroll
@@ -488,7 +432,7 @@ __device__ __forceinline__ void leaf_wave(double* __restrict__ A, long lda, int 
 // NC = 4: the 64-column leaf (same contract as panel64_kernel).  NC = 8: a 128-column leaf — mrows counts the rows below the 128×128
 // tile, kpre must be 0 (what a 64-column leaf's in-leaf pre-update does for the second half of a 128-column group is here part of the
 // ordinary update loop, on registers that are already loaded).
-template <int XR, int NC = 4, int R4 = GPMI_LEAF_R4_DEFAULT>
+template <int XR, int NC = 4>
 __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, long lda, int mrows, int* __restrict__ info, int col0,
                                                          int n_valid, double* __restrict__ logdet_acc, int* __restrict__ ticket,
                                                          int kpre) {
@@ -499,10 +443,10 @@ __global__ __launch_bounds__(256) void panel64v2_kernel(double* __restrict__ A, 
     __shared__ int writer_s, pub;
     const int w = threadIdx.x >> 6;  // wave-uniform: each wave runs the instance of its role
     if (threadIdx.x == 0) pub = 0;   // (the first barrier inside orders this before any increment)
-    if (w == 0) leaf_wave<XR, 0, NC, R4>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
-    else if (w == 1) leaf_wave<XR, 1, NC, R4>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
-    else if (w == 2) leaf_wave<XR, 2, NC, R4>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
-    else leaf_wave<XR, 3, NC, R4>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    if (w == 0) leaf_wave<XR, 0, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    else if (w == 1) leaf_wave<XR, 1, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    else if (w == 2) leaf_wave<XR, 2, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
+    else leaf_wave<XR, 3, NC>(A, lda, mrows, info, col0, n_valid, logdet_acc, ticket, kpre, Lp, Inv, dAx, yx, &writer_s, &pub);
 }
 
 // ------------------------------------------------------------------------------------------------
