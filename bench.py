@@ -125,18 +125,26 @@ def cpu_baseline(n_full: int, d: int):
 
 
 def pmc_traffic(n: int) -> dict:
-    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes over THIS command
-    (tools/gpu_r4_prof.sh -> profiles/r4/pmc_bench_summary.json; FETCH_SIZE and WRITE_SIZE are reported in KiB and
-    FETCH_SIZE is doubled, the gfx950 correction for 16-B/lane streaming reads of MI355X_MICROARCH.md §HBM).
-    PMC cannot be sampled from inside the timed run, so this is null when the summary is absent or for another N."""
-    path = next((q for q in (ROOT / "profiles" / r / "pmc_bench_summary.json" for r in ("r4", "r3", "r2", "r1")) if q.exists()), ROOT / "nonexistent")
+    """HBM/fabric bytes per launch of the dominant kernel, and its MFMA-pipe occupancy, from the committed rocprofv3 --pmc passes over THIS command
+    (round 5: tools/gpu_r5_final.sh -> profiles/r5/pmc_bench_summary.json, written by tools/pmc_bench_summary.py; FETCH_SIZE and WRITE_SIZE are reported
+    in KiB and FETCH_SIZE is doubled, the gfx950 correction for 16-B/lane streaming reads of MI355X_MICROARCH.md §HBM).  PMC cannot be sampled from inside
+    the timed run, so these are REPLAYED from the file (`source` says which) and null when it is absent or for another N; tests/test_bench_line.py ties the
+    file's launch count to `launches_per_step`."""
+    path = next((q for q in (ROOT / "profiles" / r / "pmc_bench_summary.json" for r in ("r5", "r4", "r3", "r2", "r1")) if q.exists()), ROOT / "nonexistent")
     if n != 65536 or not path.exists():
         return {"traffic": None}
     s = json.loads(path.read_text())
     rd = 2.0 * s["FETCH_SIZE"]["avg"] * 1024.0
     wr = s["WRITE_SIZE"]["avg"] * 1024.0
-    return {"traffic": rd + wr, "traffic_detail": {"unit": "bytes per launch (average over the bench's MFMA GEMM launches)",
-                                                   "read": rd, "write": wr, "source": str(path.relative_to(ROOT))}}
+    out = {"traffic": rd + wr, "traffic_detail": {"unit": "bytes per launch (average over the bench's MFMA GEMM launches)",
+                                                  "read": rd, "write": wr, "source": str(path.relative_to(ROOT))}}
+    g = (s.get("SQ") or {}).get("gemm")
+    if g:  # SQ counters of the same launches: MFMA pipe busy relative to the pure-MFMA kernel of the same pass, effective clock, where the waves' cycles go
+        out["mfma_busy"] = g.get("mfma_busy_vs_pure_mfma_kernel")
+        out["mfma_busy_detail"] = {"definition": "(SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the MFMA GEMM launches) / (the same ratio of gp_bench_mfma_f64's kernel in the same rocprofv3 pass)",
+                                   "clock_ghz": g.get("clock_ghz"), "waves_parked": g.get("waves_parked"), "waves_issue_stall": g.get("waves_issue_stall"),
+                                   "waves_issuing": g.get("waves_issuing"), "source": str(path.relative_to(ROOT))}
+    return out
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak

@@ -101,3 +101,22 @@ def test_param_defaults_macro_covers_every_single_device_parameter():
     getter = src[src.index("int32_t gp_ctx_get_param("):src.index("int32_t gp_ctx_trim(")]
     readable = set(re.findall(r'\{"([a-z0-9_]+)",', getter))
     assert readable == single, (sorted(single - readable), sorted(readable - single))
+
+
+def test_integration_md_build_recipe_names_every_translation_unit_and_flag():
+    """INTEGRATION.md §1 is what a maintainer follows by hand: it lists every translation unit __graft_entry__.build() compiles, with the per-unit flags
+    (round 4's text omitted leaf.hip and its -mllvm -amdgpu-mfma-vgpr-form: a link error for anyone following it)."""
+    from pathlib import Path
+
+    import __graft_entry__ as ge
+
+    txt = (Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    sec = txt[txt.index("## 1. Build"):txt.index("## 2.")]
+    for u in ge.UNITS:
+        line = next((ln for ln in sec.splitlines() if f"-c {u}" in ln), None)
+        assert line, f"INTEGRATION.md §1 does not compile {u}"
+        for flag in ge.UNIT_FLAGS.get(u, []):
+            assert flag in line, (u, flag)
+    link = next(ln for ln in sec.splitlines() if "-shared" in ln)
+    for u in ge.UNITS:
+        assert f"{u}.o" in link, u

@@ -8,7 +8,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-ROUNDS = ("r4", "r3", "r2", "r1")
+ROUNDS = ("r5", "r4", "r3", "r2", "r1")
 
 
 def _latest():
@@ -78,3 +78,22 @@ def test_bench_line_carries_the_parity_checks_and_the_other_configs():
         assert oc[name]["steps"] >= 5 and oc[name]["statistic"] == "median"
     for name in ("mean_and_var_4096", "cov_1024", "sequential_update_8192", "value_and_gradient"):
         assert name in oc["next"], name
+
+
+def test_pmc_summary_counts_whole_passes_of_the_bench():
+    """roofline.traffic / mfma_busy are replayed from profiles/r*/pmc_bench_summary.json (PMC cannot be sampled inside the timed run): the file must come
+    from the SAME launch mix — its launch count is a whole multiple of the line's launches_per_step (round 5 on: every dispatch of the pass is counted)."""
+    r, d = _latest()
+    p = ROOT / "profiles" / r / "pmc_bench_summary.json"
+    if not p.exists():
+        pytest.skip("no committed PMC summary for that round")
+    s = json.loads(p.read_text())
+    lps = int(d["roofline"]["launches_per_step"])
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        n = int(s[ctr]["n"])
+        if r in ("r1", "r2", "r3", "r4"):
+            n += 1  # the summariser of those rounds dropped the first dispatch of the pass
+        assert n >= lps and n % lps == 0, (ctr, n, lps)
+    if "SQ" in s:
+        assert int(s["SQ"]["gemm"]["dispatches"]) % lps == 0
+        assert d["roofline"]["traffic_detail"]["source"].endswith(f"{r}/pmc_bench_summary.json")

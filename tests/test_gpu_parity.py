@@ -6,7 +6,9 @@ var abs <= 1e-9.  fp32: logpdf/ELBO rel <= 1e-4 against the fp64 oracle.
 What the two comparisons are: the committed fixtures tests/golden/*.npz were WRITTEN BY THE ORACLE (tests/golden/make_golden.py imports
 oracle.gp_oracle), so "golden and oracle" is one source seen twice — a regression pin of the oracle's past output plus the oracle's present
 output, not two independent references.  The independent pins live in tests/test_oracle.py (MvNormal, 60-digit mpmath, scikit-learn's
-GaussianProcessRegressor) and, once a maintainer has run tests/golden/make_golden.jl, in tests/test_julia_golden.py (the real AbstractGPs.jl)."""
+GaussianProcessRegressor) and, once a maintainer has run tests/golden/make_golden.jl, in tests/test_julia_golden.py (the real AbstractGPs.jl).
+(The fixture `c1_se_1d_256` is BASELINE config 1's shape — N = 256, D = 1, SE, σ² = 0.01 — with the fixture generator's name-derived seed and
+y = sin(x) + 0.1 ε, not SURVEY.md §8(d)'s literal recipe (seed 1, sin(3x)); `__graft_entry__.smoke()` runs that shape through `synth_inputs(256, 1, 1)`.)"""
 import glob
 from pathlib import Path
 

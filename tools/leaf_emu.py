@@ -138,7 +138,9 @@ def check_p3(rng):
 
 
 def check_p3_rank4(rng):
-    """NOT in the kernel: the same factorisation with ONE MFMA per FOUR columns.  The rows 4p..4p+3 of a sub-block are register p
+    """NOT in the kernel: built and measured in round 5 (`leaf_rank4`, history at 2ba1531: same values, 49 000 instead of 46 800 cycles per 128-column
+    leaf — the two row moves and the per-group multipliers of every column cost what the 24 saved MFMAs gave; profiles/NOTES_r5.md) and removed again.
+    The same factorisation with ONE MFMA per FOUR columns.  The rows 4p..4p+3 of a sub-block are register p
     of the four lane groups, i.e. exactly a K-slot operand, so after the three intra-sub-block recurrences (row k minus its projections on rows
     j < k — each needs row j of ANOTHER lane group: a 16-lane row move, counted here, and one scalar per group) a single MFMA applies the rank-4
     update to the block; the inverse rides the same way.  Returns (|L − chol|, |Inv − L⁻¹|, row moves per block, MFMAs per block)."""
