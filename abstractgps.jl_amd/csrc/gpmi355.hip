@@ -645,7 +645,7 @@ int32_t gpmi::eng_assemble(gp_ctx* c, hipStream_t s, int kind, double variance, 
     (void)c;
     dim3 grid((unsigned)(n_loc / 128), (unsigned)(m_loc / 128));
     if (grid.x == 0 || grid.y == 0) return 0;
-    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d, kind, variance,
+    launch_kmat<double>(grid, s, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d, kind, variance,
                        noise_dev, n_valid, n_valid, 1, g, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
@@ -691,7 +691,7 @@ int32_t gpmi::eng_kcross(gp_ctx* c, hipStream_t s, int kind, double variance, co
     (void)c;
     dim3 grid((unsigned)(nc_pad / 128), (unsigned)(nr_pad / 128));
     if (grid.x == 0 || grid.y == 0) return 0;
-    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, out, ld, xr, ldxr, xc, ldxc, d, kind, variance, (const double*)nullptr, nr_valid,
+    launch_kmat<double>(grid, s, out, ld, xr, ldxr, xc, ldxc, d, kind, variance, (const double*)nullptr, nr_valid,
                        nc_valid, 0, plain_map(0, 0, 0), (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
@@ -760,7 +760,7 @@ template <typename T> static int32_t assemble_sym(gp_ctx* c, const gp_kernel* k,
                                                   const T* noise_dev, long n, long np, T* A, long ld) {
     GridMap g = plain_map(1, 0, 0);
     dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
-    hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, A, ld, xs_dev, ldx, xs_dev, ldx, d, k->kind,
+    launch_kmat<T>(grid, c->sm, A, ld, xs_dev, ldx, xs_dev, ldx, d, k->kind,
                        (T)k->variance, noise_dev, n, n, 1, g, (const T*)nullptr, (const T*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
@@ -952,7 +952,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
                 const long rows = std::min(chunk, nsp - r0);
                 GridMap g = plain_map(0, r0, 0);
                 dim3 grid((unsigned)(np / 128), (unsigned)(rows / 128));
-                hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, X, ldx, (const T*)xs_v, nsp,
+                launch_kmat<T>(grid, c->sm, X, ldx, (const T*)xs_v, nsp,
                                    (const T*)post->xs, np, d, post->kind, (T)post->variance, (const T*)nullptr, ns, n,
                                    0, g, (const T*)nullptr, (const T*)nullptr);
                 HIPCHK(hipGetLastError());
@@ -975,7 +975,7 @@ static int32_t predict_impl(gp_post* post, const gp_points* xs, const void* pm, 
                 T* Cm = (T*)C_v;
                 GridMap g = plain_map(0, 0, 0);
                 dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
-                hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, Cm, ldc, (const T*)xs_v, nsp,
+                launch_kmat<T>(grid, c->sm, Cm, ldc, (const T*)xs_v, nsp,
                                    (const T*)xs_v, nsp, d, post->kind, (T)post->variance, (const T*)nullptr, ns, ns,
                                    0, g, (const T*)nullptr, (const T*)nullptr);
                 HIPCHK(hipGetLastError());
@@ -1165,7 +1165,7 @@ static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* no
         {
             GridMap g = plain_map(0, 0, 0);
             dim3 grid((unsigned)(np1 / 128), (unsigned)(n2p / 128));
-            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, X, ldx, (const T*)x2_v, n2p, (const T*)old->xs, np1, d,
+            launch_kmat<T>(grid, s, X, ldx, (const T*)x2_v, n2p, (const T*)old->xs, np1, d,
                                k.kind, (T)k.variance, (const T*)nullptr, n2, n1, 0, g, (const T*)nullptr, (const T*)nullptr);
             HIPCHK(hipGetLastError());
         }
@@ -1174,7 +1174,7 @@ static int32_t update_impl(gp_post* old, const gp_points* x2, const gp_noise* no
         {
             GridMap g = plain_map(1, 0, 0);
             dim3 grid((unsigned)(n2p / 128), (unsigned)(n2p / 128));
-            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, S, lds, (const T*)x2_v, n2p, (const T*)x2_v, n2p, d,
+            launch_kmat<T>(grid, s, S, lds, (const T*)x2_v, n2p, (const T*)x2_v, n2p, d,
                                k.kind, (T)k.variance, (const T*)nz_v, n2, n2, 1, g, (const T*)nullptr, (const T*)nullptr);
             HIPCHK(hipGetLastError());
         }
@@ -1324,7 +1324,7 @@ static int32_t post_joint(gp_post* post, const gp_points* xs, const void* pm, co
     {
         GridMap g = plain_map(0, 0, 0);
         dim3 grid((unsigned)(np / 128), (unsigned)(nsp / 128));
-        hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, X, ldx, (const T*)xs_v, nsp, (const T*)post->xs, np, d,
+        launch_kmat<T>(grid, s, X, ldx, (const T*)xs_v, nsp, (const T*)post->xs, np, d,
                            post->kind, (T)post->variance, (const T*)nullptr, ns, n, 0, g, (const T*)nullptr, (const T*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -1332,7 +1332,7 @@ static int32_t post_joint(gp_post* post, const gp_points* xs, const void* pm, co
     {
         GridMap g = plain_map(1, 0, 0);
         dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
-        hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, s, Cm, ldc, (const T*)xs_v, nsp, (const T*)xs_v, nsp, d,
+        launch_kmat<T>(grid, s, Cm, ldc, (const T*)xs_v, nsp, (const T*)xs_v, nsp, d,
                            post->kind, (T)post->variance, (const T*)nz_v, ns, ns, 1, g, (const T*)nullptr, (const T*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -1381,7 +1381,7 @@ static int32_t post_joint_dist(gp_post* post, const gp_points* xs, const void* p
     {
         GridMap g = plain_map(1, 0, 0);
         dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
-        hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Cm, ldc, (const double*)xs_v, nsp, (const double*)xs_v, nsp, d, post->kind,
+        launch_kmat<double>(grid, s, Cm, ldc, (const double*)xs_v, nsp, (const double*)xs_v, nsp, d, post->kind,
                            post->variance, (const double*)nz_v, ns, ns, 1, g, (const double*)nullptr, (const double*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -1562,6 +1562,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "sk_max_tiles")) c->sk_max_tiles = v;
     else if (!strcmp(name, "sk_min_k")) c->sk_min_k = v;
     else if (!strcmp(name, "gemm_pipe")) c->gemm_pipe = v != 0;
+    else if (!strcmp(name, "kmat_rows")) g_kmat_rows = v != 0;
     else if (!strcmp(name, "dib_nb")) c->dib_nb = v <= 0 ? 0 : std::min<int64_t>(round_up(std::max<int64_t>(v, 128), 128), 8192);
     else if (!strcmp(name, "gemm_pad_f32")) c->gemm_pad_f32 = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
     else if (!strcmp(name, "gemm_pad_lds")) {
@@ -1606,7 +1607,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
-        {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
+        {"kmat_rows", g_kmat_rows}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {
             *out = e.v;
@@ -1665,7 +1666,7 @@ int32_t gp_kernelmatrix(gp_ctx* c, const gp_kernel* k, const gp_points* x, const
             if (y) HIPCHK(hipMemcpyAsync(xr_v, xr_h.data(), xrb, hipMemcpyHostToDevice, c->sm));
             GridMap g = plain_map(0, 0, 0);
             dim3 grid((unsigned)(np / 128), (unsigned)(mp / 128));
-            hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, c->sm, (T*)K_v, ld, (const T*)(y ? xr_v : xc_v),
+            launch_kmat<T>(grid, c->sm, (T*)K_v, ld, (const T*)(y ? xr_v : xc_v),
                                y ? mp : np, (const T*)xc_v, np, x->d, k->kind, (T)k->variance, (const T*)nullptr, m, n,
                                0, g, (const T*)nullptr, (const T*)nullptr);
             HIPCHK(hipGetLastError());
@@ -2389,7 +2390,7 @@ int32_t gpd_assemble(gp_ctx* c, const gp_kernel* k, const double* x_dev, int64_t
     GridMap m = to_map(g, 0, 0);
     dim3 grid((unsigned)(n_loc / 128), (unsigned)(m_loc / 128));
     if (grid.x == 0 || grid.y == 0) return 0;
-    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, c->sm, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d,
+    launch_kmat<double>(grid, c->sm, a_loc, lda, x_dev, n_pad, x_dev, n_pad, d,
                        k->kind, k->variance, noise_dev, n_valid, n_valid, 1, m, (const double*)nullptr, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;

@@ -23,6 +23,7 @@
 #define GPMI_ABL 0  // ablation switches of tools/gemm_ablate.hip (timing experiments only; 0 in the product build)
 #endif
 #include <stdint.h>
+#include <type_traits>
 #include "kcommon.hpp"
 
 namespace gpmi {
@@ -558,7 +559,7 @@ template <typename T> __device__ __forceinline__ T kappa(int kind, T d2) {
     return (T(1) + a + T(5.0 / 3.0) * d2) * exp_nonpos<T>(-a);
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, int DR>  // DR = 4 / 8 / 16: D <= DR, row-by-row form; 0: any D
 __device__ __forceinline__ void kmat_body(T (*xi)[128], T (*xj)[128], T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
                                                     const T* __restrict__ xc, long ldxc, int d, T variance,
                                                     const T* __restrict__ noise, long nr_valid, long nc_valid, int sym,
@@ -572,7 +573,90 @@ __device__ __forceinline__ void kmat_body(T (*xi)[128], T (*xj)[128], T* __restr
     if (g.lower && gc0 > gr0 + 127) return;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long gj0 = gc0 + 2 * lane, gj1 = gj0 + 1;
+    // interior tiles (no padding, not on the diagonal, no row/column scaling): nothing but κ and the 1 KiB row stores
+    const bool interior = gr0 + 128 <= nr_valid && gc0 + 128 <= nc_valid && !(sym && gr0 == gc0) && colscale == nullptr && rowscale == nullptr;
+    auto emit_interior = [&](int rr, T a0, T a1) {
+        pair_t o;
+        o.x = variance * kappa<T>(KIND, a0);
+        o.y = variance * kappa<T>(KIND, a1);
+        *reinterpret_cast<pair_t*>(out + (long)(m0 + w + 4 * rr) * ld + n0 + 2 * lane) = o;
+    };
+    auto emit_edge = [&](int rr, T a0, T a1) {  // padding (identity when sym), the noise on the global diagonal, row / column scaling
+        const int row = w + 4 * rr;
+        const long gi = gr0 + row;
+        T v0, v1;
+        if (gi >= nr_valid) {
+            v0 = (sym && gi == gj0) ? T(1) : T(0);
+            v1 = (sym && gi == gj1) ? T(1) : T(0);
+        } else {
+            v0 = (gj0 < nc_valid) ? variance * kappa<T>(KIND, a0) : T(0);
+            v1 = (gj1 < nc_valid) ? variance * kappa<T>(KIND, a1) : T(0);
+            if (sym && noise != nullptr) {
+                if (gi == gj0) v0 += noise[gi];
+                if (gi == gj1) v1 += noise[gi];
+            }
+            if (colscale != nullptr) {
+                if (gj0 < nc_valid) v0 *= colscale[gj0];
+                if (gj1 < nc_valid) v1 *= colscale[gj1];
+            }
+            if (rowscale != nullptr) {
+                const T rs = rowscale[gi];
+                v0 *= rs;
+                v1 *= rs;
+            }
+        }
+        pair_t o;
+        o.x = v0;
+        o.y = v1;
+        *reinterpret_cast<pair_t*>(out + (long)(m0 + row) * ld + n0 + 2 * lane) = o;
+    };
 
+    if constexpr (DR != 0) {
+        // D <= DR (one staged chunk; one kernel instance per DR so that the register count is this path's): row by row — distance, κ, store — with
+        // nothing but this lane's two columns of the inputs held in registers (85 / 101 / 133 VGPRs for DR = 4 / 8 / 16 in fp64).  The accumulate form
+        // below keeps all 64 squared distances of a thread live across the dimension chunks (162 VGPRs: three waves per SIMD); its counters (round 5,
+        // N = 32 768: VALU issuing 31 % of a wave's cycles, 36 % issue-stalled, 28 % parked; 35 VALU instructions per element) say the Gram kernel is bound
+        // by what three waves can issue, not by its stores (the same 1 KiB row stores alone: 5.6–5.7 TB/s, tools/kmat_probe.hip).  Same-box A/B
+        // ("kmat_rows", profiles/r5/sweep_kmat_rows.txt): C2 0.277 vs 0.291 ms, C3 (D = 8) 1.34 vs 1.42, C4 3.72 vs 3.75 — the large matrix is not limited by
+        // occupancy either; what holds the C4 launch at 4.6 TB/s is where it sits: it is the first heavy kernel after the previous fit's latency-bound tail
+        // (tools/kmat_repeat.py: 4.04 TB/s cold, 4.95 after five back-to-back launches).
+        for (int e = tid; e < DR * 128; e += 256) {  // rows d..DR-1 zero: the unrolled loops below need no predicate
+            const int dd = e >> 7, i = e & 127;
+            xi[dd][i] = dd < d ? xr[(long)dd * ldxr + gr0 + i] : T(0);
+            xj[dd][i] = dd < d ? xc[(long)dd * ldxc + gc0 + i] : T(0);
+        }
+        __syncthreads();
+        pair_t yv[DR];
+#pragma unroll
+        for (int dd = 0; dd < DR; ++dd) yv[dd] = *reinterpret_cast<const pair_t*>(&xj[dd][2 * lane]);
+        auto dist = [&](int rr, T& a0, T& a1) {
+            a0 = T(0);
+            a1 = T(0);
+#pragma unroll
+            for (int dd = 0; dd < DR; ++dd) {
+                const T xv = xi[dd][w + 4 * rr];
+                const T t0 = xv - yv[dd].x, t1 = xv - yv[dd].y;
+                a0 = fma(t0, t0, a0);
+                a1 = fma(t1, t1, a1);
+            }
+        };
+        if (interior) {
+#pragma unroll 2
+            for (int rr = 0; rr < 32; ++rr) {
+                T a0, a1;
+                dist(rr, a0, a1);
+                emit_interior(rr, a0, a1);
+            }
+        } else {
+            for (int rr = 0; rr < 32; ++rr) {
+                T a0, a1;
+                dist(rr, a0, a1);
+                emit_edge(rr, a0, a1);
+            }
+        }
+        return;
+    } else {
     T acc0[32], acc1[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc0[i] = acc1[i] = T(0);
@@ -597,65 +681,47 @@ __device__ __forceinline__ void kmat_body(T (*xi)[128], T (*xj)[128], T* __restr
             }
         }
     }
-    const long gj0 = gc0 + 2 * lane, gj1 = gj0 + 1;
-    // interior tiles (no padding, not on the diagonal, no row/column scaling): nothing but κ and the 1 KiB row stores
-    if (gr0 + 128 <= nr_valid && gc0 + 128 <= nc_valid && !(sym && gr0 == gc0) && colscale == nullptr && rowscale == nullptr) {
+    if (interior) {
 #pragma unroll
-        for (int rr = 0; rr < 32; ++rr) {
-            pair_t o;
-            o.x = variance * kappa<T>(KIND, acc0[rr]);
-            o.y = variance * kappa<T>(KIND, acc1[rr]);
-            *reinterpret_cast<pair_t*>(out + (long)(m0 + w + 4 * rr) * ld + n0 + 2 * lane) = o;
-        }
+        for (int rr = 0; rr < 32; ++rr) emit_interior(rr, acc0[rr], acc1[rr]);
         return;
     }
 #pragma unroll
-    for (int rr = 0; rr < 32; ++rr) {
-        const int row = w + 4 * rr;
-        const long gi = gr0 + row;
-        T v0, v1;
-        if (gi >= nr_valid) {
-            v0 = (sym && gi == gj0) ? T(1) : T(0);
-            v1 = (sym && gi == gj1) ? T(1) : T(0);
-        } else {
-            v0 = (gj0 < nc_valid) ? variance * kappa<T>(KIND, acc0[rr]) : T(0);
-            v1 = (gj1 < nc_valid) ? variance * kappa<T>(KIND, acc1[rr]) : T(0);
-            if (sym && noise != nullptr) {
-                if (gi == gj0) v0 += noise[gi];
-                if (gi == gj1) v1 += noise[gi];
-            }
-            if (colscale != nullptr) {
-                if (gj0 < nc_valid) v0 *= colscale[gj0];
-                if (gj1 < nc_valid) v1 *= colscale[gj1];
-            }
-            if (rowscale != nullptr) {
-                const T rs = rowscale[gi];
-                v0 *= rs;
-                v1 *= rs;
-            }
-        }
-        pair_t o;
-        o.x = v0;
-        o.y = v1;
-        *reinterpret_cast<pair_t*>(out + (long)(m0 + row) * ld + n0 + 2 * lane) = o;
+    for (int rr = 0; rr < 32; ++rr) emit_edge(rr, acc0[rr], acc1[rr]);
     }
 }
 
-// runtime kernel kind -> compile-time specialisation (the κ branch is hoisted out of the 64-element inner loops)
-template <typename T>
+// runtime kernel kind -> compile-time specialisation (the κ branch is hoisted out of the 64-element inner loops).  DR = 4 / 8 / 16: D <= DR, the
+// row-by-row form (few registers, high occupancy: one kernel instance per DR so that each gets its own register count); 0: any D, squared
+// distances accumulated over chunks of 16 dimensions.  launch_kmat picks.
+template <typename T, int DR>
 __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld, const T* __restrict__ xr, long ldxr,
                                                     const T* __restrict__ xc, long ldxc, int d, int kind, T variance,
                                                     const T* __restrict__ noise, long nr_valid, long nc_valid, int sym,
                                                     GridMap g, const T* __restrict__ colscale,
                                                     const T* __restrict__ rowscale) {
-    __shared__ T xi[16][128];
-    __shared__ __attribute__((aligned(16))) T xj[16][128];
+    constexpr int LR = DR != 0 ? DR : 16;  // staged dimensions per chunk
+    __shared__ T xi[LR][128];
+    __shared__ __attribute__((aligned(16))) T xj[LR][128];
     switch (kind) {
-        case 0: kmat_body<T, 0>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
-        case 1: kmat_body<T, 1>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
-        case 2: kmat_body<T, 2>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
-        default: kmat_body<T, 3>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        case 0: kmat_body<T, 0, DR>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        case 1: kmat_body<T, 1, DR>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        case 2: kmat_body<T, 2, DR>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
+        default: kmat_body<T, 3, DR>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
     }
+}
+static int g_kmat_rows = 1;  // 1: the row-by-row instances for D <= 16; 0: always the accumulate form (A/B switch: ctx parameter "kmat_rows")
+template <typename T>
+static inline void launch_kmat(dim3 grid, hipStream_t s, T* out, long ld, const T* xr, long ldxr, const T* xc, long ldxc, int d, int kind, T variance,
+                               const T* noise, long nr_valid, long nc_valid, int sym, GridMap g, const T* colscale, const T* rowscale) {
+#define GPMI_KMAT_LAUNCH(DR_) \
+    hipLaunchKernelGGL((kmat_kernel<T, DR_>), grid, dim3(256), 0, s, out, ld, xr, ldxr, xc, ldxc, d, kind, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale)
+    if (!g_kmat_rows) GPMI_KMAT_LAUNCH(0);
+    else if (d <= 4) GPMI_KMAT_LAUNCH(4);
+    else if (d <= 8) GPMI_KMAT_LAUNCH(8);
+    else if (d <= 16) GPMI_KMAT_LAUNCH(16);
+    else GPMI_KMAT_LAUNCH(0);
+#undef GPMI_KMAT_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -206,7 +206,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     auto kmat_chunk = [&](const ObsSeg& sg, long c0, int bb) -> int32_t {
         GridMap g = plain_map(0, c0, 0);
         dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
-        hipLaunchKernelGGL(kmat_kernel<T>, grid, dim3(256), 0, sa, (T*)Xb[bb], ld, (const T*)sg.xs, sg.npad, (const T*)zsT_v, mp, d,
+        launch_kmat<T>(grid, sa, (T*)Xb[bb], ld, (const T*)sg.xs, sg.npad, (const T*)zsT_v, mp, d,
                            k->kind, (T)k->variance, (const T*)nullptr, sg.n, m, 0, g, (const T*)nullptr, (const T*)sg.rs);
         HIPCHK(hipGetLastError());
         if (ovl) {
@@ -317,7 +317,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 // ---- L_z = chol(K_zz + jitter I), fp64                                                :62
                 GridMap g = plain_map(1, 0, 0);
                 dim3 grid((unsigned)(mp / 128), (unsigned)(mp / 128));
-                hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Lz, ld, (const double*)zsD_v, mp,
+                launch_kmat<double>(grid, s, Lz, ld, (const double*)zsD_v, mp,
                                    (const double*)zsD_v, mp, d, k->kind, k->variance, (const double*)jit_v, m, m, 1, g,
                                    (const double*)nullptr, (const double*)nullptr);
                 HIPCHK(hipGetLastError());
@@ -339,7 +339,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 {
                     GridMap g = plain_map(0, 0, 0);
                     dim3 grid((unsigned)(mpo / 128), (unsigned)(m2p / 128));
-                    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Xb, ldx, (const double*)znD_v, m2p,
+                    launch_kmat<double>(grid, s, Xb, ldx, (const double*)znD_v, m2p,
                                        (const double*)prev->zs, mpo, d, k->kind, k->variance, (const double*)nullptr, m2, m_old, 0, g,
                                        (const double*)nullptr, (const double*)nullptr);
                     HIPCHK(hipGetLastError());
@@ -349,7 +349,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                     GridMap g = plain_map(1, 0, 0);
                     dim3 grid((unsigned)(m2p / 128), (unsigned)(m2p / 128));
                     // C22 = _symmetric(cov(prior, z_new)) carries NO jitter in the reference (src/sparse_approximations.jl:138)
-                    hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Sb, lds, (const double*)znD_v, m2p,
+                    launch_kmat<double>(grid, s, Sb, lds, (const double*)znD_v, m2p,
                                        (const double*)znD_v, m2p, d, k->kind, k->variance, (const double*)nullptr, m2, m2, 1, g,
                                        (const double*)nullptr, (const double*)nullptr);
                     HIPCHK(hipGetLastError());
@@ -530,7 +530,7 @@ static int32_t vfe_joint(gp_vfe* p, const gp_points* xs, const void* pm, const g
     {
         GridMap g = plain_map(0, 0, 0);
         dim3 grid((unsigned)(mp / 128), (unsigned)(nsp / 128));
-        hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, X1, ld, (const double*)xs_v, nsp, (const double*)p->zs, mp, d,
+        launch_kmat<double>(grid, s, X1, ld, (const double*)xs_v, nsp, (const double*)p->zs, mp, d,
                            p->kind, p->variance, (const double*)nullptr, ns, m, 0, g, (const double*)nullptr, (const double*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -546,7 +546,7 @@ static int32_t vfe_joint(gp_vfe* p, const gp_points* xs, const void* pm, const g
     {
         GridMap g = plain_map(1, 0, 0);
         dim3 grid((unsigned)(nsp / 128), (unsigned)(nsp / 128));
-        hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, Cm, ldc, (const double*)xs_v, nsp, (const double*)xs_v, nsp, d,
+        launch_kmat<double>(grid, s, Cm, ldc, (const double*)xs_v, nsp, (const double*)xs_v, nsp, d,
                            p->kind, p->variance, (const double*)nz_v, ns, ns, 1, g, (const double*)nullptr, (const double*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -620,7 +620,7 @@ static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, 
         if (what & 2) {  // var = k** − ‖A‖²_col + ‖Λ_ε.U⁻ᵀ A‖²_col, Aᵀ = K_*z L_z⁻ᵀ                 :192-195
             GridMap g = plain_map(0, 0, 0);
             dim3 grid((unsigned)(mp / 128), (unsigned)(nsp / 128));
-            hipLaunchKernelGGL(kmat_kernel<double>, grid, dim3(256), 0, s, X, ld, (const double*)xs_v, nsp,
+            launch_kmat<double>(grid, s, X, ld, (const double*)xs_v, nsp,
                                (const double*)p->zs, mp, d, p->kind, p->variance, (const double*)nullptr, ns, m, 0, g,
                                (const double*)nullptr, (const double*)nullptr);
             HIPCHK(hipGetLastError());

@@ -169,6 +169,8 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    pipelined k loop; with "gemm_pipe" = 0 one workgroup per CU, 20480, was 5 % faster)   default 0
  *   "gemm_pipe"      k loop of the MFMA GEMMs software-pipelined across the step boundary (csrc/kernels.hpp gemm_kloop_pipe: the fragments of
  *                    the next half-step are in registers before the barrier, operand DMA issued between MFMAs); 0 = the round-2 loop   default 1
+ *   "kmat_rows"      Gram tiles row by row (distance, κ, store; one kernel instance per dimension bucket D <= 4 / 8 / 16, few registers) instead of
+ *                    all 64 squared distances of a thread accumulated first (the form D > 16 always takes); process-wide   default 1
  *   "dib_nb"         forward solves X L⁻ᵀ against a resident factor (predictive variances / covariances, held-out logpdf, sampling, sequential
  *                    conditioning, the gradient's L⁻ᵀ): column blocks of at most this width are solved by ONE triangular-k MFMA GEMM with the
  *                    explicit inverse of the diagonal block — built once per posterior handle (np × (dib_nb + 32) elements, 3 % of the factor at
@@ -193,7 +195,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
     "nb=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
     "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=0,gemm_pad_lds=0,trsv_nb=256,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
     "updk_max_k=512,updk_rt=0,updk_tall_k=256,updk_tall_m=8192,upd128=1,leaf_group=128,ldpad=32,vfe_ks=2048,vfe_sk=0,"          \
-    "vfe_overlap=1,vfe_chunk=16384,dib_nb=2048,pool_cap_mb=98304"
+    "vfe_overlap=1,vfe_chunk=16384,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Read a parameter back (same names; "gemm_pad_lds" reads 0 until it has been set explicitly).  Used by the test-suite to assert that
  * every GPU test starts from the documented defaults. */

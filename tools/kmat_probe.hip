@@ -46,6 +46,34 @@ __global__ __launch_bounds__(256) void fill_tiles(double* __restrict__ out, long
     }
 }
 
+
+// other tile shapes with the same 16 384 elements per workgroup: TR rows × TC columns (TC a multiple of 128); wave w owns rows w, w+4, ..; a row of
+// the tile is TC/128 store instructions of 1 KiB each (contiguous) — fewer distinct rows (DRAM pages, TLB entries) per workgroup, longer bursts
+template <int TR, int TC, int V>
+__global__ __launch_bounds__(256) void fill_shape(double* __restrict__ out, long ld, long n, double seed) {
+    const long tcols = n / TC;
+    // lower trapezoid in units of this shape: tile (bi, bj) is written when its first column is <= its last row
+    const long bi = blockIdx.y, bj = blockIdx.x;
+    const long m0 = bi * TR, n0 = bj * TC;
+    if (n0 > m0 + TR - 1 || bj >= tcols) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double a = seed + lane * 1e-3, b = seed - w * 1e-3;
+    for (int rr = 0; rr < TR / 4; ++rr) {
+#pragma unroll
+        for (int cs = 0; cs < TC / 128; ++cs) {
+            d2_t o;
+            o.x = a + rr + cs;
+            o.y = b - rr - cs;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                o.x = fma(o.x, 0.999999, 1e-7);
+                o.y = fma(o.y, 0.999999, 1e-7);
+            }
+            *reinterpret_cast<d2_t*>(out + (m0 + w + 4 * rr) * ld + n0 + 128 * cs + 2 * lane) = o;
+        }
+    }
+}
+
 // whole rows of the lower triangle: row r has r + 1 elements, rounded up to its 128-column tile boundary; one workgroup per 4 rows
 __global__ __launch_bounds__(256) void fill_rows(double* __restrict__ out, long ld, long n, double seed, int nt) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -67,6 +95,7 @@ int main(int argc, char** argv) {
     const long ld = n + 32;
     const long tiles = (n / 128) * (n / 128 + 1) / 2;
     const double bytes = (double)tiles * 128 * 128 * 8;
+    double launch_bytes = 0;  // != 0: bytes of the shape being timed
     double* A;
     CK(hipMalloc(&A, sizeof(double) * (size_t)n * ld));
     hipEvent_t e0, e1;
@@ -85,7 +114,8 @@ int main(int argc, char** argv) {
             (void)hipEventElapsedTime(&ms, e0, e1);
             best = ms < best ? ms : best;
         }
-        printf("{\"n\": %ld, \"case\": \"%s\", \"ms\": %.4f, \"GBps\": %.1f}\n", n, name, best, bytes / (best * 1e-3) / 1e9);
+        const double bb = launch_bytes > 0 ? launch_bytes : bytes;
+        printf("{\"n\": %ld, \"case\": \"%s\", \"ms\": %.4f, \"GBps\": %.1f}\n", n, name, best, bb / (best * 1e-3) / 1e9);
     };
     const dim3 g((unsigned)tiles), blk(256);
     time_it("tiles_plain", [&] { hipLaunchKernelGGL((fill_tiles<0, 0>), g, blk, 0, 0, A, ld, 1.0); });
@@ -93,6 +123,21 @@ int main(int argc, char** argv) {
     time_it("tiles_plain_valu16", [&] { hipLaunchKernelGGL((fill_tiles<2, 16>), g, blk, 0, 0, A, ld, 1.0); });
     time_it("tiles_plain_valu32", [&] { hipLaunchKernelGGL((fill_tiles<2, 32>), g, blk, 0, 0, A, ld, 1.0); });
     time_it("tiles_plain_valu48", [&] { hipLaunchKernelGGL((fill_tiles<2, 48>), g, blk, 0, 0, A, ld, 1.0); });
+    {
+        auto shape = [&](const char* name, auto kern, int TR, int TC) {
+            const dim3 gs((unsigned)(n / TC), (unsigned)(n / TR));
+            // bytes actually written by this shape (tiles crossing the diagonal are written whole)
+            double by = 0;
+            for (long bi = 0; bi < n / TR; ++bi) by += (double)((bi * TR + TR - 1) / TC + 1) * TR * TC * 8.0;
+            launch_bytes = by;
+            time_it(name, [&] { hipLaunchKernelGGL(kern, gs, blk, 0, 0, A, ld, n, 1.0); });
+            launch_bytes = 0;
+        };
+        shape("shape_64x256_valu32", fill_shape<64, 256, 32>, 64, 256);
+        shape("shape_32x512_valu32", fill_shape<32, 512, 32>, 32, 512);
+        shape("shape_16x1024_valu32", fill_shape<16, 1024, 32>, 16, 1024);
+        shape("shape_32x512_valu0", fill_shape<32, 512, 0>, 32, 512);
+    }
     time_it("rows_plain", [&] { hipLaunchKernelGGL(fill_rows, dim3((unsigned)((n + 3) / 4)), blk, 0, 0, A, ld, n, 1.0, 0); });
     time_it("rows_nontemporal", [&] { hipLaunchKernelGGL(fill_rows, dim3((unsigned)((n + 3) / 4)), blk, 0, 0, A, ld, n, 1.0, 1); });
     {
