@@ -32,6 +32,7 @@ struct GridMap {
                      // 2: A is upper triangular from row ktri_off on: the k loop of row tile m0 starts at column max(0, m0 − ktri_off)
     int nbatch;      // > 1: blockIdx.z = b selects an independent product over the k range [b·K, (b+1)·K) of A and B,
     long cstride;    //      written to C + b·cstride (split-K partial products of one SYRK, summed by the caller)
+    long astride, bstride;  // != 0 with nbatch > 1: independent products instead — A + b·astride, B + b·bstride, the full k range each
     int ktri_off;    // ktri == 1 with A pointing at row ktri_off of the triangular matrix: row tile m0 stops at ktri_off + m0 + 128
                      // ktri == 2: rows [0, ktri_off) of A are dense, the upper-triangular block starts at row ktri_off (row tile m0 > ktri_off starts at column m0 − ktri_off)
 };

@@ -292,6 +292,8 @@ GridMap gpmi::plain_map(int lower, long row0, long col0) {
     g.ktri = 0;
     g.nbatch = 1;
     g.cstride = 0;
+    g.astride = 0;
+    g.bstride = 0;
     g.ktri_off = 0;
     return g;
 }
@@ -488,6 +490,21 @@ static int32_t dib_build(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np
     dib_ranges(0, np, nbi, blocks);
     HIPCHK(hipMemsetAsync(Iw, 0, sizeof(T) * (size_t)(np + 128) * ldw, s));
     HIPCHK(hipMemsetAsync(W, 0, sizeof(T) * (size_t)(np + 128) * ldw, s));
+    bool uniform = blocks.size() > 1;
+    for (const auto& b : blocks) uniform = uniform && b.second == blocks[0].second;
+    if (uniform) {  // equal blocks (np a power-of-two multiple of the block): the whole batch per launch
+        const long n = blocks[0].second, nb = (long)blocks.size(), xs = n * ldw, ls = n * ldl + n;
+        hipLaunchKernelGGL(diag_ones_kernel<T>, dim3((unsigned)((n + 255) / 256), (unsigned)nb), dim3(256), 0, s, Iw, ldw, n, xs);
+        HIPCHK(hipGetLastError());
+        RC(trsm_upper_rec_batched<T>(c, s, Iw, ldw, L, ldl, 0, n, nb, xs, ls));
+        hipLaunchKernelGGL(transpose_scale_kernel<T>, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), (unsigned)nb), dim3(256), 0, s, (const T*)Iw, ldw,
+                           W, ldw, n, T(-1), xs, xs);
+        HIPCHK(hipGetLastError());
+        if (up)
+            for (const auto& b : blocks)
+                HIPCHK(hipMemcpy2DAsync(up + b.first * ldu + b.first, sizeof(T) * ldu, Iw + b.first * ldw, sizeof(T) * ldw, sizeof(T) * n, n, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     for (const auto& b : blocks) {
         const long j0 = b.first, n = b.second;
         T* Ib = Iw + j0 * ldw;
@@ -499,6 +516,29 @@ static int32_t dib_build(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np
         HIPCHK(hipGetLastError());
         if (up) HIPCHK(hipMemcpy2DAsync(up + j0 * ldu + j0, sizeof(T) * ldu, Ib, sizeof(T) * ldw, sizeof(T) * n, n, hipMemcpyDeviceToDevice, s));
     }
+    return 0;
+}
+
+// The restricted-row recursion of trsm_upper_rec for `nb` equal blocks at once (block b: X + b·xs against L + b·ls): every launch of the recursion
+// carries the whole batch (trsm64 leaves: grid.y; GEMMs: grid.z with independent operand strides), so the inverse blocks of a factor cost the ≈ 63
+// launches of ONE 2 048-column block instead of N/2 048 times that (C4: 32 × 0.6 ms of serial chains -> ≈ 1 ms).
+template <typename T>
+static int32_t trsm_upper_rec_batched(gp_ctx* c, hipStream_t s, T* X, long ldx, const T* L, long ldl, long j0, long n, long nb, long xs, long ls) {
+    if (n <= 64) {
+        hipLaunchKernelGGL(trsm64_mfma_kernel<T>, dim3((unsigned)((j0 + 64 + 127) / 128), (unsigned)nb), dim3(256), 0, s, X + j0, ldx, (int)(j0 + 64),
+                           L + j0 * ldl + j0, ldl, xs, ls);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const long h = split_half(n);
+    RC(trsm_upper_rec_batched<T>(c, s, X, ldx, L, ldl, j0, h, nb, xs, ls));
+    GridMap g = plain_map(0, 0, 0);
+    g.nbatch = (int)nb;
+    g.cstride = xs;
+    g.astride = xs;
+    g.bstride = ls;
+    RC(launch_gemm<T>(c, s, X + j0 + h, ldx, X + j0, ldx, L + (j0 + h) * ldl + j0, ldl, j0 + h, n - h, h, g));
+    RC(trsm_upper_rec_batched<T>(c, s, X, ldx, L, ldl, j0 + h, n - h, nb, xs, ls));
     return 0;
 }
 
@@ -1036,11 +1076,25 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         // GEMM over-reads need defined values (until round 5 both N×N blocks were zeroed first: 2 × 34 GB of writes at C4)
         HIPCHK(hipMemsetAsync(W + np * ld, 0, sizeof(T) * (size_t)128 * ld, s));
         HIPCHK(hipMemsetAsync(Ci + np * ld, 0, sizeof(T) * (size_t)128 * ld, s));
-        // (the inverse-diagonal-block leaves of the predictive solves do not pay here — measured: C2 93.0 -> 95.6 ms, C4 4.71 -> 4.72 s: for the
-        //  identity right-hand side the serial chain that builds the blocks costs what the leaves it replaces cost)
         hipLaunchKernelGGL(identity_kernel<T>, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, s, W, ld, np);
         HIPCHK(hipGetLastError());
-        RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np));                 // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
+        if (c->dib_nb >= 128 && np >= 2 * c->dib_nb) {
+            // L⁻ᵀ with the inverse diagonal blocks: dib_build (batched: one launch sequence for all blocks) writes L_bb⁻ᵀ onto W's diagonal and −L_bb⁻¹
+            // into Wn; a leaf of the recursion is then ONE triangular-k GEMM over the rows above its block.  (With the blocks built one after the
+            // other this did not pay — C2 93.0 -> 95.6 ms, C4 4.71 -> 4.72 s: the serial chains cost what the leaves they replaced cost.)
+            const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
+            const size_t wb = sizeof(T) * (size_t)(np + 128) * ldw;
+            void *Wn_v = 0, *Iw_v = 0, *S_v = 0;
+            RC(bufs.get(wb, &Wn_v));
+            RC(bufs.get(wb, &Iw_v));
+            RC(bufs.get(wb, &S_v));
+            RC(dib_build<T>(c, s, (const T*)post.A, ld, np, nbi, (T*)Wn_v, ldw, (T*)Iw_v, W, ld));
+            DibArgs<T> dib;
+            dib.W = (const T*)Wn_v; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = ldw;
+            RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np, dib));
+        } else {
+            RC(trsm_upper_rec<T>(c, s, W, ld, (const T*)post.A, ld, 0, np));             // W = I L⁻ᵀ = L⁻ᵀ (upper, row-major)
+        }
         {
             GridMap gw = plain_map(1, 0, 0);
             gw.ktri = 2;                                                                   // W upper: k starts at the row tile

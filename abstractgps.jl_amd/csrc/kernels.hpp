@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     }
     if (g.nbatch > 1) {
         C += (long)blockIdx.z * g.cstride;
-        A += (long)blockIdx.z * K;
-        B += (long)blockIdx.z * K;
+        A += (long)blockIdx.z * (g.astride ? g.astride : (long)K);  // astride / bstride = 0: split-K (the k range [z·K, (z+1)·K) of both operands)
+        B += (long)blockIdx.z * (g.bstride ? g.bstride : (long)K);
     }
     const int m0 = bi * 128, n0 = bj * 128;
     long gr0 = 0, gc0 = 0;
@@ -1325,7 +1325,10 @@ __global__ __launch_bounds__(256) void panel64_kernel(T* __restrict__ A, long ld
 //   in panel64_kernel.  M multiple of 64.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void trsm64_mfma_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L, long ldl) {
+__global__ __launch_bounds__(256) void trsm64_mfma_kernel(T* __restrict__ X, long ldx, int M, const T* __restrict__ L, long ldl, long xstride = 0,
+                                                           long lstride = 0) {  // blockIdx.y = b: an independent solve on X + b·xstride against L + b·lstride
+    X += (long)blockIdx.y * xstride;
+    L += (long)blockIdx.y * lstride;
     using TR = Tr<T>;
     using chunk_t = typename TR::chunk_t;
     using acc_t = typename TR::acc_t;
@@ -1834,7 +1837,10 @@ __global__ __launch_bounds__(256) void add_lower_to_f64_kernel(const T* __restri
 // dst[j][i] = scale · src[i][j] for an n×n block (n multiple of 32): 32×32 tiles through LDS; the inverse diagonal blocks of a factor
 // (L_bb⁻ᵀ upper, row-major -> −L_bb⁻¹ lower, row-major: the B operand of the triangular-k GEMM that replaces a TRSM leaf)
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_scale_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long n, T scale) {
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd, long n, T scale,
+                                                               long sstride = 0, long dstride = 0) {  // blockIdx.z = b: block b of a batch
+    src += (long)blockIdx.z * sstride;
+    dst += (long)blockIdx.z * dstride;
     __shared__ T tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long i0 = (long)blockIdx.y * 32, j0 = (long)blockIdx.x * 32;
@@ -1871,6 +1877,12 @@ __global__ __launch_bounds__(256) void diag_shift_trace_kernel(double* __restric
     if (threadIdx.x == 0 && out) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 // A = I (n×n, leading dimension lda)
+// A[b·stride + i·lda + i] = 1 for i < n, b < gridDim.y (the diagonals of a batch of n×n blocks in a zeroed buffer)
+template <typename T>
+__global__ __launch_bounds__(256) void diag_ones_kernel(T* __restrict__ A, long lda, long n, long stride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[(long)blockIdx.y * stride + i * lda + i] = T(1);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void identity_kernel(T* __restrict__ A, long lda, long n) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
