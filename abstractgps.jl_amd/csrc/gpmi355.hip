@@ -550,8 +550,23 @@ static int32_t trsm_post(gp_post* post, hipStream_t s, T* X, long ldx, long M, D
     const long np = post->np, ld = post->ld;
     const T* A = (const T*)post->A;
     if (M <= 0) return 0;
-    if (c->dib_nb < 128 || np < c->dib_nb) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
+    if (c->dib_nb < 128 || np < c->dib_nb || post->dib_nbi < 0) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
     const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
+    if (!post->dib) {
+        // guard: a product with an explicit inverse carries an error of order cond(L_bb)·ε where substitution is backward stable.  max / min of the
+        // factor's diagonal bounds cond(L) from below; beyond 1e5 (cond(K + Σy) >= 1e10: interpolation-style fits with vanishing noise) this handle
+        // keeps the recursion with substitution leaves for good (dib_nbi = −1)
+        RC(ctx_scal(c, 16));
+        hipLaunchKernelGGL(diag_minmax_kernel<T>, dim3(1), dim3(1024), 0, s, A, ld, post->n, c->scal_dev + 6);
+        HIPCHK(hipGetLastError());
+        double mm[2] = {1.0, 1.0};
+        HIPCHK(hipMemcpyAsync(mm, c->scal_dev + 6, sizeof(mm), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!(mm[0] > 0.0) || mm[1] / mm[0] > 1e5) {
+            post->dib_nbi = -1;
+            return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
+        }
+    }
     const size_t wb = sizeof(T) * (size_t)(np + 128) * ldw;
     if (!post->dib || post->dib_nbi != nbi) {
         if (post->dib) ctx_release(c, post->dib, post->dib_bytes);

@@ -618,9 +618,8 @@ __device__ __forceinline__ void kmat_body(T (*xi)[128], T (*xj)[128], T* __restr
         // below keeps all 64 squared distances of a thread live across the dimension chunks (162 VGPRs: three waves per SIMD); its counters (round 5,
         // N = 32 768: VALU issuing 31 % of a wave's cycles, 36 % issue-stalled, 28 % parked; 35 VALU instructions per element) say the Gram kernel is bound
         // by what three waves can issue, not by its stores (the same 1 KiB row stores alone: 5.6–5.7 TB/s, tools/kmat_probe.hip).  Same-box A/B
-        // ("kmat_rows", profiles/r5/sweep_kmat_rows.txt): C2 0.277 vs 0.291 ms, C3 (D = 8) 1.34 vs 1.42, C4 3.72 vs 3.75 — the large matrix is not limited by
-        // occupancy either; what holds the C4 launch at 4.6 TB/s is where it sits: it is the first heavy kernel after the previous fit's latency-bound tail
-        // (tools/kmat_repeat.py: 4.04 TB/s cold, 4.95 after five back-to-back launches).
+        // ("kmat_rows"): launch_kmat below.  What holds the C4 launch at 4.6 TB/s is where it sits: it is the first heavy kernel after the previous fit's
+        // latency-bound tail (tools/kmat_repeat.py: 4.04 TB/s cold, 4.95 after five back-to-back launches).
         for (int e = tid; e < DR * 128; e += 256) {  // rows d..DR-1 zero: the unrolled loops below need no predicate
             const int dd = e >> 7, i = e & 127;
             xi[dd][i] = dd < d ? xr[(long)dd * ldxr + gr0 + i] : T(0);
@@ -716,7 +715,12 @@ static inline void launch_kmat(dim3 grid, hipStream_t s, T* out, long ld, const 
                                const T* noise, long nr_valid, long nc_valid, int sym, GridMap g, const T* colscale, const T* rowscale) {
 #define GPMI_KMAT_LAUNCH(DR_) \
     hipLaunchKernelGGL((kmat_kernel<T, DR_>), grid, dim3(256), 0, s, out, ld, xr, ldxr, xc, ldxc, d, kind, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale)
-    if (!g_kmat_rows) GPMI_KMAT_LAUNCH(0);
+    // Which form: alternating A/B inside fits on one box (tools/kmat_ab.py, profiles/r5/kmat_ab.jsonl; row form vs accumulate form, ms): N = 8 192 D = 3
+    // 0.128 / 0.138, C2 0.277 / 0.286, N = 32 768 D = 3 0.891 / 0.888, C3 (D = 8) 1.32 / 1.42, N = 49 152 D = 3 1.85 / 1.87, N = 65 536 D = 8 6.27 / 6.43 —
+    // and C4 (N = 65 536, D = 3) 4.02 / 3.74: with the cheapest distance loop five workgroups per CU stream into more DRAM rows at once than the big
+    // matrix tolerates.  So: the row form, except for D <= 4 on launches of more than ≈ 54 000² elements.
+    const bool huge = (long)grid.x * (long)grid.y >= 180000;
+    if (!g_kmat_rows || (d <= 4 && huge)) GPMI_KMAT_LAUNCH(0);
     else if (d <= 4) GPMI_KMAT_LAUNCH(4);
     else if (d <= 8) GPMI_KMAT_LAUNCH(8);
     else if (d <= 16) GPMI_KMAT_LAUNCH(16);
@@ -1877,6 +1881,37 @@ __global__ __launch_bounds__(256) void diag_shift_trace_kernel(double* __restric
     if (threadIdx.x == 0 && out) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 // A = I (n×n, leading dimension lda)
+// out[0] = min_i |A[i][i]|, out[1] = max_i |A[i][i]| over i < n (one workgroup): max / min of a Cholesky factor's diagonal is a lower bound of its
+// condition number — the guard of the inverse-diagonal-block solves (gpmi355.hip trsm_post)
+template <typename T>
+__global__ __launch_bounds__(1024) void diag_minmax_kernel(const T* __restrict__ A, long lda, long n, double* __restrict__ out) {
+    __shared__ double smin[16], smax[16];
+    double mn = 1e300, mx = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const double v = fabs((double)A[i * lda + i]);
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = mn;
+        smax[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            mn = smin[w] < mn ? smin[w] : mn;
+            mx = smax[w] > mx ? smax[w] : mx;
+        }
+        out[0] = mn;
+        out[1] = mx;
+    }
+}
 // A[b·stride + i·lda + i] = 1 for i < n, b < gridDim.y (the diagonals of a batch of n×n blocks in a zeroed buffer)
 template <typename T>
 __global__ __launch_bounds__(256) void diag_ones_kernel(T* __restrict__ A, long lda, long n, long stride) {

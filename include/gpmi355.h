@@ -174,7 +174,9 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "dib_nb"         forward solves X L⁻ᵀ against a resident factor (predictive variances / covariances, held-out logpdf, sampling, sequential
  *                    conditioning, the gradient's L⁻ᵀ): column blocks of at most this width are solved by ONE triangular-k MFMA GEMM with the
  *                    explicit inverse of the diagonal block — built once per posterior handle (np × (dib_nb + 32) elements, 3 % of the factor at
- *                    N = 65 536) on its first forward solve; 0 = the recursion down to 64-column TRSM leaves   default 2048
+ *                    N = 65 536) on its first forward solve; 0 = the recursion down to 64-column TRSM leaves.  A product with an explicit inverse
+ *                    carries an error of order cond(L_bb)·ε where substitution is backward stable: a handle whose factor has max |L_ii| / min |L_ii|
+ *                    above 1e5 (cond(K + Σy) >= 1e10) keeps the substitution leaves                   default 2048
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32
  *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048

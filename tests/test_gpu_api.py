@@ -555,3 +555,30 @@ def test_forward_solves_with_inverse_diagonal_blocks(agp, dib_nb):
         assert g["noise"] == pytest.approx(go["noise"], rel=1e-7)
     finally:
         ctx.close()
+
+
+def test_inverse_block_solves_step_aside_for_an_ill_conditioned_factor(agp):
+    """A product with an explicit inverse is not backward stable: a posterior whose factor has max |L_ii| / min |L_ii| > 1e5 keeps the substitution
+    leaves whatever "dib_nb" says — here ONE observation with noise variance 1e12 among 2 300 (L_11 = 1e6, everything else O(1): the guard's criterion
+    without any numerical trouble), so its predictions are BITWISE those of a context with dib_nb = 0; with the ordinary noise vector the inverse blocks
+    are used (agreement to rounding, not bitwise)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2300, 2))
+    y = np.sin(x.sum(1))
+    xs = rng.standard_normal((200, 2))
+    out = {}
+    for tag, big in (("guarded", 1e12), ("plain", 0.05)):
+        noise = np.full(2300, 0.05)
+        noise[0] = big
+        for dib in (2048, 0):
+            ctx = agp.Context(0)
+            ctx.set_param("dib_nb", dib)
+            try:
+                post = agp.posterior(agp.GP(agp.Matern32Kernel(), ctx=ctx)(agp.RowVecs(x), noise), y)
+                out[(tag, dib)] = post.mean_and_var(agp.RowVecs(xs))[1]
+                post.data.C.free()
+            finally:
+                ctx.close()
+    assert np.array_equal(out[("guarded", 2048)], out[("guarded", 0)])
+    assert not np.array_equal(out[("plain", 2048)], out[("plain", 0)])
+    np.testing.assert_allclose(out[("plain", 2048)], out[("plain", 0)], atol=1e-12)
