@@ -573,6 +573,7 @@ def test_inverse_block_solves_step_aside_for_an_ill_conditioned_factor(agp):
         for dib in (2048, 0):
             ctx = agp.Context(0)
             ctx.set_param("dib_nb", dib)
+            ctx.set_param("deterministic", 1)  # no stream-K atomics anywhere: two fits of the same inputs give the same bits, so the comparison isolates the solve
             try:
                 post = agp.posterior(agp.GP(agp.Matern32Kernel(), ctx=ctx)(agp.RowVecs(x), noise), y)
                 out[(tag, dib)] = post.mean_and_var(agp.RowVecs(xs))[1]
