@@ -1,6 +1,11 @@
+"""Round 5: alternating A/B of the two Gram-kernel forms INSIDE fits on one box (ctx parameter "kmat_rows": 1 = row by row, 0 = accumulate form): five
+fits each, interleaved, the assemble phase of every fit from the library's phase events.  profiles/r5/kmat_ab.jsonl; the selection rule in
+csrc/kernels.hpp launch_kmat comes from these numbers."""
 import json, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import abstractgps_jl_amd as agp
 ctx = agp.default_context(0)
 for n, d, kern in ((65536, 8, agp.Matern32Kernel() @ agp.ScaleTransform(0.5)), (49152, 3, agp.SqExponentialKernel()), (32768, 3, agp.SqExponentialKernel()), (8192, 3, agp.SqExponentialKernel())):
