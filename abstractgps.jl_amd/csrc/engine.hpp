@@ -70,7 +70,9 @@ struct gp_ctx {
     hipStream_t sp = nullptr;  // panel stream (look-ahead)
     bool own_sm = false;
     std::mutex mu;
-    long nb = 2048;        // outer panel width
+    long nb = -1;          // outer panel width: −1 automatic (nb_small below lookahead_min_n — one-stream schedule, wider panels halve the passes over the
+                           // trailing matrix — nb_large from there on), 0 purely recursive, > 0 that width at every size
+    long nb_small = 4096, nb_large = 2048;
     int lookahead = 1;
     long lookahead_min_n = 24576;  // the look-ahead pays from here on (N <= 16 384: 0.5-3 % slower with it since the register-resident leaf; measured round 4)
     int time_kernels = 0;

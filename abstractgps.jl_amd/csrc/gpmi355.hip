@@ -599,7 +599,7 @@ static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int*
 template <typename T>
 static int32_t potrf_full(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
                           double* logdet_dev) {
-    if (c->nb <= 0) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    if (c->nb == 0) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
     return potrf_full_la<T>(c, A, lda, np, mtot, info_dev, n_valid, logdet_dev);
 }
 
@@ -612,7 +612,11 @@ template <typename T>
 static int32_t potrf_full_la(gp_ctx* c, T* A, long lda, long np, long mtot, int* info_dev, long n_valid,
                              double* logdet_dev) {
     long nb = c->nb;
-    if (nb >= np) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
+    // below the look-ahead threshold the schedule is one stream anyway: panels of "nb_small" (4 096) columns halve the passes over the trailing matrix
+    // (K = 4 096 updates) — C2 29.8-30.1 -> 29.0-29.2 ms on two boxes, N = 8 192 6.51 -> 6.43 (profiles/r5/nb_sweep.txt); from the threshold on the
+    // widths measure within ± 0.5 % of each other ("nb_large" = 2 048).  An explicit "nb" >= 0 applies to every size.
+    if (nb < 0) nb = np < c->lookahead_min_n ? c->nb_small : c->nb_large;  // "nb" = −1: automatic
+    if (nb <= 0 || nb >= np) return potrf_rec<T>(c, c->sm, A, lda, 0, np, mtot, info_dev, 0, n_valid, logdet_dev);
     nb = round_up(nb, 128);
     const bool la = c->lookahead != 0 && np >= c->lookahead_min_n;
     hipStream_t sM = c->sm, sP = la ? c->sp : c->sm;
@@ -1622,7 +1626,9 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     if (!name) return set_arg_err(2, "name is NULL");
     std::lock_guard<std::mutex> l(c->mu);
     if (c->multi && multi_set_param(c, name, v) == 0) return 0;  // (generic names are forwarded to the rank contexts too)
-    if (!strcmp(name, "nb")) c->nb = (v <= 0) ? 0 : round_up(v, 128);
+    if (!strcmp(name, "nb")) c->nb = v < 0 ? -1 : (v == 0 ? 0 : round_up(v, 128));
+    else if (!strcmp(name, "nb_small")) c->nb_small = (v <= 0) ? 0 : round_up(v, 128);
+    else if (!strcmp(name, "nb_large")) c->nb_large = (v <= 0) ? 0 : round_up(v, 128);
     else if (!strcmp(name, "lookahead")) c->lookahead = v != 0;
     else if (!strcmp(name, "lookahead_min_n")) c->lookahead_min_n = std::max<int64_t>(0, v);
     else if (!strcmp(name, "time_kernels")) c->time_kernels = v != 0;
@@ -1669,7 +1675,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
     std::lock_guard<std::mutex> l(c->mu);
     if (c->multi && multi_get_param(c, name, out) == 0) return 0;
     const struct { const char* n; int64_t v; } tab[] = {
-        {"nb", c->nb}, {"lookahead", c->lookahead}, {"lookahead_min_n", c->lookahead_min_n}, {"time_kernels", c->time_kernels},
+        {"nb", c->nb}, {"nb_small", c->nb_small}, {"nb_large", c->nb_large}, {"lookahead", c->lookahead}, {"lookahead_min_n", c->lookahead_min_n}, {"time_kernels", c->time_kernels},
         {"xcd_swizzle", c->xcd_swizzle}, {"xcd_min_tiles", c->xcd_min_tiles}, {"gemm_streamk", c->gemm_streamk},
         {"sk_max_tiles", c->sk_max_tiles}, {"sk_min_k", c->sk_min_k}, {"gemm_pipe", c->gemm_pipe}, {"gemm_pad_f32", c->gemm_pad_f32},
         {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb}, {"deterministic", c->deterministic},

@@ -138,7 +138,10 @@ int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk, int32_t dept
 int32_t gp_ctx_destroy(gp_ctx* ctx);
 /* Tuning / diagnostic parameters (all optional; the GPMI_PARAMS="name=value,..." environment variable applies the same
  * names at gp_ctx_create):
- *   "nb"             outer panel width (multiple of 128; 0 = purely recursive)            default 2048
+ *   "nb"             outer panel width: −1 = automatic ("nb_small" for matrices below "lookahead_min_n", "nb_large" from there on), 0 = purely
+ *                    recursive, > 0 = that width (multiple of 128) at every size                default −1
+ *   "nb_small", "nb_large"  the automatic widths: below the look-ahead threshold the schedule is one stream and 4 096-column panels halve the
+ *                    passes over the trailing matrix (C2 −2.5 %); above it 2 048 / 4 096 / 8 192 measure within ± 0.5 %   default 4096, 2048
  *   "lookahead"      next panel on a second, high-priority stream (0/1)                   default 1
  *   "lookahead_min_n" ... for matrices of at least this (padded) order                    default 24576
  *   "time_kernels"   bracket every MFMA GEMM launch with HIP events (gp_get_timings)      default 0
@@ -194,7 +197,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  * every GPU test that the shared default context still has exactly these values, so that no test can leave a non-production setting
  * behind for the tests that follow it (tests/conftest.py). */
 #define GPMI355_PARAM_DEFAULTS                                                                                                   \
-    "nb=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
+    "nb=-1,nb_small=4096,nb_large=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
     "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=0,gemm_pad_lds=0,trsv_nb=256,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
     "updk_max_k=512,updk_rt=0,updk_tall_k=256,updk_tall_m=8192,upd128=1,leaf_group=128,ldpad=32,vfe_ks=2048,vfe_sk=0,"          \
     "vfe_overlap=1,vfe_chunk=16384,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"

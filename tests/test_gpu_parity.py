@@ -108,7 +108,7 @@ def test_mid_size_parity(agp, n, d, kind, layout):
         f = agp.GP(agp.Kernel(kind) @ agp.ScaleTransform(scale))
         post = agp.posterior(f(xin, 0.01), y)
     finally:
-        ctx.set_param("nb", 2048)
+        ctx.set_param("nb", -1)
     assert post.logpdf_value == pytest.approx(ref_lp, rel=1e-10)
     assert _relnorm(post.data.alpha, ref_post.alpha) <= 1e-8
     xs = x[:130] + 0.05
@@ -126,12 +126,12 @@ def test_variants_agree(agp):
     vals = []
 
     def reset():  # back to the documented defaults (include/gpmi355.h); tests/conftest.py asserts it before and after every GPU test
-        ctx.set_param("nb", 2048), ctx.set_param("lookahead", 1), ctx.set_param("xcd_swizzle", 0)
+        ctx.set_param("nb", -1), ctx.set_param("lookahead", 1), ctx.set_param("xcd_swizzle", 0)
         ctx.set_param("xcd_min_tiles", 256), ctx.set_param("gemm_streamk", 1), ctx.set_param("leaf_group", 128)
         ctx.set_param("gemm_pipe", 1)
 
     try:
-        for nb, la, extra in [(2048, 1, {}), (1024, 0, {"gemm_streamk": 0}), (0, 0, {"gemm_streamk": 0}), (1024, 1, {}), (512, 0, {"gemm_streamk": 0}),
+        for nb, la, extra in [(-1, 1, {}), (2048, 1, {}), (1024, 0, {"gemm_streamk": 0}), (0, 0, {"gemm_streamk": 0}), (1024, 1, {}), (512, 0, {"gemm_streamk": 0}),
                               (512, 1, {"xcd_swizzle": 1, "xcd_min_tiles": 4, "gemm_streamk": 0}),
                               (512, 0, {"xcd_swizzle": 1, "xcd_min_tiles": 4}), (0, 0, {}),
                               (1024, 1, {"leaf_group": 64, "gemm_streamk": 0}), (1024, 1, {"leaf_group": 256}),
