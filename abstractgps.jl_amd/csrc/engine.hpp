@@ -207,6 +207,13 @@ struct DevBufs {
     }
 };
 
+// −inv(L_bb) of a resident factor's diagonal blocks (lower, row-major [np + 128][ldw]; rows of block (j0, n) at j0): gpmi355.hip dib_build / trsm_cached
+struct DibCache {
+    void* w = nullptr;
+    size_t bytes = 0;
+    long nbi = 0, ldw = 0;  // nbi = −1: this factor keeps the substitution leaves (conditioning guard)
+};
+
 // ---- posterior handle -----------------------------------------------------------------------------
 struct gp_multi;
 struct gp_multi_post;  // multi.hip: block-cyclic pieces of a factor that has not been gathered yet
@@ -226,9 +233,7 @@ struct gp_post {
     void* alpha;
     size_t alpha_bytes;  // [np]
     double logdet_half;  // Σ log L_ii
-    void* dib = nullptr;      // −inv(L_bb) of the factor's diagonal blocks (lower, row-major [np + 128][dib_ldw]; rows of block (j0, n) at j0), built on the
-    size_t dib_bytes = 0;     // first forward solve against the resident factor and kept with it ("dib_nb"; gpmi355.hip dib_build)
-    long dib_nbi = 0, dib_ldw = 0;
+    DibCache dibc;            // −inv(L_bb) of the factor's diagonal blocks, built on the first forward solve against the resident factor ("dib_nb")
     gp_multi_post* pieces = nullptr;  // multi-device fit: the factor still lives as block-cyclic pieces (A == nullptr until gathered)
 };
 

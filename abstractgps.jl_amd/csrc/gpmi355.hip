@@ -542,35 +542,32 @@ static int32_t trsm_upper_rec_batched(gp_ctx* c, hipStream_t s, T* X, long ldx, 
     return 0;
 }
 
-// The forward solve against the factor of a posterior handle: builds the handle's inverse blocks on first use (kept until the handle is freed)
-// and runs the recursion with them.  X: M × np (+ 128 slack rows).
+// The forward solve X ← X L⁻ᵀ against a RESIDENT factor L (np × np, nvalid real rows) with the inverse diagonal blocks kept in `cache` beside it: built on
+// first use (kept until the owner of the factor is freed), then the recursion runs with them.  X: M × np (+ 128 slack rows).
 template <typename T>
-static int32_t trsm_post(gp_post* post, hipStream_t s, T* X, long ldx, long M, DevBufs& bufs) {
-    gp_ctx* c = post->ctx;
-    const long np = post->np, ld = post->ld;
-    const T* A = (const T*)post->A;
+static int32_t trsm_cached(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, const T* A, long ld, long np, long nvalid, DibCache& cache, DevBufs& bufs) {
     if (M <= 0) return 0;
-    if (c->dib_nb < 128 || np < c->dib_nb || post->dib_nbi < 0) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
+    if (c->dib_nb < 128 || np < c->dib_nb || cache.nbi < 0) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
     const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
-    if (!post->dib) {
+    if (!cache.w) {
         // guard: a product with an explicit inverse carries an error of order cond(L_bb)·ε where substitution is backward stable.  max / min of the
-        // factor's diagonal bounds cond(L) from below; beyond 1e5 (cond(K + Σy) >= 1e10: interpolation-style fits with vanishing noise) this handle
-        // keeps the recursion with substitution leaves for good (dib_nbi = −1)
+        // factor's diagonal bounds cond(L) from below; beyond 1e5 (cond(K + Σy) >= 1e10: interpolation-style fits with vanishing noise) this factor
+        // keeps the recursion with substitution leaves for good (nbi = −1)
         RC(ctx_scal(c, 16));
-        hipLaunchKernelGGL(diag_minmax_kernel<T>, dim3(1), dim3(1024), 0, s, A, ld, post->n, c->scal_dev + 6);
+        hipLaunchKernelGGL(diag_minmax_kernel<T>, dim3(1), dim3(1024), 0, s, A, ld, nvalid, c->scal_dev + 6);
         HIPCHK(hipGetLastError());
         double mm[2] = {1.0, 1.0};
         HIPCHK(hipMemcpyAsync(mm, c->scal_dev + 6, sizeof(mm), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (!(mm[0] > 0.0) || mm[1] / mm[0] > 1e5) {
-            post->dib_nbi = -1;
+            cache.nbi = -1;
             return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
         }
     }
     const size_t wb = sizeof(T) * (size_t)(np + 128) * ldw;
-    if (!post->dib || post->dib_nbi != nbi) {
-        if (post->dib) ctx_release(c, post->dib, post->dib_bytes);
-        post->dib = nullptr;
+    if (!cache.w || cache.nbi != nbi) {
+        if (cache.w) ctx_release(c, cache.w, cache.bytes);
+        cache.w = nullptr;
         void* w = nullptr;
         void* iw = nullptr;
         RC(ctx_alloc(c, wb, &w));
@@ -581,14 +578,18 @@ static int32_t trsm_post(gp_post* post, hipStream_t s, T* X, long ldx, long M, D
             ctx_release(c, w, wb);
             return rc;
         }
-        post->dib = w; post->dib_bytes = wb; post->dib_nbi = nbi; post->dib_ldw = ldw;
+        cache.w = w; cache.bytes = wb; cache.nbi = nbi; cache.ldw = ldw;
     }
     void* S_v = nullptr;
     const long lds = nbi + c->ldpad;
     RC(bufs.get(sizeof(T) * (size_t)(M + 128) * lds, &S_v));
     DibArgs<T> dib;
-    dib.W = (const T*)post->dib; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = lds;
+    dib.W = (const T*)cache.w; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = lds;
     return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np, dib);
+}
+template <typename T>
+static int32_t trsm_post(gp_post* post, hipStream_t s, T* X, long ldx, long M, DevBufs& bufs) {
+    return trsm_cached<T>(post->ctx, s, X, ldx, M, (const T*)post->A, post->ld, post->np, post->n, post->dibc, bufs);
 }
 
 // Full factorisation of the np×np matrix (rows [np, mtot) are carried RHS rows): right-looking over panels of width nb with a
@@ -2049,7 +2050,7 @@ int32_t gp_posterior_free(gp_post* post) {
         ctx_release(c, post->A, post->A_bytes);
         ctx_release(c, post->xs, post->xs_bytes);
         ctx_release(c, post->alpha, post->alpha_bytes);
-        if (post->dib) ctx_release(c, post->dib, post->dib_bytes);
+        if (post->dibc.w) ctx_release(c, post->dibc.w, post->dibc.bytes);
         delete post;
     }
     ctx_unref(c);

@@ -54,6 +54,7 @@ struct gp_vfe {
     void *Dacc = nullptr, *cacc = nullptr, *rowss = nullptr, *Li = nullptr, *zsT = nullptr;
     std::vector<std::shared_ptr<ObsSeg>> segs;  // every observation seen so far (shared between a posterior and its updates)
     double logdet_sy = 0, dd = 0, tr_kff = 0, trZ = 0;
+    DibCache dib_z, dib_d;  // inverse diagonal blocks of Lz / Ld for the predictive solves (built on the first prediction; a new handle after every update)
 };
 
 static void vfe_release(gp_vfe* p) {  // under the ctx lock
@@ -67,6 +68,10 @@ static void vfe_release(gp_vfe* p) {  // under the ctx lock
     ctx_release(c, p->rowss, 0);
     ctx_release(c, p->Li, 0);
     ctx_release(c, p->zsT, 0);
+    if (p->dib_z.w) ctx_release(c, p->dib_z.w, p->dib_z.bytes);
+    if (p->dib_d.w) ctx_release(c, p->dib_d.w, p->dib_d.bytes);
+    p->dib_z = DibCache();
+    p->dib_d = DibCache();
     p->segs.clear();
 }
 
@@ -534,9 +539,9 @@ static int32_t vfe_joint(gp_vfe* p, const gp_points* xs, const void* pm, const g
                            p->kind, p->variance, (const double*)nullptr, ns, m, 0, g, (const double*)nullptr, (const double*)nullptr);
         HIPCHK(hipGetLastError());
     }
-    RC(trsm_rec<double>(c, s, X1, ld, nsp, (const double*)p->Lz, ld, mp));
+    RC(trsm_cached<double>(c, s, X1, ld, nsp, (const double*)p->Lz, ld, mp, p->m, p->dib_z, bufs));
     HIPCHK(hipMemcpyAsync(X2_v, X1_v, X_b, hipMemcpyDeviceToDevice, s));
-    RC(trsm_rec<double>(c, s, X2, ld, nsp, (const double*)p->Ld, ld, mp));
+    RC(trsm_cached<double>(c, s, X2, ld, nsp, (const double*)p->Ld, ld, mp, p->m, p->dib_d, bufs));
     {
         const long cnt = (long)(nsp + 128) * ld;
         hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const double*)X2,
@@ -624,10 +629,10 @@ static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, 
                                (const double*)p->zs, mp, d, p->kind, p->variance, (const double*)nullptr, ns, m, 0, g,
                                (const double*)nullptr, (const double*)nullptr);
             HIPCHK(hipGetLastError());
-            RC(trsm_rec<double>(c, s, X, ld, nsp, (const double*)p->Lz, ld, mp));
+            RC(trsm_cached<double>(c, s, X, ld, nsp, (const double*)p->Lz, ld, mp, p->m, p->dib_z, bufs));
             hipLaunchKernelGGL(rowsumsq_kernel<double>, dim3((unsigned)nsp), dim3(256), 0, s, X, ld, mp, o + nsp);
             HIPCHK(hipGetLastError());
-            RC(trsm_rec<double>(c, s, X, ld, nsp, (const double*)p->Ld, ld, mp));
+            RC(trsm_cached<double>(c, s, X, ld, nsp, (const double*)p->Ld, ld, mp, p->m, p->dib_d, bufs));
             hipLaunchKernelGGL(rowsumsq_kernel<double>, dim3((unsigned)nsp), dim3(256), 0, s, X, ld, mp, o + 2 * nsp);
             HIPCHK(hipGetLastError());
         }

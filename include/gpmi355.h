@@ -175,7 +175,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "kmat_rows"      Gram tiles row by row (distance, κ, store; one kernel instance per dimension bucket D <= 4 / 8 / 16, few registers) instead of
  *                    all 64 squared distances of a thread accumulated first (the form D > 16 always takes); process-wide   default 1
  *   "dib_nb"         forward solves X L⁻ᵀ against a resident factor (predictive variances / covariances, held-out logpdf, sampling, sequential
- *                    conditioning, the gradient's L⁻ᵀ): column blocks of at most this width are solved by ONE triangular-k MFMA GEMM with the
+ *                    conditioning, the gradient's L⁻ᵀ; both factors of a VFE / DTC prediction): column blocks of at most this width are solved by ONE triangular-k MFMA GEMM with the
  *                    explicit inverse of the diagonal block — built once per posterior handle (np × (dib_nb + 32) elements, 3 % of the factor at
  *                    N = 65 536) on its first forward solve; 0 = the recursion down to 64-column TRSM leaves.  A product with an explicit inverse
  *                    carries an error of order cond(L_bb)·ε where substitution is backward stable: a handle whose factor has max |L_ii| / min |L_ii|

@@ -557,6 +557,40 @@ def test_forward_solves_with_inverse_diagonal_blocks(agp, dib_nb):
         ctx.close()
 
 
+@pytest.mark.parametrize("dib_nb", [128, 256, 0])
+def test_vfe_predictions_with_inverse_diagonal_blocks(agp, dib_nb):
+    """The two forward solves of a VFE prediction (against chol(K_zz + jitter) and chol(I + ...): src/sparse_approximations.jl:183-203) with the
+    handle's cached inverse diagonal blocks: M = 700 pseudo-points (padded 768: ragged last block at both widths), marginals, full and cross
+    covariance against the oracle, twice (the second pass reuses the blocks), then after update_posterior (a new handle, new blocks)."""
+    rng = np.random.default_rng(43)
+    n, m, d = 3000, 700, 3
+    X = rng.uniform(0, 4, (n + 500, d))
+    y = np.sin(X.sum(1)) + 0.2 * rng.standard_normal(n + 500)
+    z = X[rng.permutation(n)[:m]]
+    ctx = agp.Context(0)
+    ctx.set_param("dib_nb", dib_nb)
+    try:
+        f = agp.GP(1.3 * agp.Matern32Kernel() @ agp.ScaleTransform(0.9), ctx=ctx)
+        of = o.GP(o.Kernel(o.MATERN32, 1.3, 0.9))
+        jitter = 1e-4
+        ap = agp.posterior(agp.VFE(f(agp.RowVecs(z), jitter)), f(agp.RowVecs(X[:n]), 0.04), y[:n])
+        oap = o.vfe_posterior(of, z, jitter, o.FiniteGP(of, X[:n], 0.04), y[:n])
+        xs, zs = rng.uniform(0, 4, (260, d)), rng.uniform(0, 4, (90, d))
+        for _ in range(2):
+            mu, v = ap.mean_and_var(agp.RowVecs(xs))
+            np.testing.assert_allclose(mu, oap.mean(xs), atol=1e-7)
+            np.testing.assert_allclose(v, oap.var(xs), atol=1e-8)
+            np.testing.assert_allclose(ap.cov(agp.RowVecs(xs)), oap.cov(xs), atol=1e-8)
+            np.testing.assert_allclose(ap.cov(agp.RowVecs(xs), agp.RowVecs(zs)), oap.cov(xs, zs), atol=1e-8)
+        ap2 = agp.update_posterior(ap, f(agp.RowVecs(X[n:]), 0.04), y[n:])
+        oap2 = o.vfe_posterior(of, z, jitter, o.FiniteGP(of, X, 0.04), y)
+        mu, v = ap2.mean_and_var(agp.RowVecs(xs))
+        np.testing.assert_allclose(mu, oap2.mean(xs), atol=1e-7)
+        np.testing.assert_allclose(v, oap2.var(xs), atol=1e-8)
+    finally:
+        ctx.close()
+
+
 def test_inverse_block_solves_step_aside_for_an_ill_conditioned_factor(agp):
     """A product with an explicit inverse is not backward stable: a posterior whose factor has max |L_ii| / min |L_ii| > 1e5 keeps the substitution
     leaves whatever "dib_nb" says — here ONE observation with noise variance 1e12 among 2 300 (L_11 = 1e6, everything else O(1): the guard's criterion
