@@ -1,12 +1,16 @@
 """GPU: seeded random sweep over the API surface (sizes around tile boundaries, all kernel kinds and transforms, scalar /
 diagonal noise, zero / constant mean, the three input layouts) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import gp_oracle as o
 
 pytestmark = pytest.mark.gpu
-NCASES = 24
+# GPMI_TEST_RANDOM_CASES / GPMI_TEST_RANDOM_SEED: a longer or different sweep than the 24 cases of the suite (profiles/r5/random_sweep_extra.log)
+NCASES = int(os.environ.get("GPMI_TEST_RANDOM_CASES", "24"))
+SEED0 = int(os.environ.get("GPMI_TEST_RANDOM_SEED", "1000"))
 
 
 def _case(agp, rng):
@@ -53,11 +57,11 @@ def _case(agp, rng):
 def test_random_configuration(agp, seed):
     """production configuration of the default context (tests/conftest.py asserts that it IS the documented default): stream-K GEMM tails
     with fp64 atomics, atomics in the backward sweep"""
-    _case(agp, np.random.default_rng(1000 + seed))
+    _case(agp, np.random.default_rng(SEED0 + seed))
 
 
 @pytest.mark.parametrize("exact_mode", ["no_atomics"], indirect=True)
 @pytest.mark.parametrize("seed", range(0, NCASES, 3))
 def test_random_configuration_without_atomics(agp, seed, exact_mode):
     """the same cases with gemm_streamk = 0 and deterministic = 1: hardware-dispatched GEMMs, no floating-point atomics in the exact path"""
-    _case(agp, np.random.default_rng(1000 + seed))
+    _case(agp, np.random.default_rng(SEED0 + seed))
