@@ -201,6 +201,22 @@ struct DevBufs {
             if (q == p) q = nullptr;
         return p;
     }
+    // ONE reusable scratch block per API call (the inverse-block solve's S panel: trsm_cached runs once per chunk of test points, every chunk's work is
+    // ordered on one stream, so the chunks share it; it grows only if a later chunk is larger than every earlier one)
+    void* scr = nullptr;
+    size_t scr_bytes = 0;
+    int32_t scratch(size_t bytes, void** out) {
+        if (scr && scr_bytes >= bytes) {
+            *out = scr;
+            return 0;
+        }
+        int32_t rc = get(bytes, out);
+        if (rc == 0) {
+            scr = *out;
+            scr_bytes = bytes;
+        }
+        return rc;
+    }
     ~DevBufs() {
         for (void* q : v)
             if (q) ctx_release(c, q, 0);

@@ -549,17 +549,21 @@ static int32_t trsm_cached(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, con
     if (M <= 0) return 0;
     if (c->dib_nb < 128 || np < c->dib_nb || cache.nbi < 0) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
     const long nbi = round_up(c->dib_nb, 128), ldw = nbi + c->ldpad;
+    // a handful of rows never repays the build (≈ np·nbi elements allocated, zeroed and inverted: a sequential-conditioning loop with tiny batches would pay
+    // it for every new handle): blocks that exist are used, new ones are built from 128 rows on
+    if (!cache.w && M < 128) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
     if (!cache.w) {
         // guard: a product with an explicit inverse carries an error of order cond(L_bb)·ε where substitution is backward stable.  max / min of the
-        // factor's diagonal bounds cond(L) from below; beyond 1e5 (cond(K + Σy) >= 1e10: interpolation-style fits with vanishing noise) this factor
-        // keeps the recursion with substitution leaves for good (nbi = −1)
+        // factor's diagonal bounds cond(L) from below; beyond the limit — 1e5 in fp64 (cond(K + Σy) >= 1e10: interpolation-style fits with vanishing
+        // noise), 300 ≈ √(1/ε)/10 in fp32 — this factor keeps the recursion with substitution leaves for good (nbi = −1)
+        const double limit = sizeof(T) == 8 ? 1e5 : 300.0;
         RC(ctx_scal(c, 16));
         hipLaunchKernelGGL(diag_minmax_kernel<T>, dim3(1), dim3(1024), 0, s, A, ld, nvalid, c->scal_dev + 6);
         HIPCHK(hipGetLastError());
         double mm[2] = {1.0, 1.0};
         HIPCHK(hipMemcpyAsync(mm, c->scal_dev + 6, sizeof(mm), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (!(mm[0] > 0.0) || mm[1] / mm[0] > 1e5) {
+        if (!(mm[0] > 0.0) || mm[1] / mm[0] > limit) {
             cache.nbi = -1;
             return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
         }
@@ -570,9 +574,13 @@ static int32_t trsm_cached(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, con
         cache.w = nullptr;
         void* w = nullptr;
         void* iw = nullptr;
-        RC(ctx_alloc(c, wb, &w));
-        int32_t rc = bufs.get(wb, &iw);
-        if (rc == 0) rc = dib_build<T>(c, s, A, ld, np, nbi, (T*)w, ldw, (T*)iw, (T*)nullptr, 0);
+        // no memory for the blocks (W) or the build's workspace (Iw): the solve itself needs neither — substitution leaves, this call only
+        if (ctx_alloc(c, wb, &w) != 0) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
+        if (bufs.get(wb, &iw) != 0) {
+            ctx_release(c, w, wb);
+            return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
+        }
+        int32_t rc = dib_build<T>(c, s, A, ld, np, nbi, (T*)w, ldw, (T*)iw, (T*)nullptr, 0);
         if (rc != 0) {
             (void)hipStreamSynchronize(s);
             ctx_release(c, w, wb);
@@ -580,9 +588,11 @@ static int32_t trsm_cached(gp_ctx* c, hipStream_t s, T* X, long ldx, long M, con
         }
         cache.w = w; cache.bytes = wb; cache.nbi = nbi; cache.ldw = ldw;
     }
+    // S: ONE panel per API call (DevBufs::scratch), shared by the chunks of a large prediction — allocated per call of this function it grew with the
+    // number of test points (70 MB per 4 096-row chunk: 17 GB beside the factor for 10⁶ points)
     void* S_v = nullptr;
     const long lds = nbi + c->ldpad;
-    RC(bufs.get(sizeof(T) * (size_t)(M + 128) * lds, &S_v));
+    if (bufs.scratch(sizeof(T) * (size_t)(M + 128) * lds, &S_v) != 0) return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np);
     DibArgs<T> dib;
     dib.W = (const T*)cache.w; dib.ldw = ldw; dib.nbi = nbi; dib.S = (T*)S_v; dib.lds = lds;
     return trsm_rec_v<T>(c, s, X, ldx, M, A, ld, np, dib);
@@ -1683,7 +1693,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
-        {"kmat_rows", g_kmat_rows}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
+        {"kmat_rows", g_kmat_rows.load()}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {
             *out = e.v;

@@ -14,6 +14,7 @@
 //   rowsumsq_kernel    sum(abs2, ·) reductions                              src/util/common_covmat_ops.jl:64-67
 //   kvec_kernel        K_*x α without materialising K_*x                    src/exact_gpr_posterior.jl:60-62
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include "engine.hpp"
 #ifndef GPMI_GEMM_SCHED
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(T* __restrict__ out, long ld,
         default: kmat_body<T, 3, DR>(xi, xj, out, ld, xr, ldxr, xc, ldxc, d, variance, noise, nr_valid, nc_valid, sym, g, colscale, rowscale); break;
     }
 }
-static int g_kmat_rows = 1;  // 1: the row-by-row instances for D <= 16; 0: always the accumulate form (A/B switch: ctx parameter "kmat_rows")
+static std::atomic<int> g_kmat_rows{1};  // PROCESS-WIDE (every ctx of the process reads it; relaxed atomic: contexts run on their own threads).  1: the row-by-row instances for D <= 16; 0: always the accumulate form (A/B switch: ctx parameter "kmat_rows")
 template <typename T>
 static inline void launch_kmat(dim3 grid, hipStream_t s, T* out, long ld, const T* xr, long ldxr, const T* xc, long ldxc, int d, int kind, T variance,
                                const T* noise, long nr_valid, long nc_valid, int sym, GridMap g, const T* colscale, const T* rowscale) {
@@ -720,7 +721,7 @@ static inline void launch_kmat(dim3 grid, hipStream_t s, T* out, long ld, const 
     // and C4 (N = 65 536, D = 3) 4.02 / 3.74: with the cheapest distance loop five workgroups per CU stream into more DRAM rows at once than the big
     // matrix tolerates.  So: the row form, except for D <= 4 on launches of more than ≈ 54 000² elements.
     const bool huge = (long)grid.x * (long)grid.y >= 180000;
-    if (!g_kmat_rows || (d <= 4 && huge)) GPMI_KMAT_LAUNCH(0);
+    if (!g_kmat_rows.load(std::memory_order_relaxed) || (d <= 4 && huge)) GPMI_KMAT_LAUNCH(0);
     else if (d <= 4) GPMI_KMAT_LAUNCH(4);
     else if (d <= 8) GPMI_KMAT_LAUNCH(8);
     else if (d <= 16) GPMI_KMAT_LAUNCH(16);

@@ -303,7 +303,10 @@ class RankPool {
         cv_start_.notify_all();
         for (auto& t : th_) t.join();
     }
+    // One pass at a time: every caller holds its ctx's mutex today, but nothing else enforces it — a second caller waits at run_mu_ instead of
+    // overwriting the pass in flight (fn_ / left_ / gen_) while the first waits on cv_done_.
     void run(const std::function<void(int)>& fn) {
+        std::lock_guard<std::mutex> one(run_mu_);
         std::unique_lock<std::mutex> l(mu_);
         fn_ = &fn;
         left_ = n_;
@@ -325,6 +328,7 @@ class RankPool {
                 seen = gen_;
                 fn = fn_;
             }
+            set_err_text(0, std::string());  // the threads persist across passes: every pass starts with a clean thread-local gp_last_error text
             (*fn)(r);
             {
                 std::lock_guard<std::mutex> l(mu_);
@@ -334,7 +338,7 @@ class RankPool {
     }
     int n_;
     std::vector<std::thread> th_;
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_start_, cv_done_;
     const std::function<void(int)>* fn_ = nullptr;
     long gen_ = 0;
@@ -1617,6 +1621,7 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
         return rc;
     }
     (void)hipSetDevice(devices[0]);
+    m->pool.reset(new RankPool(m->R));  // the rank threads exist with the context (run_ranks' lazy creation is for the dry-run traces on a stack gp_multi)
     main_ctx->multi = m;
     *out = main_ctx;
     return 0;

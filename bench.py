@@ -63,14 +63,25 @@ def gram_threads_default() -> int:
     return min(32, os.cpu_count() or 1)
 
 
-def cpu_baseline(n_full: int, d: int):
-    """Oracle (NumPy/SciPy -> OpenBLAS LAPACK, the routines Julia's cholesky reaches) timed on this box's host cores on a
-    bounded sample of the same workload: the in-place fused pair (one Fortran-ordered N×N, dpotrf('U') in place — SURVEY.md
-    §8(d)) at N = 8 192, 16 384 and 32 768 points, Gram / potrf / solves timed separately, extrapolated to n_full with
-    t = a·N³ + b·N² (least squares).  `value` is the fused pair (one Gram + one dpotrf: what the engine does);
-    `two_factorisations` is the pair as the reference executes it (logpdf and posterior each rebuild and refactor the Gram
-    matrix).  The full-size run of the same oracle on an MI355X box's host (tools/fullsize_parity.py) is quoted
-    from profiles/r2/fullsize_parity.jsonl when that record is present."""
+def host_mem_available_gb() -> float:
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return float(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(n_full: int, d: int, full: bool = True):
+    """Oracle (NumPy/SciPy -> OpenBLAS LAPACK, the routines Julia's cholesky reaches) timed on this box's host cores.
+    `value` is MEASURED: the oracle's in-place fused pair (one Fortran-ordered N×N, dpotrf('U') in place — SURVEY.md §8(d): "C4 in full when
+    the host has >= 40 GB") run once at n_full on the same inputs the GPU was timed on (≈ 2–3 minutes at C4), its result checked against the
+    engine's.  `samples` are the same pair at N = 8 192 / 16 384 / 32 768 (after a discarded warm-up call that starts the thread pools), Gram /
+    potrf / solves timed separately; `extrapolated` is what they predict for n_full (potrf cubic, Gram and solves quadratic, each through
+    its largest sample) — reported beside the measurement, and used as `value` only when the host cannot hold the N×N matrix (the sample
+    string says which).  `two_factorisations` is the pair as the reference executes it (logpdf and posterior each rebuild and refactor the
+    Gram matrix): the measured pair plus one more Gram + potrf."""
     from oracle import gp_oracle as o
 
     pools, cores = [], os.cpu_count() or 1
@@ -87,6 +98,7 @@ def cpu_baseline(n_full: int, d: int):
     x, y = synth_inputs(n_full, d, 4)
     f = o.GP(o.Kernel(o.SE))
     sizes = [nn for nn in (8192, 16384, 32768) if nn <= n_full]
+    o.logpdf_and_posterior_inplace(o.FiniteGP(f, x[:sizes[0]], 0.01), y[:sizes[0]], threads=gram_threads)   # warm-up, discarded
     rows, ts = [], []
     for nn in sizes:
         tm = {}
@@ -95,32 +107,34 @@ def cpu_baseline(n_full: int, d: int):
         ts.append(time.perf_counter() - t0)
         rows.append({"n": nn, "pair_s": ts[-1], **{k: round(v, 4) for k, v in tm.items()},
                      "potrf_gflops": nn**3 / 3 / tm["potrf_s"] / 1e9})
-    A = np.array([[float(nn)**3, float(nn)**2] for nn in sizes])
-    coef, *_ = np.linalg.lstsq(A, np.array(ts), rcond=None)
-    a, b = coef
-    if a <= 0 or b < 0:  # degenerate fit: pure cubic through the largest sample
-        a, b = ts[-1] / float(sizes[-1])**3, 0.0
-    t_full = a * n_full**3 + b * n_full**2
     last = rows[-1]
-    t_twice = t_full + (last["gram_s"] + last["potrf_s"]) / last["pair_s"] * t_full
-    out = {
-        "value": n_full / t_full, "unit": "points/s", "cores": int(cores), "kind": "port",
-        "sample": (f"in-place fused logpdf+posterior pair of the oracle (one Gram + one dpotrf) at N={sizes} points of the "
-                   f"same workload ({', '.join(f'{t:.2f}s' for t in ts)}), extrapolated to N={n_full} with t=a*N^3+b*N^2 -> "
-                   f"{t_full:.0f}s"),
-        "samples": rows, "gram_threads": gram_threads, "threadpools": pools,
-        "two_factorisations": {"value": n_full / t_twice, "unit": "points/s",
-                               "note": "the reference's own logpdf(fx,y) + posterior(fx,y) assemble and factor K twice"},
-    }
-    rec_path = ROOT / "profiles" / "r2" / "fullsize_parity.jsonl"
-    if rec_path.exists():
-        for line in rec_path.read_text().splitlines():
-            r = json.loads(line)
-            if r.get("config") == "C4" and r.get("n") == n_full:
-                out["measured_full_run"] = {"source": "profiles/r2/fullsize_parity.jsonl (tools/fullsize_parity.py on an MI355X box's host)",
-                                            "pair_s": r["oracle_pair_s"], "phases_s": r["oracle_phases_s"],
-                                            "points_per_s_fused": r["oracle_points_per_s_fused"],
-                                            "points_per_s_two_factorisations": r["oracle_points_per_s_two_factorisations"]}
+    r = n_full / float(last["n"])
+    ex = {"gram_s": last["gram_s"] * r**2, "potrf_s": last["potrf_s"] * r**3, "solves_s": last["solves_s"] * r**2}
+    t_ex = sum(ex.values())
+    out = {"unit": "points/s", "cores": int(cores), "kind": "port", "samples": rows, "gram_threads": gram_threads, "threadpools": pools,
+           "extrapolated": {"pair_s": t_ex, "phases_s": ex, "points_per_s": n_full / t_ex,
+                            "how": f"from the N={last['n']} sample: potrf x (N/n)^3, Gram and solves x (N/n)^2"}}
+    need_gb = 8.0 * n_full * n_full / 1e9 + 6.0
+    avail = host_mem_available_gb()
+    if full and avail >= need_gb:
+        note(f"cpu baseline: full N={n_full} oracle run ({avail:.0f} GB of host memory available, {need_gb:.0f} needed)")
+        tm = {}
+        t0 = time.perf_counter()
+        lp, alpha, _ = o.logpdf_and_posterior_inplace(o.FiniteGP(f, x, 0.01), y, threads=gram_threads, timings=tm)
+        t_full = time.perf_counter() - t0
+        out.update({"value": n_full / t_full, "pair_s": t_full, "phases_s": {k: round(v, 3) for k, v in tm.items()},
+                    "potrf_gflops": n_full**3 / 3 / tm["potrf_s"] / 1e9, "logpdf": float(lp), "_alpha": alpha,
+                    "sample": (f"full run: the oracle's in-place fused logpdf+posterior pair (one Gram + one dpotrf) at N={n_full}, the bench's own "
+                               f"inputs, measured once on this box's host: {t_full:.1f} s (Gram {tm['gram_s']:.1f} / potrf {tm['potrf_s']:.1f} / "
+                               f"solves {tm['solves_s']:.1f})")})
+        t_twice = t_full + tm["gram_s"] + tm["potrf_s"]
+    else:
+        out.update({"value": n_full / t_ex,
+                    "sample": (f"EXTRAPOLATED (host has {avail:.0f} GB available, the full run needs {need_gb:.0f}): in-place fused pair of the oracle at "
+                               f"N={sizes} ({', '.join(f'{t:.2f}s' for t in ts)}) -> {t_ex:.0f} s at N={n_full}")})
+        t_twice = t_ex + ex["gram_s"] + ex["potrf_s"]
+    out["two_factorisations"] = {"value": n_full / t_twice, "unit": "points/s",
+                                 "note": "the reference's own logpdf(fx,y) + posterior(fx,y) assemble and factor K twice"}
     return out
 
 
@@ -273,21 +287,56 @@ def next_rows(agp, ctx, post, x, y, n: int, sigma2: float) -> dict:
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts)), ts
 
+    keep = {}
     xs = rng.standard_normal((4096, x.shape[1]))
-    dt, ts = med3(lambda: post.mean_and_var(agp.RowVecs(xs)))
+    dt, ts = med3(lambda: keep.__setitem__("mv", post.mean_and_var(agp.RowVecs(xs))))
     rec("mean_and_var_4096", dt, float(n) * n * 4096, "marginals at 4096 test points: K_*x, TRSM with the resident factor, column sums")
     out["mean_and_var_4096"]["ms_all"] = [t * 1e3 for t in ts]
-    dt, ts = med3(lambda: post.cov(agp.RowVecs(xs[:1024])))
+    dt, ts = med3(lambda: keep.__setitem__("cov", post.cov(agp.RowVecs(xs[:1024]))))
     rec("cov_1024", dt, float(n) * n * 1024 + float(n) * 1024 * 1024, "full 1024x1024 predictive covariance: TRSM + SYRK")
     out["cov_1024"]["ms_all"] = [t * 1e3 for t in ts]
+    # checks on the TIMED results (untimed): the two rows reach the same numbers through different kernels (column sums of squares of the
+    # solve vs the MFMA SYRK), the mean of 16 points is recomputed on the host from α, variances lie in [0, k(x, x)]
+    m4, v4 = keep["mv"]
+    c1 = keep["cov"]
+    alpha = np.asarray(post.data.alpha, dtype=np.float64)
+    out["mean_and_var_4096"]["check"] = {
+        "mean_vs_host_K_alpha_max_abs_16pts": float(np.max(np.abs(se_rows(xs[:16], x) @ alpha - m4[:16]))), "tol_mean": 1e-8,
+        "var_min": float(v4.min()), "var_max": float(v4.max()), "var_in_0_1": bool(v4.min() >= -1e-9 and v4.max() <= 1 + 1e-9)}
+    out["cov_1024"]["check"] = {"diag_vs_mean_and_var_max_abs": float(np.max(np.abs(np.diag(c1) - v4[:1024]))), "tol": 1e-9,
+                                "asymmetry_max_abs": float(np.max(np.abs(c1 - c1.T)))}
+    out["mean_and_var_4096"]["check"]["pass"] = bool(out["mean_and_var_4096"]["check"]["mean_vs_host_K_alpha_max_abs_16pts"] <= 1e-8
+                                                      and out["mean_and_var_4096"]["check"]["var_in_0_1"])
+    out["cov_1024"]["check"]["pass"] = bool(out["cov_1024"]["check"]["diag_vs_mean_and_var_max_abs"] <= 1e-9
+                                            and out["cov_1024"]["check"]["asymmetry_max_abs"] <= 1e-12)
     n2 = 8192
     x2 = rng.standard_normal((n2, x.shape[1]))
     y2 = np.sin(x2.sum(1)) + 0.1 * rng.standard_normal(n2)
+
+    def upd():
+        old = keep.pop("p2", None)
+        if old is not None:
+            old.data.C.free()
+        keep["p2"] = agp.posterior(post(agp.RowVecs(x2), sigma2), y2)
+
     # (the warm-up call allocates the (N + n2)² block: hipMalloc of 43 GB ≈ 1.3 s)
-    dt, ts = med3(lambda: agp.posterior(post(agp.RowVecs(x2), sigma2), y2).data.C.free())
+    dt, ts = med3(upd)
     rec("sequential_update_8192", dt, float(n) * n * n2 + float(n) * n2 * n2 + n2**3 / 3.0,
         "posterior(post(x2, s2), y2) with 8192 new observations: bordered Cholesky on the resident factor")
     out["sequential_update_8192"]["ms_all"] = [t * 1e3 for t in ts]
+    # check on the TIMED result: (K + σ²I) α = δ over the UNION of the observations, through the Gram-row kernel (no factor involved) at 256 old and
+    # 256 new inputs, and on the host for 8 + 8 rows
+    p2 = keep.pop("p2")
+    a2, d2 = np.asarray(p2.data.alpha, dtype=np.float64), np.asarray(p2.data.delta, dtype=np.float64)
+    xa = np.concatenate([x, x2], axis=0)
+    idx = np.concatenate([np.linspace(0, n - 1, 256).astype(int), n + np.linspace(0, n2 - 1, 256).astype(int)])
+    res_dev = float(np.max(np.abs(p2.mean(agp.RowVecs(xa[idx])) - (d2[idx] - sigma2 * a2[idx]))))
+    hidx = np.concatenate([idx[:8], idx[-8:]])
+    res_host = float(np.max(np.abs(se_rows(xa[hidx], xa) @ a2 + sigma2 * a2[hidx] - d2[hidx])))
+    p2.data.C.free()
+    out["sequential_update_8192"]["check"] = {"normal_equations_residual_max_abs_512_rows_device": res_dev,
+                                              "normal_equations_residual_max_abs_16_rows_host": res_host, "tol": 1e-8,
+                                              "pass": bool(res_dev <= 1e-8 and res_host <= 1e-8)}
     for v in out.values():
         v["statistic"] = "median of 3 after a same-size warm-up"
     return out
@@ -312,6 +361,15 @@ def grad_rows(agp, ctx) -> dict:
         out[name] = {"ms": dt * 1e3, "flops": flops, "tflops": flops / dt / 1e12, "frac": flops / dt / pk, "logpdf": float(lp),
                      "ms_all": [t * 1e3 for t in ts], "statistic": "median of 3 after warm-up",
                      "what": "logpdf + d/d(variance, scale, noise, y): factor, C^-1 = L^-T L^-1 (triangular inverse + triangular product), one fused gradient pass"}
+        # check on the TIMED result: the gradient along the direction (variance, scale, noise) -> (1 ± h)·(variance, scale, noise) against the central
+        # difference of two gp_logpdf calls (a different entry point: no C⁻¹, no gradient kernels)
+        h = 1e-4
+        lps = [float(agp.logpdf(agp.GP((1 + sg * h) * agp.SqExponentialKernel() @ agp.ScaleTransform(1.0 + sg * h), ctx=ctx)(agp.RowVecs(x), 0.01 * (1 + sg * h)), y))
+               for sg in (+1, -1)]
+        fd = (lps[0] - lps[1]) / (2 * h)
+        an = float(g["variance"]) * 1.0 + float(g["scale"]) * 1.0 + float(g["noise"]) * 0.01
+        out[name]["check"] = {"directional_derivative": an, "central_difference_of_gp_logpdf": fd, "rel": abs(an - fd) / abs(fd), "tol": 1e-5,
+                              "pass": bool(abs(an - fd) <= 1e-5 * abs(fd))}
         ctx.trim()
     return out
 
@@ -478,6 +536,7 @@ def main():
     ap.add_argument("--selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--comparator-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-sample-only", action="store_true", help="skip the full-size oracle run (≈ 2-3 minutes at C4); value is then the extrapolation")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C3 / C5 lines (other_configs)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run parity properties")
     ap.add_argument("--no-comparator", action="store_true", help="skip the rocsolver_dpotrf comparator (run after the timed region; never on the product path)")
@@ -684,10 +743,16 @@ def main():
         }
         line.update(extra)
         if not multi and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, d)
-            note("cpu baseline sample done")
+            cb = cpu_baseline(n, d, full=not args.cpu_baseline_sample_only)
+            a_cpu = cb.pop("_alpha", None)
+            if a_cpu is not None:  # the measured oracle run is also a live parity check of the timed result (1e-10 / 1e-8)
+                cb["engine_vs_this_run"] = {"logpdf_rel": abs(logpdf_val - cb["logpdf"]) / abs(cb["logpdf"]),
+                                            "alpha_rel": float(np.linalg.norm(np.asarray(alpha, dtype=np.float64) - a_cpu) / np.linalg.norm(a_cpu))}
+                cb["engine_vs_this_run"]["pass"] = bool(cb["engine_vs_this_run"]["logpdf_rel"] <= 1e-10 and cb["engine_vs_this_run"]["alpha_rel"] <= 1e-8)
+            line["cpu_baseline"] = cb
+            note("cpu baseline done")
         elif multi and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cached_cpu_baseline(n) or cpu_baseline(n, d)
+            line["cpu_baseline"] = cached_cpu_baseline(n) or cpu_baseline(n, d, full=False)
         print(json.dumps(line), flush=True)
     if have_pg:
         dist.destroy_process_group()

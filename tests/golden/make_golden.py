@@ -32,7 +32,7 @@ CASES = [
 def build(name, n, d, kind, variance, scale, sigma2, mean, ns):
     seed = abs(hash(name)) % (2**31)
     seed = sum(ord(c) * (i + 1) for i, c in enumerate(name))  # deterministic across processes
-    x, y = o.synth_inputs(n, d, seed)
+    x, y = o.synth_c1() if name == "c1_se_1d_256" else o.synth_inputs(n, d, seed)   # C1: SURVEY.md §8(d)'s literal recipe (seed 1, sin(3x))
     rng = np.random.default_rng(seed + 1)
     xs = rng.standard_normal((ns, d))
     xs = xs[:, 0].copy() if d == 1 else xs

@@ -617,3 +617,49 @@ def test_inverse_block_solves_step_aside_for_an_ill_conditioned_factor(agp):
     assert np.array_equal(out[("guarded", 2048)], out[("guarded", 0)])
     assert not np.array_equal(out[("plain", 2048)], out[("plain", 0)])
     np.testing.assert_allclose(out[("plain", 2048)], out[("plain", 0)], atol=1e-12)
+
+
+@pytest.mark.parametrize("dib_nb", [512, 0])
+def test_fp32_predictions_with_inverse_diagonal_blocks(agp, dib_nb):
+    """An fp32 posterior (Float32 in -> Float32 out, test/finite_gp_projection.jl:180-191) with n >= dib_nb: the forward solves of its predictions take the
+    inverse diagonal blocks only while max |L_ii| / min |L_ii| <= 300 (≈ √(1/ε)/10 for fp32; fp64: 1e5) — here ≈ 5, so the blocks are used — and agree
+    with the fp64 oracle at the fp32 tolerances of SURVEY.md §8(c) (mean abs <= 1e-3) with and without them; a factor beyond the fp32 limit (one observation
+    with noise variance 1e6: ratio 1e3, far below the fp64 limit) gives BITWISE the substitution result."""
+    rng = np.random.default_rng(47)
+    n, d = 2300, 2
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    y = (np.sin(X.sum(1)) + 0.2 * rng.standard_normal(n)).astype(np.float32)
+    xs = rng.standard_normal((300, d)).astype(np.float32)
+    ctx = agp.Context(0)
+    ctx.set_param("dib_nb", dib_nb)
+    ctx.set_param("deterministic", 1)
+    try:
+        f = agp.GP(agp.Matern52Kernel(), ctx=ctx)
+        post = agp.posterior(f(agp.RowVecs(X), np.float32(0.05)), y)
+        m, v = post.mean_and_var(agp.RowVecs(xs))
+        assert m.dtype == np.float32 and v.dtype == np.float32
+        opost = o.posterior(o.FiniteGP(o.GP(o.Kernel(o.MATERN52)), X.astype(np.float64), 0.05), y.astype(np.float64))
+        mo, vo = opost.mean_and_var(xs.astype(np.float64))
+        np.testing.assert_allclose(m, mo, atol=1e-3)
+        np.testing.assert_allclose(v, vo, atol=1e-3)
+        c = post.cov(agp.RowVecs(xs[:200]))
+        np.testing.assert_allclose(c, opost.cov(xs[:200].astype(np.float64)), atol=1e-3)
+        post.data.C.free()
+        noise = np.full(n, 0.05, dtype=np.float32)
+        noise[0] = 1e6
+        pg = agp.posterior(f(agp.RowVecs(X), noise), y)
+        vg = pg.mean_and_var(agp.RowVecs(xs))[1]
+        pg.data.C.free()
+    finally:
+        ctx.close()
+    if dib_nb:
+        c0 = agp.Context(0)
+        c0.set_param("dib_nb", 0)
+        c0.set_param("deterministic", 1)
+        try:
+            p0 = agp.posterior(agp.GP(agp.Matern52Kernel(), ctx=c0)(agp.RowVecs(X), noise), y)
+            v0 = p0.mean_and_var(agp.RowVecs(xs))[1]
+            p0.data.C.free()
+        finally:
+            c0.close()
+        assert np.array_equal(vg, v0)

@@ -68,6 +68,71 @@ def test_c2_full_size_values_vs_oracle(agp):
     _exact_values(agp, 16384, 3, 2, agp.SqExponentialKernel(), o.Kernel(o.SE))
 
 
+def test_c2_next_rows_values_vs_oracle(agp):
+    """SURVEY.md §8(f) rows VALUE for value at a BASELINE size (C2, N = 16 384: multi-panel recursion levels and batched inverse-block builds
+    the N = 4 500 test of test_gpu_api.py cannot reach).  The oracle keeps C.U (2.1 GB, `posterior_inplace`):
+      * predictive marginals and the full covariance at 256 test points — src/exact_gpr_posterior.jl:64-70, 85-90 — atol 1e-8 / 1e-9;
+      * sequential conditioning on 2 048 new observations — src/exact_gpr_posterior.jl:46-56 through update_chol
+        (src/util/common_covmat_ops.jl:38-42) — α rel <= 1e-8, logpdf of all observations rel <= 1e-10, and a prediction from the
+        updated posterior;
+      * value + gradient — what AD gives the reference, test/finite_gp_projection.jl:152-178 — against central finite differences of
+        the ORACLE's logpdf (its analytic gradient forms dense N×N×D arrays and cannot run at this size; the step 1e-4·θ reproduces it to
+        < 1e-6 relative where it can, N = 3 000), rel <= 1e-5; ∂/∂y = −α exactly as the fit's α."""
+    import os
+
+    n, n2, d, s2 = 16384, 2048, 3, 0.01
+    x, y = o.synth_inputs(n, d, 2)
+    rng = np.random.default_rng(202)
+    xs = rng.standard_normal((256, d))
+    x2 = rng.standard_normal((n2, d))
+    y2 = np.sin(x2.sum(1)) + 0.1 * rng.standard_normal(n2)
+    thr = min(32, os.cpu_count() or 1)
+    kern = agp.SqExponentialKernel() @ agp.ScaleTransform(1.0)       # the C2 Gram matrix, with a scale parameter to differentiate
+    fx = agp.GP(kern)(agp.RowVecs(x), s2)
+    post = agp.posterior(fx, y)
+    try:
+        m_g, v_g = post.mean_and_var(agp.RowVecs(xs))
+        c_g = post.cov(agp.RowVecs(xs))
+        p2 = agp.posterior(post(agp.RowVecs(x2), s2), y2)
+        try:
+            a2_g, lp2_g = np.array(p2.data.alpha), float(p2.logpdf_value)
+            m2_g, v2_g = p2.mean_and_var(agp.RowVecs(xs))
+        finally:
+            p2.data.C.free()
+    finally:
+        post.data.C.free()
+    lp_g, g = agp.logpdf_and_grad(fx, y)
+    agp.default_context().trim()
+
+    of = o.GP(o.Kernel(o.SE, 1.0, 1.0))
+    lp_o, opost = o.posterior_inplace(o.FiniteGP(of, x, s2), y, threads=thr)
+    assert float(lp_g) == pytest.approx(lp_o, rel=1e-10)
+    m_o, v_o = opost.mean_and_var(xs)
+    np.testing.assert_allclose(m_g, m_o, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v_g, v_o, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c_g, opost.cov(xs), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.diag(c_g), v_g, rtol=0, atol=1e-9)
+    op2 = o.posterior(o.FiniteGP(opost, x2, s2), y2)                 # :46-56
+    assert np.linalg.norm(a2_g - op2.alpha) / np.linalg.norm(op2.alpha) <= 1e-8
+    lp2_o = -(((n + n2) * o.LOG2PI + o.logdet_chol(op2.U)) + float(op2.delta @ op2.alpha)) / 2
+    assert lp2_g == pytest.approx(lp2_o, rel=1e-10)
+    m2_o, v2_o = op2.mean_and_var(xs)
+    np.testing.assert_allclose(m2_g, m2_o, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v2_g, v2_o, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(g["y"], -opost.alpha, rtol=0, atol=1e-8 * np.abs(opost.alpha).max())
+    del opost, op2
+
+    def lp_at(var, sc, nz):
+        return o.logpdf_and_posterior_inplace(o.FiniteGP(o.GP(o.Kernel(o.SE, var, sc)), x, nz), y, threads=thr)[0]
+
+    h = 1e-4
+    fd = {"variance": (lp_at(1 + h, 1.0, s2) - lp_at(1 - h, 1.0, s2)) / (2 * h),
+          "scale": (lp_at(1.0, 1 + h, s2) - lp_at(1.0, 1 - h, s2)) / (2 * h),
+          "noise": (lp_at(1.0, 1.0, s2 * (1 + h)) - lp_at(1.0, 1.0, s2 * (1 - h))) / (2 * h * s2)}
+    for name, val in fd.items():
+        assert float(g[name]) == pytest.approx(val, rel=1e-5), (name, float(g[name]), val)
+
+
 def test_c3_full_size_values_vs_oracle(agp):
     _exact_values(agp, 32768, 8, 3, agp.Matern32Kernel() @ agp.ScaleTransform(0.5), o.Kernel(o.MATERN32, 1.0, 0.5))
 
@@ -81,7 +146,8 @@ def test_c3_ard_full_size_values_vs_oracle(agp):
 def test_c4_full_size_values_vs_oracle(agp):
     """The headline size (N = 65 536): logdet (through logpdf) and α of the engine against the oracle's in-place fused pair run here
     on the box's host cores (≈ 135 s, 35 GB of host memory), at the SURVEY §8(c) tolerances — asserted by the driver-run suite
-    after every kernel change, not by a committed file.  The oracle's result is cross-checked against its own committed digest
+    after every kernel change, not by a committed file — and the predictive mean / variance at 64 test points (abs 1e-8 / 1e-9) against
+    the oracle's C.U before it is dropped (src/exact_gpr_posterior.jl:68-70, 85-90).  The oracle's result is cross-checked against its own committed digest
     (generated in the build container: a different host, a different OpenBLAS thread count)."""
     import os
 
@@ -89,6 +155,8 @@ def test_c4_full_size_values_vs_oracle(agp):
     x, y = o.synth_inputs(n, 3, 4)
     post = agp.posterior(agp.GP(agp.SqExponentialKernel())(agp.RowVecs(x), 0.01), y)
     lp_gpu, alpha_gpu = float(post.logpdf_value), np.array(post.data.alpha)
+    xs = np.random.default_rng(404).standard_normal((64, 3))
+    m_gpu, v_gpu = post.mean_and_var(agp.RowVecs(xs))
     post.data.C.free()
     agp.default_context().trim()
     dig = _digest()
@@ -97,7 +165,14 @@ def test_c4_full_size_values_vs_oracle(agp):
 
         assert lp_gpu == pytest.approx(float(dig["logpdf"]), rel=1e-10)
         assert compare(alpha_gpu, dig) <= 1e-8
-    lp, alpha, _ = o.logpdf_and_posterior_inplace(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y, threads=min(32, os.cpu_count() or 1))
+    var_o = {}
+
+    def probe(U):   # predictive variances at 64 test points from the oracle's C.U before it is dropped (exact_gpr_posterior.jl:68-70)
+        var_o["v"] = o.gp_var(o.GP(o.Kernel(o.SE)), xs) - o.diag_Xt_invA_X(U, o.kernelmatrix(o.Kernel(o.SE), x, xs))
+
+    lp, alpha, _ = o.logpdf_and_posterior_inplace(o.FiniteGP(o.GP(o.Kernel(o.SE)), x, 0.01), y, threads=min(32, os.cpu_count() or 1), probe=probe)
+    np.testing.assert_allclose(v_gpu, var_o["v"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(m_gpu, o.kernelmatrix(o.Kernel(o.SE), xs, x) @ alpha, rtol=0, atol=1e-8)
     if os.environ.get("GPMI_WRITE_C4_DIGEST"):  # (re)generate the committed digest from THIS oracle run (tests/golden/make_c4_digest.py)
         from tests.golden.make_c4_digest import digest_of
 

@@ -7,8 +7,8 @@ What the two comparisons are: the committed fixtures tests/golden/*.npz were WRI
 oracle.gp_oracle), so "golden and oracle" is one source seen twice — a regression pin of the oracle's past output plus the oracle's present
 output, not two independent references.  The independent pins live in tests/test_oracle.py (MvNormal, 60-digit mpmath, scikit-learn's
 GaussianProcessRegressor) and, once a maintainer has run tests/golden/make_golden.jl, in tests/test_julia_golden.py (the real AbstractGPs.jl).
-(The fixture `c1_se_1d_256` is BASELINE config 1's shape — N = 256, D = 1, SE, σ² = 0.01 — with the fixture generator's name-derived seed and
-y = sin(x) + 0.1 ε, not SURVEY.md §8(d)'s literal recipe (seed 1, sin(3x)); `__graft_entry__.smoke()` runs that shape through `synth_inputs(256, 1, 1)`.)"""
+(The fixture `c1_se_1d_256` is BASELINE config C1 by SURVEY.md §8(d)'s literal recipe — N = 256, D = 1, x ~ N(0, 1) from PCG64 seed 1,
+y = sin(3x) + 0.1 ε, SE, σ² = 0.01: `oracle.gp_oracle.synth_c1`; `__graft_entry__.smoke()` runs the same inputs.)"""
 import glob
 from pathlib import Path
 
