@@ -727,6 +727,23 @@ int32_t gpmi::eng_potrf(gp_ctx* c, hipStream_t s, double* a, long lda, long m, l
 int32_t gpmi::eng_trsm(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* l, long ldl, long n) {
     return trsm_rec_v<double>(c, s, x, ldx, m, l, ldl, n);
 }
+// W ← −inv(L) for ONE nb×nb lower block (the multi-device driver's diagonal block): Iw = I, Iw ← Iw L⁻ᵀ (upper; the restricted-row recursion),
+// W = −Iwᵀ.  W, Iw: nb × ldw, both fully overwritten (the caller keeps 128 finite slack rows below W: the B-operand over-read of the GEMM).
+int32_t gpmi::eng_inv_lower(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nb, double* w, long ldw, double* iw) {
+    hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((nb + 255) / 256), (unsigned)nb), dim3(256), 0, s, iw, ldw, nb);
+    HIPCHK(hipGetLastError());
+    RC(trsm_upper_rec<double>(c, s, iw, ldw, l, ldl, 0, nb));
+    hipLaunchKernelGGL(transpose_scale_kernel<double>, dim3((unsigned)((nb + 31) / 32), (unsigned)((nb + 31) / 32)), dim3(256), 0, s, (const double*)iw, ldw, w, ldw,
+                       nb, -1.0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// X (m × nb) ← X L⁻ᵀ as ONE triangular-k MFMA GEMM with w = −inv(L): S = −X wᵀ into the scratch sc ((m + 128) × lds), copied back over X
+int32_t gpmi::eng_trsm_inv(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* w, long ldw, long nb, double* sc, long lds) {
+    DibArgs<double> dib;
+    dib.W = w; dib.ldw = ldw; dib.nbi = nb; dib.S = sc; dib.lds = lds;
+    return dib_apply<double>(c, s, x, ldx, m, nb, dib);
+}
 int32_t gpmi::eng_gemm_nt(gp_ctx* c, hipStream_t s, double* cm, long ldc, const double* a, long lda, const double* b, long ldb,
                           long m, long n, long k, GridMap g) {
     return launch_gemm<double>(c, s, cm, ldc, a, lda, b, ldb, m, n, k, g);

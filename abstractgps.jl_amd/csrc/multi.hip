@@ -209,8 +209,8 @@ struct XEvent : Ev {
 };
 
 constexpr long RHS_ROWS = 128;
-enum { SM = 0, SP = 1, SC = 2 };
-const char* const SNAME[3] = {"sm", "sp", "sc"};
+enum { SM = 0, SP = 1, SC = 2, SD = 3 };  // main / panel / comm / diagonal chain ("multi_chain_cus"; otherwise the chain runs on the panel stream)
+const char* const SNAME[4] = {"sm", "sp", "sc", "sd"};
 constexpr int NXKIND = 7;
 const char* const XTAG[NXKIND] = {"ready", "lkk", "accr", "alr", "sx", "sa", "bar"};
 
@@ -257,6 +257,9 @@ struct MRank {
     int r = 0, p = 0, q = 0, device = 0;
     gp_ctx* c = nullptr;       // rank context: main stream c->sm, panel stream c->sp
     hipStream_t sc = nullptr;  // comm stream
+    // "multi_chain_cus" = r > 0: the diagonal block's chain on a stream masked to CUs [0, r) (r/8 of every XCD), main and panel work on streams masked
+    // to the other CUs (hipExtStreamCreateWithCUMask; masked streams carry no priority)
+    hipStream_t sd = nullptr, sm_m = nullptr, sp_m = nullptr;
     ncclComm_t_ comm = nullptr;
     std::vector<XEvent> ready, lkk, accr, alr;  // per block column k (see fit_rank)
     std::vector<XEvent> sx, sa;                  // forward solve on the distributed factor: X_k published / accumulators after step k
@@ -266,6 +269,7 @@ struct MRank {
     double* A = nullptr;
     long ld = 0, m_loc = 0, n_loc = 0;
     double* Lkk = nullptr;
+    double* Winv = nullptr;      // −inv(L_kk) of the diagonal blocks this rank owns, one NB×LDP slot per block (never rewritten within a fit: peers pull from it)
     double* stage[4] = {nullptr, nullptr, nullptr, nullptr};
     double* acc = nullptr;       // backward sweep: per local column partial sums
     double* alpha_blk = nullptr; // backward sweep: α blocks computed by this rank (diagonal owner), indexed by global block
@@ -363,6 +367,10 @@ struct gp_multi {
     long solves = 0;         // forward solves on the distributed factor so far
     int inject_fault = 0;    // diagnostic: the next fit hands the self-check a spoiled alpha once ("multi_inject_fault")
     long fits = 0, retries = 0;  // fit attempts / repetitions after a failed self-check (gp_ctx_multi_stats)
+    int chain_cus = 0;       // "multi_chain_cus": CUs reserved for the diagonal block's chain (0: the chain shares the machine with the bulk update)
+    bool dry_chain = false;  // (schedule trace only: the chain-stream schedule without streams)
+    int trsm_inv = 1;        // rows-below solve of a panel as ONE triangular-k GEMM with the diagonal owner's −inv(L_kk) ("multi_trsm_inv"; 0: substitution recursion)
+    bool use_inv = true;     // ... for the fit in flight (multi_fit: trsm_inv and the conditioning bound of the inputs)
     long window = 16;        // block steps a rank thread may queue ahead of its device ("multi_window")
     double timeout_s = 600;  // a rank thread that waits longer than this for a peer or for its own streams fails the fit
     std::string comm_note;
@@ -414,7 +422,7 @@ struct RankRun {
     bool dry;      // schedule trace only: no device, no HIP call
     int check;
     Trace* tr;
-    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t own_used = 0;
     long nflags = 0;
 
@@ -585,10 +593,15 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     const int R_ = me->r;
     gp_ctx* c = me->c;
     RankRun rr{M, me, dm, seq, dry, dry ? 0 : M->check, M->tr};
+    // "multi_chain_cus": the diagonal block's Cholesky (and its inverse) on a stream of their own that OWNS a few CUs, everything else of the panel and
+    // main streams on the complement — beside an unmasked bulk update a 1 024-column block's chain takes 3.6 ms instead of 0.36 (its workgroups wait
+    // for slots the update refills), on 16 masked CUs 0.46 ms while the update on the other 240 runs 4 % slower (profiles/r5/cumask_chain_probe.jsonl)
+    const bool chain = P > 1 && (dry ? M->dry_chain : (M->chain_cus > 0 && me->sd && me->sm_m && me->sp_m));
     if (!dry) {
-        rr.st[SM] = c->sm;
-        rr.st[SP] = c->sp;
+        rr.st[SM] = chain ? me->sm_m : c->sm;
+        rr.st[SP] = chain ? me->sp_m : c->sp;
         rr.st[SC] = me->sc;
+        rr.st[SD] = chain ? me->sd : rr.st[SP];
         MCHK(hipSetDevice(me->device));
         c->ev_used = 0;
         c->gemm_recs.clear();
@@ -600,12 +613,19 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     const int check = rr.check;
 
     // ---- buffers
-    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0, *ver_v = 0;
+    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0, *ver_v = 0, *Wi_v = 0, *Iw_v = 0, *Sx_v = 0;
+    // rows-below solve by the explicit inverse of the diagonal block (M->use_inv): the diagonal owner of block column k forms W_k = −inv(L_kk) into ITS
+    // slot k / lcm(P, Q) of Winv (a slot per owned diagonal block: nothing is rewritten while a peer may still read it) and W_k travels instead of L_kk;
+    // every owner of the column then solves its rows with ONE triangular-k MFMA GEMM, S = −X W_kᵀ = X L_kk⁻ᵀ, copied back over X — instead of the
+    // recursion's NB/64 latency-bound leaf launches and as many few-tile GEMMs per rank and step (NB = 1 024: 31 launches -> 2)
+    const bool use_inv = M->use_inv && P > 1;
+    const long LCM = [&] { long a = P, b = Q; while (b) { const long t = a % b; a = b; b = t; } return (long)P / a * Q; }();
+    const long n_own = use_inv ? (nblk + LCM - 1) / LCM : 0;
     void* Ab_v[4] = {0, 0, 0, 0};
     void* Bb_v[4] = {0, 0, 0, 0};
     void* St_v[4] = {0, 0, 0, 0};
     const size_t A_b = sizeof(double) * (size_t)(m_loc + 128) * ld;
-    const long own_cap = 10 * nblk + 64;
+    const long own_cap = 12 * nblk + 64;
     rr.nflags = NXKIND * nblk + own_cap;
     if (!dry) {
         RC(bufs->get(A_b, &A_v));
@@ -622,8 +642,14 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
             if (rccl) RC(bufs->get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &St_v[s]));
         }
         if (check) RC(bufs->get(sizeof(int) * (size_t)(rr.nflags + 256), &chk_v));
+        if (use_inv) {
+            RC(bufs->get(sizeof(double) * (size_t)(n_own * NB + 128) * LDP, &Wi_v));
+            RC(bufs->get(sizeof(double) * (size_t)(NB + 128) * LDP, &Iw_v));
+            RC(bufs->get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &Sx_v));
+        }
     }
     double* A = (double*)A_v;
+    me->Winv = (double*)Wi_v;
     me->A = A; me->ld = ld; me->m_loc = m_loc; me->n_loc = n_loc;
     me->Lkk = (double*)Lkk_v;
     me->acc = (double*)acc_v;
@@ -647,7 +673,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     // ---- upload + assemble (one traced operation: everything below is issued back to back on the main stream)
     RC(rr.op(SM, "init", 0, 0, {},
              {Fp{"A", R_, 0, nlb_r, 0, nlb_c, RHSF}, Fp{"Ab", R_, 0, NBUF, 0, nlb_r, 2}, Fp{"Bb", R_, 0, NBUF, 0, nlb_c, 0},
-              Fp{"St", R_, 0, NBUF, 0, nlb_r, 2}, Fp{"Lkk", R_, 0, 0, 0, 0, 0}, Fp{"acc", R_, 0, 0, 0, nlb_c, 0}},
+              Fp{"St", R_, 0, NBUF, 0, nlb_r, 2}, Fp{"Lkk", R_, 0, 0, 0, 0, 0}, Fp{"acc", R_, 0, 0, 0, nlb_c, 0}, Fp{"Wi", R_, 0, 0, 0, n_own, 0}},
              [&]() -> int32_t {
                  MCHK(hipMemcpyAsync(xs_v, xs_h, sizeof(double) * (size_t)dm.d * npad, hipMemcpyHostToDevice, sm));
                  MCHK(hipMemcpyAsync(nz_v, noise_h, sizeof(double) * (size_t)npad, hipMemcpyHostToDevice, sm));
@@ -671,6 +697,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
                          MCHK(hipMemsetAsync((double*)St_v[s] + m_loc * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
                      }
                  }
+                 if (Wi_v) MCHK(hipMemsetAsync(Wi_v, 0, sizeof(double) * (size_t)(n_own * NB + 128) * LDP, sm));  // (slack rows below the last slot stay zero)
                  MCHK(hipMemsetAsync(Lkk_v, fill, sizeof(double) * (size_t)NB * LDP, sm));
                  MCHK(hipMemsetAsync((double*)Lkk_v + NB * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
                  RC(eng_assemble(c, sm, kind, variance, (const double*)xs_v, n, npad, dm.d, (const double*)nz_v, g, A, ld, nlb_r * NB, n_loc));
@@ -767,11 +794,54 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
             if (p == pk) {
                 const long r0 = (k / P) * NB;
                 const Fp fd = Fp{"A", R_, k / P, k / P + 1, lc, lc + 1, 0};
-                RC(rr.op(SP, "potrf_diag", k, 0, {fd}, {fd}, [&]() { return eng_potrf(c, sp, A + r0 * ld + c0, ld, NB, NB, c->info_dev, k * NB, n, c->scal_dev); }));
+                const int SDg = chain ? SD : SP;  // the stream of the diagonal block's chain
+                hipStream_t sdg = rr.st[SDg];
+                if (chain) {  // the block's last update (look-ahead, panel stream) precedes the chain
+                    Ev e;
+                    RC(rr.own_event(&e, "to_chain", k));
+                    RC(rr.rec(SP, e));
+                    RC(rr.wait(SD, e));
+                }
+                RC(rr.op(SDg, "potrf_diag", k, 0, {fd}, {fd}, [&]() { return eng_potrf(c, sdg, A + r0 * ld + c0, ld, NB, NB, c->info_dev, k * NB, n, c->scal_dev); }));
                 lkk_ptr = A + r0 * ld + c0;
                 lkk_ld = ld;
                 f_l = fd;
-                if (rccl) {  // contiguous image for the sends
+                if (use_inv) {  // W_k = −inv(L_kk) into my slot of this block; W_k is what the column's other owners get
+                    const long slot = k / LCM;
+                    double* Wk = me->Winv + slot * NB * LDP;
+                    const Fp fw = Fp{"Wi", R_, 0, 0, slot, slot + 1, 0};
+                    const double* Ld = A + r0 * ld + c0;
+                    RC(rr.op(SDg, "inv_lkk", k, 0, {fd}, {fw}, [&]() { return eng_inv_lower(c, sdg, Ld, ld, NB, Wk, LDP, (double*)Iw_v); }));
+                    lkk_ptr = Wk;
+                    lkk_ld = LDP;
+                    f_l = fw;
+                }
+                if (chain) {  // ... and the panel stream continues after it (image / sends / publication / my rows-below solve)
+                    Ev e;
+                    RC(rr.own_event(&e, "from_chain", k));
+                    RC(rr.rec(SD, e));
+                    RC(rr.wait(SP, e));
+                }
+                if (use_inv) {
+                    const long slot = k / LCM;
+                    double* Wk = me->Winv + slot * NB * LDP;
+                    const Fp fw = Fp{"Wi", R_, 0, 0, slot, slot + 1, 0};
+                    if (rccl) {  // the slot is contiguous and never rewritten: sent as it lies
+                        Ev e;
+                        RC(rr.own_event(&e, "lkk_image", k));
+                        RC(rr.rec(SP, e));
+                        RC(rr.wait(SC, e));
+                        tr_group(rr, SC, 1);
+                        if (!dry) NCHK(g_rccl.GroupStart());
+                        for (int pp = 0; pp < P; ++pp)
+                            if (pp != pk) {
+                                tr_send(rr, SC, rrank(pp, qk), (long)NB * LDP, fw);
+                                if (!dry) NCHK(g_rccl.Send(Wk, (size_t)NB * LDP, NCCL_FLOAT64, rank_of(pp, qk).r, me->comm, sc));
+                            }
+                        if (!dry) NCHK(g_rccl.GroupEnd());
+                        tr_group(rr, SC, 0);
+                    }
+                } else if (rccl) {  // contiguous image for the sends
                     RC(rr.wait(SP, lkk_free));
                     RC(rr.op(SP, "lkk_image", k, 0, {fd}, {Fp{"Lkk", R_, 0, 0, 0, 0, 0}}, [&]() { return rr.pull(SP, me->Lkk, LDP, lkk_ptr, ld, NB, NB); }));
                     Ev e;
@@ -803,8 +873,14 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
                     RC(rr.wait(SP, e));
                 } else {
                     RC(rr.await(own.lkk[k], SP));
-                    RC(rr.op(SP, "pull_lkk", k, 0, {Fp{"A", own.r, k / P, k / P + 1, lc, lc + 1, 0}}, {Fp{"Lkk", R_, 0, 0, 0, 0, 0}},
-                             [&]() { return rr.pull(SP, me->Lkk, LDP, own.A + (k / P) * NB * own.ld + c0, own.ld, NB, NB); }));
+                    if (use_inv) {
+                        const long slot = k / LCM;
+                        RC(rr.op(SP, "pull_lkk", k, 0, {Fp{"Wi", own.r, 0, 0, slot, slot + 1, 0}}, {Fp{"Lkk", R_, 0, 0, 0, 0, 0}},
+                                 [&]() { return rr.pull(SP, me->Lkk, LDP, own.Winv + slot * NB * LDP, LDP, NB, NB); }));
+                    } else {
+                        RC(rr.op(SP, "pull_lkk", k, 0, {Fp{"A", own.r, k / P, k / P + 1, lc, lc + 1, 0}}, {Fp{"Lkk", R_, 0, 0, 0, 0, 0}},
+                                 [&]() { return rr.pull(SP, me->Lkk, LDP, own.A + (k / P) * NB * own.ld + c0, own.ld, NB, NB); }));
+                    }
                 }
                 lkk_ptr = me->Lkk;
                 lkk_ld = LDP;
@@ -813,7 +889,10 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
             const long r0b = rows_from(k + 1, p);
             if (m_loc - r0b > 0) {
                 const Fp fx = Fp{"A", R_, r0b / NB, nlb_r, lc, lc + 1, RHSF};
-                RC(rr.op(SP, "trsm", k, 0, {fx, f_l}, {fx}, [&]() { return eng_trsm(c, sp, A + r0b * ld + c0, ld, m_loc - r0b, lkk_ptr, lkk_ld, NB); }));
+                RC(rr.op(SP, "trsm", k, 0, {fx, f_l}, {fx}, [&]() {
+                    return use_inv ? eng_trsm_inv(c, sp, A + r0b * ld + c0, ld, m_loc - r0b, lkk_ptr, lkk_ld, NB, (double*)Sx_v, LDP)
+                                   : eng_trsm(c, sp, A + r0b * ld + c0, ld, m_loc - r0b, lkk_ptr, lkk_ld, NB);
+                }));
             }
             if (rccl && p != pk) {
                 RC(rr.own_event(&lkk_free, "lkk_free", k));
@@ -1074,6 +1153,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     RC(rr.drain(SM));
     RC(rr.drain(SP));
     RC(rr.drain(SC));
+    if (chain) RC(rr.drain(SD));
     me->gemm_ms = me->gemm_flops = 0;
     me->gemm_launches = (long)c->gemm_recs.size();
     for (auto& r : c->gemm_recs) {
@@ -1422,9 +1502,44 @@ void multi_destroy(gp_multi* m) {
                 if (x.ev) (void)hipEventDestroy(x.ev);
         for (auto e : rk.own) (void)hipEventDestroy(e);
         if (rk.sc) (void)hipStreamDestroy(rk.sc);
+        for (hipStream_t st : {rk.sd, rk.sm_m, rk.sp_m})
+            if (st) (void)hipStreamDestroy(st);
         if (rk.c) (void)gp_ctx_destroy(rk.c);
     }
     delete m;
+}
+
+// "multi_chain_cus" = r: (re)create the masked stream triple of every rank — sd on CUs [0, r), sm_m / sp_m on [r, num_cus) — or drop it (r = 0).
+// Mask bit i is CU i / 8 of XCC i % 8 (profiles/r2/traces/cumask_probe.txt), so [0, r) takes r / 8 CUs of every XCD; r is rounded to a multiple of 8
+// and kept within [8, num_cus / 2].
+static int32_t multi_set_chain_cus(gp_multi* m, int r) {
+    for (auto& rk : m->ranks) {
+        if (!rk.c) continue;
+        MCHK(hipSetDevice(rk.device));
+        for (hipStream_t* ps : {&rk.sd, &rk.sm_m, &rk.sp_m})
+            if (*ps) {
+                (void)hipStreamSynchronize(*ps);
+                (void)hipStreamDestroy(*ps);
+                *ps = nullptr;
+            }
+    }
+    m->chain_cus = 0;
+    if (r <= 0) return 0;
+    for (auto& rk : m->ranks) {
+        if (!rk.c) continue;
+        const int ncu = rk.c->num_cus > 0 ? rk.c->num_cus : 256;
+        const int rr = std::min(std::max(8, (r + 7) / 8 * 8), ncu / 2);
+        const uint32_t words = (uint32_t)((ncu + 31) / 32);
+        std::vector<uint32_t> lo(words, 0u), hi(words, 0u);
+        for (int i = 0; i < ncu; ++i) (i < rr ? lo : hi)[(size_t)i / 32] |= 1u << (i % 32);
+        MCHK(hipSetDevice(rk.device));
+        MCHK(hipExtStreamCreateWithCUMask(&rk.sd, words, lo.data()));
+        MCHK(hipExtStreamCreateWithCUMask(&rk.sm_m, words, hi.data()));
+        MCHK(hipExtStreamCreateWithCUMask(&rk.sp_m, words, hi.data()));
+        for (hipStream_t st : {rk.sd, rk.sm_m, rk.sp_m}) RC(ctx_prime_stream(rk.c, st));  // the hardware queues exist before the first fit (see gp_ctx_create_multi)
+        m->chain_cus = rr;
+    }
+    return 0;
 }
 
 int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
@@ -1462,6 +1577,11 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
         m->window = std::max<int64_t>(4, v);
         return 0;
     }
+    if (!strcmp(name, "multi_trsm_inv")) {
+        m->trsm_inv = v != 0;
+        return 0;
+    }
+    if (!strcmp(name, "multi_chain_cus")) return multi_set_chain_cus(m, (int)v);
     if (!strcmp(name, "multi_timeout_s")) {
         m->timeout_s = (double)std::max<int64_t>(1, v);
         return 0;
@@ -1496,7 +1616,7 @@ int32_t multi_get_param(gp_ctx* c, const char* name, int64_t* out) {
     const struct { const char* n; int64_t v; } tab[] = {
         {"lookahead_depth", m->depth}, {"copy_kernel", m->copy_kernel}, {"multi_debug_sync", m->debug_sync}, {"multi_check", m->check},
         {"multi_dist_predict", m->dist_predict}, {"multi_inject_fault", m->inject_fault}, {"multi_verify", m->verify},
-        {"multi_window", (int64_t)m->window}, {"multi_timeout_s", (int64_t)m->timeout_s}, {"dist_nb", (int64_t)m->nb},
+        {"multi_window", (int64_t)m->window}, {"multi_trsm_inv", m->trsm_inv}, {"multi_chain_cus", m->chain_cus}, {"multi_timeout_s", (int64_t)m->timeout_s}, {"dist_nb", (int64_t)m->nb},
         {"multi_gemm_streamk", rk_sk}, {"multi_leaf_cols", rk_lc}};
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {
@@ -1666,13 +1786,17 @@ extern "C" int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk_in
     if (P < 1 || Q < 1 || P * Q > 64) return set_arg_err(1, "P, Q");
     if (nblk_in < 1 || nblk_in > 4096) return set_arg_err(3, "nblk");
     if (depth < 1 || depth > 3) return set_arg_err(4, "depth must be 1..3");
-    if (comm != 1 && comm != 2) return set_arg_err(5, "comm must be 1 (send/recv) or 2 (copies)");
+    if ((comm & 15) != 1 && (comm & 15) != 2) return set_arg_err(5, "comm must be 1 (send/recv) or 2 (copies), + 16 for the substitution solve, + 32 for the chain stream");
     if (!path) return set_arg_err(6, "path is NULL");
     Trace tr;
     tr.f = fopen(path, "w");
     if (!tr.f) return set_arg_err(6, "cannot open the trace file");
     gp_multi M;
-    M.P = P; M.Q = Q; M.R = P * Q; M.nb = 128; M.depth = depth; M.comm = comm; M.tr = &tr; M.timeout_s = 60;
+    M.P = P; M.Q = Q; M.R = P * Q; M.nb = 128; M.depth = depth; M.comm = comm & 15; M.tr = &tr; M.timeout_s = 60;
+    M.use_inv = !(comm & 16);  // comm + 16: the schedule with the substitution solve ("multi_trsm_inv" = 0: L_kk itself travels)
+    M.dry_chain = (comm & 32) != 0;  // comm + 32: the schedule with the diagonal chain on its own stream ("multi_chain_cus" > 0)
+    const int chain_flag = M.dry_chain ? 1 : 0;
+    comm &= 15;
     const long lcm = lcm_of(P, Q);
     const long nblk = (nblk_in + lcm - 1) / lcm * lcm;
     Dims dm{nblk * 128, nblk * 128, nblk, 128, nblk / P, nblk / Q, 128 + 32, 1};
@@ -1687,7 +1811,7 @@ extern "C" int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk_in
     }
     {
         char b[160];
-        snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"dry\":1}", P, Q, nblk, depth, comm);
+        snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"inv\":%d,\"chain\":%d,\"dry\":1}", P, Q, nblk, depth, comm, (int)M.use_inv, chain_flag);
         tr.line(b);
     }
     std::vector<std::thread> th;
@@ -1737,6 +1861,18 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         for (long i = 0; i < n; ++i) xs_h[(size_t)dd * npad + i] = s * pt(i, dd);
     }
     for (long i = 0; i < n; ++i) noise_h[i] = noise->kind == 0 ? noise->s : ((const double*)noise->diag)[i];
+    {
+        // "multi_trsm_inv": a product with an explicit inverse carries an error of order cond(L_kk)·ε where substitution is backward stable (the guard of the
+        // single-device inverse-block solves, gpmi355.hip trsm_cached, reads the factor's diagonal; here the decision must precede the fit).  Every pivot
+        // of K + Σy lies in [min Σy_ii, variance + max Σy_ii] (Schur complements of K are positive semi-definite and below K), so
+        // max L_ii / min L_ii <= sqrt((variance + max Σy) / min Σy): beyond 1e5 this fit keeps the substitution recursion.
+        double lo = noise_h[0], hi = noise_h[0];
+        for (long i = 1; i < n; ++i) {
+            lo = std::min(lo, noise_h[i]);
+            hi = std::max(hi, noise_h[i]);
+        }
+        M->use_inv = M->trsm_inv != 0 && lo > 0 && std::sqrt((k->variance + hi) / lo) <= 1e5;
+    }
     for (int s = 0; s < ncols; ++s)
         for (long i = 0; i < n; ++i) rhs_h[(size_t)s * npad + i] = Y[(size_t)s * ldy + i] - (mean ? mean[i] : 0.0);
     double* alpha_pin = nullptr;
@@ -1759,7 +1895,7 @@ int32_t multi_fit(gp_ctx* c, const gp_kernel* k, const gp_points* x, const gp_no
         tr.f = fopen(tp, "w");  // the LAST fit of the process is what the file holds
         if (tr.f) {
             char b[160];
-            snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"dry\":0}", P, Q, nblk, M->depth, M->comm);
+            snprintf(b, sizeof b, "{\"t\":\"hdr\",\"P\":%d,\"Q\":%d,\"nblk\":%ld,\"depth\":%d,\"comm\":%d,\"inv\":%d,\"chain\":%d,\"dry\":0}", P, Q, nblk, M->depth, M->comm, (int)M->use_inv, M->chain_cus > 0 ? 1 : 0);
             tr.line(b);
         }
     }

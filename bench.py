@@ -38,6 +38,14 @@ def note(msg: str) -> None:
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def lib_sha16() -> str:
+    """sha256 (first 16 hex digits) of the libgpmi355.so this process loaded: which build a recorded line came from"""
+    import hashlib
+
+    p = ROOT / "abstractgps.jl_amd" / "csrc" / "libgpmi355.so"
+    return hashlib.sha256(p.read_bytes()).hexdigest()[:16] if p.exists() else ""
+
+
 def f_pair(n: int) -> float:
     """Algorithmic flops of one pair: N³/3 + 3N²."""
     return n**3 / 3.0 + 3.0 * n**2
@@ -532,6 +540,7 @@ def main():
     ap.add_argument("--nb", type=int, default=0, help="outer panel width override (single GPU) / distribution block (multi GPU)")
     ap.add_argument("--grid", default="", help="process grid PxQ of the multi-device run (default: chosen by the library)")
     ap.add_argument("--depth", type=int, default=0, help="look-ahead depth of the multi-device schedule")
+    ap.add_argument("--params", default="", help="ctx parameters name=value,name=value applied before the warm-up (e.g. multi_chain_cus=16,multi_trsm_inv=0: the A/B switches of tools/scale_sweep.sh)")
     ap.add_argument("--vranks", dest="virtual", type=int, default=0, help="V virtual ranks sharing GPU 0 (schedule test / 1-rank overhead measurement)")
     ap.add_argument("--selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--comparator-child", action="store_true", help=argparse.SUPPRESS)
@@ -609,11 +618,16 @@ def main():
                 ctx = agp.Context(devices=devices, P=P, Q=Q, nb=args.nb or 0)
                 if args.depth:
                     ctx.set_param("lookahead_depth", args.depth)
+                for kv in [kv for kv in args.params.split(",") if "=" in kv]:
+                    ctx.set_param(kv.split("=")[0].strip(), int(kv.split("=")[1]))
                 info = ctx.multi_info()
+                info["trsm_inv"], info["chain_cus"] = ctx.get_param("multi_trsm_inv"), ctx.get_param("multi_chain_cus")
             else:
                 ctx = agp.Context(local_rank)
                 if args.nb:
                     ctx.set_param("nb", args.nb)
+                for kv in [kv for kv in args.params.split(",") if "=" in kv]:
+                    ctx.set_param(kv.split("=")[0].strip(), int(kv.split("=")[1]))
             f = agp.GP(kernel, ctx=ctx)
             fx = f(agp.RowVecs(x), sigma2)
 
@@ -720,7 +734,9 @@ def main():
                 extra["multi_stats"] = ctx.multi_stats()  # fits / retries (repetitions after a failed self-check) / solves: a non-zero retry count is never silent
             if multi:
                 parallelism = (f"in-library 2D block-cyclic {info['P']}x{info['Q']}, nb={info['nb']}, look-ahead {info['lookahead_depth']}, "
-                               f"transport {info['comm']}" + (f" [{args.virtual} virtual ranks on one GPU]" if args.virtual else "")
+                               f"transport {info['comm']}, rows-below solve {'inverse block' if info['trsm_inv'] else 'substitution'}, "
+                               f"chain stream {'on ' + str(info['chain_cus']) + ' masked CUs' if info['chain_cus'] else 'unmasked'}"
+                               + (f" [{args.virtual} virtual ranks on one GPU]" if args.virtual else "")
                                + ("; one driver process, launcher ranks > 0 idle" if world > 1 else ""))
                 if transport:
                     extra["transport_selftest"] = transport
@@ -740,6 +756,7 @@ def main():
                        "parallelism": parallelism},
             "roofline": roofline,
             "logpdf": logpdf_val,
+            "lib_sha16": lib_sha16(),
         }
         line.update(extra)
         if not multi and not args.no_cpu_baseline:

@@ -131,7 +131,7 @@ int32_t gp_ctx_multi_stats(gp_ctx* ctx, int64_t* fits, int64_t* retries, int64_t
 int32_t gp_multi_solve_trace(int32_t P, int32_t Q, int32_t nblk, const char* path);
 int32_t gp_multi_solve_trace_ex(int32_t P, int32_t Q, int32_t nblk, int32_t flags, const char* path);
 /* The schedule the multi-device driver issues for a P×Q grid over nblk block columns (look-ahead depth 1..3; comm 1 =
- * send/recv transport, 2 = copies), written as JSON lines to `path`: every stream operation with its block footprint, every
+ * send/recv transport, 2 = copies; + 16 = the schedule of "multi_trsm_inv" = 0, + 32 = that of "multi_chain_cus" > 0), written as JSON lines to `path`: every stream operation with its block footprint, every
  * event record / wait, every transfer — produced by the SAME rank-thread code that drives the devices, run without a device
  * (works on a machine without a GPU).  tools/multi_schedule_check.py checks happens-before on it. */
 int32_t gp_multi_schedule_trace(int32_t P, int32_t Q, int32_t nblk, int32_t depth, int32_t comm, const char* path);
@@ -190,6 +190,16 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "multi_leaf_cols"  multi-device: columns per register-resident leaf inside the rank contexts — 64 (46 KB of LDS: starts beside the bulk
  *                    update) rather than the single-device 128 (152 KB: waits for an empty CU, i.e. for the end of a GEMM launch)   default 64
  *   "multi_window"   multi-device: block steps a rank thread may queue ahead of its device         default 16
+ *   "multi_trsm_inv" multi-device: the diagonal owner of block column k forms −inv(L_kk) (kept in a slot of its own) and THAT travels to the column's other
+ *                    owners instead of L_kk; every owner then solves its rows below the block with ONE triangular-k MFMA GEMM + one copy instead of the
+ *                    substitution recursion's nb/64 latency-bound leaf launches and as many few-tile GEMMs (nb = 1 024: 31 launches per rank and step -> 2).
+ *                    Same conditioning rule as "dib_nb", decided from the inputs before the fit: every pivot of K + Σy lies in
+ *                    [min Σy_ii, variance + max Σy_ii], and a fit with sqrt((variance + max Σy) / min Σy) > 1e5 keeps the substitution solve.   default 1
+ *   "multi_chain_cus" multi-device: r > 0 reserves r CUs (r/8 of every XCD; multiple of 8, at most half the device) of every rank's GPU for the diagonal
+ *                    block's chain (Cholesky of the nb×nb block + its inverse) on a CU-masked stream of its own; the panel and main streams' work then
+ *                    runs on streams masked to the other CUs.  Measured on one GPU (profiles/r5/cumask_chain_probe.jsonl): a 1 024-column chain beside the bulk
+ *                    update 3.6 ms unmasked -> 0.46 ms on 16 CUs, the update 4 % slower; masked HIP streams carry no priority, so the look-ahead update
+ *                    loses its priority over the bulk update — the trade-off a multi-GPU run has to price (tools/scale_sweep.sh A/Bs it).   default 0
  *   "multi_debug_sync", "multi_inject_fault"  multi-device diagnostics: host synchronisation points of the rank threads (bit mask) /
  *                    hand the next fit's self-check a spoiled α once (tests/test_gpu_multi.py)      default 0, 0
  *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */

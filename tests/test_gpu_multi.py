@@ -74,6 +74,67 @@ def test_lookahead_depths_and_ragged_sizes(agp, depth, P, Q, n, nb):
         ctx.close()
 
 
+@pytest.mark.parametrize("inv,cus", [(0, 0), (1, 16), (0, 16), (1, 64)], ids=["subst", "inv_chain16", "subst_chain16", "inv_chain64"])
+@pytest.mark.parametrize("P,Q,n,nb", [(2, 2, 2300, 256), (4, 1, 1800, 128), (2, 4, 2100, 128)])
+def test_rows_below_solve_variants_and_the_masked_chain_stream(agp, P, Q, n, nb, inv, cus):
+    """The non-default settings of the panel step: "multi_trsm_inv" = 0 (L_kk travels, substitution recursion below it; the default — −inv(L_kk) travels,
+    one triangular-k GEMM per owner — is what every other test of this file runs) and "multi_chain_cus" = r (the diagonal block's Cholesky + inverse on a
+    stream masked to r CUs, panel / main work on the complement), against the oracle at the single-GPU tolerances, two fits each; the masked streams are
+    dropped again with 0."""
+    x, y = o.synth_inputs(n, 3, 90 + P + Q)
+    rng = np.random.default_rng(n)
+    s2 = 0.03 + 0.04 * rng.random(n)
+    of = o.GP(o.Kernel(o.MATERN32, 1.2, 0.9))
+    lp_ref, opost = o.logpdf_and_posterior(o.FiniteGP(of, x, s2), y)
+    ctx = agp.Context(devices=rank_devices(P * Q), P=P, Q=Q, nb=nb)
+    try:
+        assert ctx.get_param("multi_trsm_inv") == 1 and ctx.get_param("multi_chain_cus") == 0      # the defaults
+        ctx.set_param("multi_trsm_inv", inv)
+        ctx.set_param("multi_chain_cus", cus)
+        assert ctx.get_param("multi_trsm_inv") == inv and ctx.get_param("multi_chain_cus") == cus
+        f = agp.GP(1.2 * agp.Matern32Kernel() @ agp.ScaleTransform(0.9), ctx=ctx)
+        for _ in range(2):
+            post = agp.posterior(f(agp.RowVecs(x), s2), y)
+            assert float(post.logpdf_value) == pytest.approx(lp_ref, rel=1e-10)
+            assert _relnorm(post.data.alpha, opost.alpha) <= 1e-8
+        xs = x[:50] + 0.03
+        m, v = post.mean_and_var(agp.RowVecs(xs))
+        mo, vo = opost.mean_and_var(xs)
+        np.testing.assert_allclose(m, mo, atol=1e-8)
+        np.testing.assert_allclose(v, vo, atol=1e-9)
+        assert np.max(np.abs(post.data.C.U - opost.U)) <= 1e-10
+        ctx.set_param("multi_chain_cus", 0)
+        assert ctx.get_param("multi_chain_cus") == 0
+        post = agp.posterior(f(agp.RowVecs(x), s2), y)
+        assert float(post.logpdf_value) == pytest.approx(lp_ref, rel=1e-10)
+        assert ctx.multi_stats()["retries"] == 0
+    finally:
+        ctx.close()
+
+
+def test_ill_conditioned_inputs_keep_the_substitution_solve(agp):
+    """The explicit inverse of a diagonal block is used only while sqrt((variance + max Σy) / min Σy) <= 1e5 (every pivot of K + Σy lies between min Σy and
+    variance + max Σy): one observation with noise variance 1e-12 puts the bound at 1e6, and the fit is then BITWISE the fit of a context with
+    "multi_trsm_inv" = 0 — while with ordinary noise the two settings agree to rounding only."""
+    n = 1200
+    x, y = o.synth_inputs(n, 2, 17)
+    out = {}
+    for tag, tiny in (("guarded", 1e-12), ("plain", 0.05)):
+        s2 = np.full(n, 0.05)
+        s2[7] = tiny
+        for inv in (1, 0):
+            ctx = agp.Context(devices=rank_devices(4), P=2, Q=2, nb=128)
+            try:
+                ctx.set_param("multi_trsm_inv", inv)
+                post = agp.posterior(agp.GP(agp.Matern52Kernel(), ctx=ctx)(agp.RowVecs(x), s2), y)
+                out[(tag, inv)] = np.array(post.data.C.U)
+            finally:
+                ctx.close()
+    assert np.array_equal(out[("guarded", 1)], out[("guarded", 0)])
+    assert not np.array_equal(out[("plain", 1)], out[("plain", 0)])
+    np.testing.assert_allclose(out[("plain", 1)], out[("plain", 0)], atol=1e-11)
+
+
 def test_multi_sequential_update_and_rand_after_gather(agp):
     """posterior(f_post(x2, σ²), y2) on a posterior that was fitted block-cyclically (extended on the pieces, then gathered for
     C.U) and prior sampling through the gathered factor."""

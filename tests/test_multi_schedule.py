@@ -16,6 +16,11 @@ sys.path.insert(0, str(ROOT / "tools"))
 import multi_schedule_check as M  # noqa: E402
 
 COPIES, SENDRECV = 2, 1
+SUBST = 16   # comm + 16: the schedule with the substitution solve of the rows below a diagonal block ("multi_trsm_inv" = 0: L_kk itself travels);
+             # without it (the default) the diagonal owner's −inv(L_kk) travels and every owner's solve is one triangular-k GEMM
+CHAIN = 32   # comm + 32: the diagonal block's chain (Cholesky + inverse) on a stream of its own ("multi_chain_cus" > 0)
+ALL_COMMS = [COPIES, SENDRECV, COPIES + SUBST, SENDRECV + SUBST, COPIES + CHAIN, SENDRECV + CHAIN, COPIES + SUBST + CHAIN]
+ALL_IDS = ["copies", "sendrecv", "copies_subst", "sendrecv_subst", "copies_chain", "sendrecv_chain", "copies_subst_chain"]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -23,7 +28,7 @@ def _built(agp):  # the .so (cross-compiled here when missing); no GPU is needed
     return agp
 
 
-@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
+@pytest.mark.parametrize("comm", ALL_COMMS, ids=ALL_IDS)
 @pytest.mark.parametrize("grid", M.GRIDS)
 def test_no_unordered_conflicts(grid, comm):
     P, Q = grid
@@ -154,7 +159,7 @@ def test_solve_passes_visit_every_block_column_once_per_sweep(grid):
             assert all(v == sorted(v, reverse=True) for v in per_rank.values()), (grid, sweep)
 
 
-@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
+@pytest.mark.parametrize("comm", ALL_COMMS, ids=ALL_IDS)
 @pytest.mark.parametrize("grid", M.GRIDS)
 def test_fit_updates_every_block_by_every_earlier_panel_exactly_once(grid, comm):
     """completeness of the factorisation schedule (right-looking): block (i, j) of the lower triangle — and the right-hand-side
@@ -234,7 +239,7 @@ def _operand_dataflow(hdr, lines):
     for i in range(n):
         for loc in g.wr[i]:
             writers.setdefault(loc, []).append(i)
-    OPERAND = ("Ab", "Bb", "St", "Lkk")
+    OPERAND = ("Ab", "Bb", "St", "Lkk", "Wi")
 
     def latest_writer(i, loc):
         cands = [w for w in writers.get(loc, []) if (reach[i] >> w) & 1]
@@ -285,7 +290,7 @@ def _operand_dataflow(hdr, lines):
             continue
         panel = int(m.group(5)) if m.group(3) in ("la", "bulk") else int(m.group(4))
         for loc in g.rd[i]:
-            if loc[0] not in ("Ab", "Bb", "Lkk"):
+            if loc[0] not in ("Ab", "Bb", "Lkk", "Wi"):
                 continue
             w = latest_writer(i, loc)
             checked += 1
@@ -294,7 +299,7 @@ def _operand_dataflow(hdr, lines):
     return checked, bad
 
 
-@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
+@pytest.mark.parametrize("comm", ALL_COMMS, ids=ALL_IDS)
 @pytest.mark.parametrize("grid", M.GRIDS)
 def test_updates_consume_the_blocks_of_their_own_panel(grid, comm):
     """data flow of the traced schedule, both transports: what an update of panel k reads from the operand slots — and what the
@@ -310,6 +315,68 @@ def test_updates_consume_the_blocks_of_their_own_panel(grid, comm):
         checked, bad = _operand_dataflow(hdr, lines)
         assert not bad, (grid, depth, bad[:3])
         assert checked > 0 or P * Q == 1
+
+
+@pytest.mark.parametrize("comm", [COPIES, SENDRECV], ids=["copies", "sendrecv"])
+@pytest.mark.parametrize("grid", [g for g in M.GRIDS if g[0] > 1])
+def test_inverse_block_solve_schedule(grid, comm):
+    """"multi_trsm_inv" (default): per block column k exactly ONE inv_lkk, on the diagonal owner, written to a slot of its own that no other
+    operation of the fit writes (peers may read it at any later time); the owner's rows-below solve reads that slot, every other owner of the
+    column reads its L_kk image — filled from the owner's slot by the peer copy or by the matched send / receive; nothing reads L_kk out of the
+    factor matrix any more except the inverse itself.  With comm + 16 no inv_lkk appears and the images are filled from the matrix."""
+    P, Q = grid
+    with __import__("tempfile").TemporaryDirectory() as td:
+        path = Path(td) / "t.jsonl"
+        M.emit_trace(P, Q, 9, 2, comm, path)
+        hdr, lines = M.load(path)
+        M.emit_trace(P, Q, 9, 2, comm + SUBST, path)
+        hdr0, lines0 = M.load(path)
+    assert hdr["inv"] == 1 and hdr0["inv"] == 0
+    assert not [ln for ln in lines0 if ln["t"] == "op" and ln["n"] == "inv_lkk"]
+    nblk = hdr["nblk"]
+    inv = [ln for ln in lines if ln["t"] == "op" and ln["n"] == "inv_lkk"]
+    assert sorted((ln["k"][0], ln["r"]) for ln in inv) == [(k, (k % P) * Q + k % Q) for k in range(nblk)]
+    slots = {}
+    for ln in lines:
+        if ln["t"] != "op" or ln["n"] == "init":
+            continue
+        for f in ln["W"]:
+            for key in M.expand(f, hdr):
+                if key[0] == "Wi":
+                    slots.setdefault(key, []).append(ln["n"])
+    assert len(slots) == nblk and all(v == ["inv_lkk"] for v in slots.values()), slots
+    for ln in lines:
+        if ln["t"] == "op" and ln["n"] == "trsm":
+            names = {f[0] for f in ln["R"]}
+            owner = ln["r"] == (ln["k"][0] % P) * Q + ln["k"][0] % Q
+            assert ("Wi" in names) == owner and ("Lkk" in names) == (not owner), ln
+        if ln["t"] == "op" and ln["n"] == "pull_lkk":
+            assert {f[0] for f in ln["R"]} == {"Wi"}, ln
+
+
+def test_chain_stream_schedule():
+    """"multi_chain_cus" > 0 (comm + 32): the Cholesky of every diagonal block and its inverse are the ONLY operations on the chain stream "sd", each preceded
+    by a wait for the panel stream (the block's last look-ahead update) and followed by a record the panel stream waits for; without the flag no
+    operation names that stream."""
+    with __import__("tempfile").TemporaryDirectory() as td:
+        path = Path(td) / "t.jsonl"
+        M.emit_trace(4, 2, 9, 2, COPIES + CHAIN, path)
+        hdr, lines = M.load(path)
+        M.emit_trace(4, 2, 9, 2, COPIES, path)
+        hdr0, lines0 = M.load(path)
+    assert hdr["chain"] == 1 and hdr0["chain"] == 0
+    assert not [ln for ln in lines0 if ln.get("s") == "sd"]
+    on_sd = [ln for ln in lines if ln["t"] == "op" and ln["s"] == "sd"]
+    assert {ln["n"] for ln in on_sd} == {"potrf_diag", "inv_lkk"}
+    assert not [ln for ln in lines if ln["t"] == "op" and ln["n"] in ("potrf_diag", "inv_lkk") and ln["s"] != "sd"]
+    nblk = hdr["nblk"]
+    assert len(on_sd) == 2 * nblk
+    waits = [ln for ln in lines if ln["t"] == "wait" and ln["s"] == "sd"]
+    recs = [ln for ln in lines if ln["t"] == "rec" and ln["s"] == "sd"]
+    assert len(waits) == nblk and {ln["tag"] for ln in waits} == {"to_chain"}
+    assert len(recs) == nblk and {ln["tag"] for ln in recs} == {"from_chain"}
+    back = [ln for ln in lines if ln["t"] == "wait" and ln["tag"] == "from_chain"]
+    assert len(back) == nblk and {ln["s"] for ln in back} == {"sp"}
 
 
 def test_dataflow_check_notices_a_stale_slot():

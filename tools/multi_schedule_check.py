@@ -87,7 +87,7 @@ def expand(fp, hdr):
                 out.add(("A2", r, li, lj))
     elif name == "Lkk":
         out.add(("Lkk", r))
-    elif name in ("acc", "alb", "tmp", "ACC", "X", "Xb", "T", "Vs", "Cv"):  # (the last six: buffers of the forward solve on the distributed factor)
+    elif name in ("acc", "alb", "tmp", "Wi", "ACC", "X", "Xb", "T", "Vs", "Cv"):  # (Wi: the −inv(L_kk) slots of a diagonal owner; the last six: buffers of the forward solve on the distributed factor)
         for i in range(b0, b1):
             out.add((name, r, i))
     else:
