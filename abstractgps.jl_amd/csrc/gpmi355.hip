@@ -116,8 +116,19 @@ void ctx_unref(gp_ctx* c) {
     if (c->w_ws) (void)hipFree(c->w_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
     if (c->sp) (void)hipStreamDestroy(c->sp);
+    if (c->sq) (void)hipStreamDestroy(c->sq);
     if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
     delete c;
+}
+// the ctx's third stream (same priority as the main stream), created and primed on first use
+int32_t ctx_third_stream(gp_ctx* c, hipStream_t* out) {
+    if (!c->sq) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamCreateWithFlags(&c->sq, hipStreamNonBlocking));
+        RC(ctx_prime_stream(c, c->sq));
+    }
+    *out = c->sq;
+    return 0;
 }
 int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing) {
     // timing events are separate objects (created on demand, pooled)
@@ -1151,7 +1162,7 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
         // fold the sign: the kernels below read +C⁻¹
         {
             const long cnt = np * ld;
-            hipLaunchKernelGGL((convert_kernel<T, T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const T*)Ci, Ci, cnt,
+            hipLaunchKernelGGL((convert_kernel<T, T>), convert_grid(cnt), dim3(256), 0, s, (const T*)Ci, Ci, cnt,
                                -1.0);
             HIPCHK(hipGetLastError());
         }
@@ -1687,6 +1698,8 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "ldpad")) c->ldpad = round_up(std::max<int64_t>(0, v), 16);
     else if (!strcmp(name, "vfe_ks")) c->vfe_ks = std::max<int64_t>(512, round_up(v, 512));
     else if (!strcmp(name, "vfe_sk")) c->vfe_sk = v != 0;
+    else if (!strcmp(name, "vfe_dual")) c->vfe_dual = v != 0;
+    else if (!strcmp(name, "vfe_inv_nb")) c->vfe_inv_nb = v <= 0 ? 0 : round_up(v, 128);
     else if (!strcmp(name, "vfe_overlap")) c->vfe_overlap = v != 0;
     else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
@@ -1709,7 +1722,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb}, {"deterministic", c->deterministic},
         {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
-        {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
+        {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_dual", c->vfe_dual}, {"vfe_inv_nb", c->vfe_inv_nb}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
         {"kmat_rows", g_kmat_rows.load()}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {

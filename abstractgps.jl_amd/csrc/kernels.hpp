@@ -1926,9 +1926,11 @@ __global__ __launch_bounds__(256) void identity_kernel(T* __restrict__ A, long l
 }
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, double scale) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = (TD)(scale * (double)src[i]);
+    // grid-stride: a launch may not carry 2³² work-items per dimension (the runtime wraps the count WITHOUT an error — round 6: the gradient's sign fold
+    // over np·ld = 65 536 · 65 568 > 2³² elements touched the first 2 M only; launches go through convert_grid below)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (TD)(scale * (double)src[i]);
 }
+static inline dim3 convert_grid(long n) { return dim3((unsigned)std::min<long>((n + 255) / 256, 1L << 20)); }
 // r[j] -= Σ_{i<nrows} L[i][j] a[i]  for j < ncols.  grid (ceil(ncols/256), ceil(nrows/64)); one atomic per (block, column)
 template <typename T, typename RT = T>
 __global__ __launch_bounds__(256) void gemv_t_kernel(const T* __restrict__ L, long ldl, long nrows, long ncols,

@@ -203,6 +203,13 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     // buffers: kmat of chunk c+1 and the partial-sum adds of chunk c overlap the GEMMs of their neighbours ("vfe_overlap").
     hipStream_t sa = c->vfe_overlap ? c->sp : s;
     const bool ovl = sa != s;
+    // "vfe_dual": the chunk SYRKs on a third stream sy, the triangular products stay on s — Y(c+1) is independent of SYRK(c), so the two launches run
+    // side by side and each fills the other's last partial round of workgroups (SYRK: 528 lower tiles × 8 partials = 4 224 workgroups = 8.25 rounds of the
+    // 512 slots; Y: 4 096 tiles of unequal length).  Same buffers, same arithmetic, same order of the sums into D_acc (the SYRKs stay ordered on sy).
+    hipStream_t sy = s;
+    if (ovl && c->vfe_dual) RC(ctx_third_stream(c, &sy));
+    const bool dual = sy != s;
+    hipEvent_t evSy[2] = {nullptr, nullptr};  // SYRK(c) has finished reading Y[bb]
     void* Xb[2] = {X_v, X2_v};
     void* Yb[2] = {Y_v, Y2_v};
     void* Sb[2] = {S_v, S2_v};
@@ -228,6 +235,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             if (ovl) {
                 HIPCHK(hipStreamWaitEvent(s, evK[bb], 0));
                 if (evYs[bb]) HIPCHK(hipStreamWaitEvent(s, evYs[bb], 0));  // chunk cidx−2 is done with Y[bb]
+                if (dual && evSy[bb]) HIPCHK(hipStreamWaitEvent(s, evSy[bb], 0));  // ... its SYRK too
             }
             {
                 GridMap gy = plain_map(0, 0, 0);
@@ -240,6 +248,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 RC(ctx_event(c, &e, false));
                 HIPCHK(hipEventRecord(e, s));
                 HIPCHK(hipStreamWaitEvent(sa, e, 0));
+                if (dual) HIPCHK(hipStreamWaitEvent(sy, e, 0));
             }
             hipLaunchKernelGGL(ystats_kernel<T>, dim3((unsigned)(mp - row_lo)), dim3(256), 0, sa, (const T*)Yb[bb], ldy, CH,
                                (const T*)sg.b + c0, row_lo, (double*)cT_v, (double*)rss_v);   // c += B_c b_c ; ‖B‖² rows (fp64)
@@ -254,8 +263,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             }
             const T* Yr = (const T*)Yb[bb] + row_lo * ldy;
             if constexpr (is_f64) {
-                RC((launch_gemm<T, double>(c, s, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, CH,
+                RC((launch_gemm<T, double>(c, sy, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, CH,
                                            plain_map(1, row_lo, 0))));
+                if (dual) {
+                    RC(ctx_event(c, &evSy[bb], false));
+                    HIPCHK(hipEventRecord(evSy[bb], sy));
+                }
             } else {
                 // fp32: the chunk's SYRK runs on the LDS-DMA kernel into fp32 scratch — NBAT partial products over KS data points
                 // each in ONE launch (blockIdx.z) — which one pass then adds into the fp64 accumulator: fp64 sums across
@@ -264,13 +277,14 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 gs.beta0 = 1;
                 gs.nbatch = NBAT;
                 gs.cstride = (long)(mp + 128) * ld;
-                if (ovl && evAdd[bb]) HIPCHK(hipStreamWaitEvent(s, evAdd[bb], 0));  // chunk cidx−2's partials have been added
-                RC(launch_gemm<T>(c, s, (T*)Sb[bb] + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, KS, gs));
+                if (ovl && evAdd[bb]) HIPCHK(hipStreamWaitEvent(sy, evAdd[bb], 0));  // chunk cidx−2's partials have been added
+                RC(launch_gemm<T>(c, sy, (T*)Sb[bb] + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, KS, gs));
                 if (ovl) {
                     hipEvent_t e;
                     RC(ctx_event(c, &e, false));
-                    HIPCHK(hipEventRecord(e, s));
+                    HIPCHK(hipEventRecord(e, sy));
                     HIPCHK(hipStreamWaitEvent(sa, e, 0));
+                    if (dual) evSy[bb] = e;
                 }
                 hipLaunchKernelGGL(add_lower_batched_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(mp - row_lo)), dim3(256),
                                    0, sa, (const T*)Sb[bb], gs.cstride, NBAT, ld, (double*)D_v, ld, mp, row_lo);
@@ -290,6 +304,11 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         RC(ctx_event(c, &e, false));
         HIPCHK(hipEventRecord(e, sa));
         HIPCHK(hipStreamWaitEvent(s, e, 0));
+        if (dual) {
+            RC(ctx_event(c, &e, false));
+            HIPCHK(hipEventRecord(e, sy));
+            HIPCHK(hipStreamWaitEvent(s, e, 0));
+        }
         return 0;
     };
 
@@ -382,11 +401,27 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             HIPCHK(hipMemsetAsync(I_v, 0, L_b, s));
             hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
             HIPCHK(hipGetLastError());
-            RC(trsm_upper_rec<double>(c, s, Iw, ld, Lz, ld, 0, mp));
+            const long inb = c->vfe_inv_nb;
+            if (inb >= 128 && mp >= 2 * inb) {
+                // the inverse diagonal blocks of L_z, all at once (dib_build: every launch of the restricted-row recursion carries the batch; L_bb⁻ᵀ lands on Iw's
+                // diagonal), then the levels above them with ONE triangular-k GEMM per block — the mechanism of the gradient's L⁻ᵀ (grad_impl)
+                const long ldw = inb + c->ldpad;
+                const size_t wb = sizeof(double) * (size_t)(mp + 128) * ldw;
+                void *Wn_v = 0, *Iw2_v = 0, *Sw_v = 0;
+                RC(bufs.get(wb, &Wn_v));
+                RC(bufs.get(wb, &Iw2_v));
+                RC(bufs.get(wb, &Sw_v));
+                RC(dib_build<double>(c, s, Lz, ld, mp, inb, (double*)Wn_v, ldw, (double*)Iw2_v, Iw, ld));
+                DibArgs<double> dib;
+                dib.W = (const double*)Wn_v; dib.ldw = ldw; dib.nbi = inb; dib.S = (double*)Sw_v; dib.lds = ldw;
+                RC(trsm_upper_rec<double>(c, s, Iw, ld, Lz, ld, 0, mp, dib));
+            } else {
+                RC(trsm_upper_rec<double>(c, s, Iw, ld, Lz, ld, 0, mp));
+            }
             hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, s, Iw, ld, Ld, ld, mp);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemsetAsync(Li_v, 0, Li_b, s));
-            hipLaunchKernelGGL((convert_kernel<double, T>), dim3((unsigned)(((long)mp * ld + 255) / 256)), dim3(256), 0, s, Ld,
+            hipLaunchKernelGGL((convert_kernel<double, T>), convert_grid((long)mp * ld), dim3(256), 0, s, Ld,
                                (T*)Li_v, (long)mp * ld, 1.0);
             HIPCHK(hipGetLastError());
         }
@@ -397,6 +432,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             RC(ctx_event(c, &e, false));
             HIPCHK(hipEventRecord(e, s));
             HIPCHK(hipStreamWaitEvent(sa, e, 0));
+            if (dual) HIPCHK(hipStreamWaitEvent(sy, e, 0));
         }
         if (mode == VFE_APPEND) {
             for (size_t si = 0; si < prev->segs.size(); ++si)
@@ -405,7 +441,8 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             RC(stream_seg(*seg, nullptr));
         }
         RC(stream_join());
-        hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, s,
+        HIPCHK(hipEventRecord(c->ev_phase[2], s));
+        hipLaunchKernelGGL((convert_kernel<double, double>), convert_grid(mp), dim3(256), 0, s,
                            (const double*)cT_v, vec, mp, 1.0);                                                              // c = B b_y
         HIPCHK(hipGetLastError());
         // ---- D = I + B Bᵀ (fp64, symmetric), Λ_ε = chol(D)                                       :68-69
@@ -423,7 +460,6 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         RC(trsv<double>(c, s, Ld, ld, mp, vec + mp, mp, 1, false));               // m_ε = L_D⁻ᵀ w      :71
         HIPCHK(hipMemcpyAsync(vec + 2 * mp, vec + mp, sizeof(double) * mp, hipMemcpyDeviceToDevice, s));
         RC(trsv<double>(c, s, Lz, ld, mp, vec + 2 * mp, mp, 1, false));           // α = L_z⁻ᵀ m_ε      :73
-        HIPCHK(hipEventRecord(c->ev_phase[2], s));
         HIPCHK(hipEventRecord(c->ev_phase[3], s));
         HIPCHK(hipMemcpyAsync(&info_h, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(scal_h, c->scal_dev, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
@@ -431,10 +467,11 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         HIPCHK(hipStreamSynchronize(s));
         float ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[1]));
-        c->tm.assemble_ms = ms;  // K_zz + its Cholesky
+        c->tm.assemble_ms = ms;  // the M×M prelude: K_zz, its Cholesky, inv(L_z)
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[1], c->ev_phase[2]));
-        c->tm.potrf_ms = ms;     // streamed pass + M×M side
-        c->tm.solve_ms = 0;
+        c->tm.potrf_ms = ms;     // the streamed pass over the data points
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[2], c->ev_phase[3]));
+        c->tm.solve_ms = ms;     // the M×M side after it: Λ_ε = chol(I + B Bᵀ), the vector solves
         HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[3]));
         c->tm.total_ms = ms;
         c->tm.gemm_ms = 0;
@@ -544,7 +581,7 @@ static int32_t vfe_joint(gp_vfe* p, const gp_points* xs, const void* pm, const g
     RC(trsm_cached<double>(c, s, X2, ld, nsp, (const double*)p->Ld, ld, mp, p->m, p->dib_d, bufs));
     {
         const long cnt = (long)(nsp + 128) * ld;
-        hipLaunchKernelGGL((convert_kernel<double, double>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const double*)X2,
+        hipLaunchKernelGGL((convert_kernel<double, double>), convert_grid(cnt), dim3(256), 0, s, (const double*)X2,
                            (double*)X2n_v, cnt, -1.0);
         HIPCHK(hipGetLastError());
     }

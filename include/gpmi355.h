@@ -184,6 +184,10 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
+ *   "vfe_dual"       VFE: the two MFMA GEMMs of a chunk on two streams — the triangular product of chunk c+1 runs beside the SYRK of chunk c, each filling
+ *                    the other's last partial round of workgroups (needs "vfe_overlap"); 0 = back to back on the main stream   default 1
+ *   "vfe_inv_nb"     VFE prelude: inv(L_z) through inverse diagonal blocks of this width, built in one batched launch sequence, the levels above them one
+ *                    triangular-k GEMM per block (≈ 40 launches at M = 4 096 instead of 127); 0 = the recursion down to 64-wide leaves   default 512
  *   "sk_max_tiles"   largest launch (in 128×128 tiles) that takes the persistent stream-K GEMM    default 4096
  *   "vfe_sk"         VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))   default 0
  *   "copy_kernel"    multi-device: block copies by a kernel instead of hipMemcpy2DAsync            default 0
@@ -210,7 +214,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
     "nb=-1,nb_small=4096,nb_large=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
     "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=0,gemm_pad_lds=0,trsv_nb=256,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
     "updk_max_k=512,updk_rt=0,updk_tall_k=256,updk_tall_m=8192,upd128=1,leaf_group=128,ldpad=32,vfe_ks=2048,vfe_sk=0,"          \
-    "vfe_overlap=1,vfe_chunk=16384,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"
+    "vfe_overlap=1,vfe_dual=1,vfe_inv_nb=512,vfe_chunk=16384,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Read a parameter back (same names; "gemm_pad_lds" reads 0 until it has been set explicitly).  Used by the test-suite to assert that
  * every GPU test starts from the documented defaults. */

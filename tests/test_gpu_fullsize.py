@@ -184,6 +184,38 @@ def test_c4_full_size_values_vs_oracle(agp):
         assert compare(alpha, dig) <= 1e-9
 
 
+def test_c4_gradient_vs_finite_differences_of_logpdf(agp):
+    """value + gradient at the headline size against central differences of gp_logpdf (a different entry point: no C⁻¹, no gradient kernels; its values
+    are pinned by the C4 value test above), component by component.  Round 6: the 4 500-point tests and the C2 check were green while the C4 gradient was
+    WRONG — N = 65 536 is the first size with more than 2³² matrix elements (np·ld = 65 536 · 65 568) and the one-thread-per-element sign fold of −C⁻¹ was
+    launched with a work-item count the runtime wrapped without an error (tools/grad_check.py, profiles/r6/grad_check.jsonl: variance −2 777 for −229,
+    noise 6.5e6 for 3 386).  rel 1e-5 as in the C2 test (the differences carry ≈ 1e-7)."""
+    n = 65536
+    x, y = o.synth_inputs(n, 3, 4)
+    ctx = agp.default_context()
+
+    def lp_at(var, sc, nz):
+        return float(agp.logpdf(agp.GP(var * agp.SqExponentialKernel() @ agp.ScaleTransform(sc))(agp.RowVecs(x), nz), y))
+
+    lp, g = agp.logpdf_and_grad(agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(1.0))(agp.RowVecs(x), 0.01), y, wrt_x=True)
+    ctx.trim()
+    assert float(lp) == pytest.approx(lp_at(1.0, 1.0, 0.01), rel=1e-12)
+    h = 1e-4
+    fd = {"variance": (lp_at(1 + h, 1.0, 0.01) - lp_at(1 - h, 1.0, 0.01)) / (2 * h),
+          "scale": (lp_at(1.0, 1 + h, 0.01) - lp_at(1.0, 1 - h, 0.01)) / (2 * h),
+          "noise": (lp_at(1.0, 1.0, 0.01 * (1 + h)) - lp_at(1.0, 1.0, 0.01 * (1 - h))) / (2 * h * 0.01)}
+    for name, val in fd.items():
+        assert float(g[name]) == pytest.approx(val, rel=1e-5), (name, float(g[name]), val)
+    # ∂/∂x along one random direction (the input-gradient kernel reads the same C⁻¹, mirrored for the tiles above the diagonal)
+    rng = np.random.default_rng(9)
+    dirx = rng.standard_normal(x.shape)
+    hx = 1e-5
+    fdx = (float(agp.logpdf(agp.GP(agp.SqExponentialKernel())(agp.RowVecs(x + hx * dirx), 0.01), y))
+           - float(agp.logpdf(agp.GP(agp.SqExponentialKernel())(agp.RowVecs(x - hx * dirx), 0.01), y))) / (2 * hx)
+    assert float(np.sum(g["x"] * dirx)) == pytest.approx(fdx, rel=1e-4)
+    ctx.trim()
+
+
 def test_committed_fullsize_parity_records():
     """The C4 / C5 (and C2 / C3) value comparisons produced on an MI355X box by tools/fullsize_parity.py."""
     import json

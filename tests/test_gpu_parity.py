@@ -211,6 +211,43 @@ def test_vfe_fp32_streaming(agp):
     assert got64 == pytest.approx(ref, rel=1e-7)
 
 
+@pytest.mark.parametrize("dual,inv_nb", [(1, 128), (0, 256), (1, 0), (0, 0)], ids=["dual_inv128", "single_inv256", "dual_leaves", "single_leaves"])
+def test_vfe_schedule_variants(agp, dual, inv_nb):
+    """The two round-6 switches of the sparse fit on a private context: "vfe_dual" (the chunk's SYRK on a third stream beside the next chunk's triangular
+    product; 0 = back to back) and "vfe_inv_nb" (inv(L_z) of the prelude through batched inverse diagonal blocks of that width — small here so that
+    M = 700 pseudo-points (padded 768: six 128-blocks, ragged three 256-blocks) takes the path the C5 default takes at M = 4 096; 0 = 64-wide leaves).
+    Three chunks of 16 384 observations (double buffers reused), fp32 and fp64, fit + ELBO + predictions + update_posterior against the fp64 oracle
+    (src/sparse_approximations.jl:58-75, 248-254, 183-217, 87-121)."""
+    rng = np.random.default_rng(55)
+    n, n2, m, d = 40000, 3000, 700, 3
+    X = rng.uniform(0, 4, (n + n2, d)).astype(np.float32).astype(np.float64)
+    y = (np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n + n2)).astype(np.float32).astype(np.float64)
+    z = X[rng.permutation(n)[:m]].copy()
+    xs = rng.uniform(0, 4, (200, d)).astype(np.float32).astype(np.float64)
+    of = o.GP(o.Kernel(o.SE))
+    ofx = o.FiniteGP(of, X[:n], 0.1)
+    op = o.vfe_posterior(of, z, 1e-4, ofx, y[:n])
+    elbo = o.objective_from_posterior(op, ofx, y[:n], vfe=True)
+    mo, vo = op.mean_and_var(xs)
+    op2 = o.vfe_posterior(of, z, 1e-4, o.FiniteGP(of, X, 0.1), y)
+    ctx = agp.Context(0)
+    ctx.set_param("vfe_dual", dual)
+    ctx.set_param("vfe_inv_nb", inv_nb)
+    try:
+        f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
+        for dt, rtol, atol in ((np.float32, 1e-4, 1e-3), (np.float64, 1e-8, 1e-6)):
+            ap = agp.posterior(agp.VFE(f(agp.RowVecs(z.astype(dt)), 1e-4)), f(agp.RowVecs(X[:n].astype(dt)), dt(0.1)), y[:n].astype(dt))
+            assert float(ap.objective) == pytest.approx(elbo, rel=rtol)
+            mm, vv = ap.mean_and_var(agp.RowVecs(xs.astype(dt)))
+            np.testing.assert_allclose(mm, mo, atol=atol)
+            np.testing.assert_allclose(vv, vo, atol=atol)
+            ap2 = agp.update_posterior(ap, f(agp.RowVecs(X[n:].astype(dt)), dt(0.1)), y[n:].astype(dt))
+            np.testing.assert_allclose(ap2.mean(agp.RowVecs(xs.astype(dt))), op2.mean(xs), atol=atol)
+            del ap, ap2
+    finally:
+        ctx.close()
+
+
 def test_sequential_conditioning_matches_batch(agp):
     """posterior(p_fx1(X2, σ²), y2) ≡ posterior(f(X, σ²), y) — reference test/exact_gpr_posterior.jl:29-43 (atol 1e-5 there),
     here also against the oracle's update_chol path and with n1, n2 that are not tile multiples."""
