@@ -68,7 +68,7 @@ struct gp_ctx {
     int device = 0;
     hipStream_t sm = nullptr;  // main stream (trailing updates, assembly, solves)
     hipStream_t sp = nullptr;  // panel stream (look-ahead)
-    hipStream_t sq = nullptr;  // third stream, created on first use (VFE: the chunk SYRKs beside the next chunk's triangular product — "vfe_dual")
+    hipStream_t sq = nullptr;  // third stream (high priority), created on first use (VFE: the next chunk's triangular product beside the chunk SYRK — "vfe_dual")
     bool own_sm = false;
     std::mutex mu;
     long nb = -1;          // outer panel width: −1 automatic (nb_small below lookahead_min_n — one-stream schedule, wider panels halve the passes over the
@@ -109,8 +109,8 @@ struct gp_ctx {
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
     int vfe_overlap = 1;   // VFE: kmat / ystats / partial-sum adds on the second stream beside the chunk GEMMs (double buffers)
     int vfe_sk = 0;        // VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))
-    int vfe_dual = 1;      // VFE: the two MFMA GEMMs of a chunk on TWO streams — Y(c+1) = −inv(L_z) X(c+1)ᵀ runs beside the SYRK of chunk c and each fills the
-                           // other's last partial wave of workgroups (4 224 workgroups per SYRK launch = 8.25 rounds of 512 slots); 0: back to back on one stream
+    int vfe_dual = 1;      // VFE: the triangular products Y(c) on a high-priority third stream beside the chunk SYRKs on the main stream: Y(c+1) takes the workgroup
+                           // slots first, SYRK(c) fills what it leaves (4 224 workgroups per SYRK launch = 8.25 rounds of 512 slots); 0: back to back on one stream
     long vfe_inv_nb = 512; // VFE prelude: inv(L_z) with the inverse diagonal blocks of this width built in one batched launch sequence (0: 64-wide leaves)
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;

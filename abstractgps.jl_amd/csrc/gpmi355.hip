@@ -120,11 +120,13 @@ void ctx_unref(gp_ctx* c) {
     if (c->own_sm && c->sm) (void)hipStreamDestroy(c->sm);
     delete c;
 }
-// the ctx's third stream (same priority as the main stream), created and primed on first use
+// the ctx's third stream (high priority, like the panel stream), created and primed on first use
 int32_t ctx_third_stream(gp_ctx* c, hipStream_t* out) {
     if (!c->sq) {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamCreateWithFlags(&c->sq, hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&c->sq, hipStreamNonBlocking, hi));
         RC(ctx_prime_stream(c, c->sq));
     }
     *out = c->sq;

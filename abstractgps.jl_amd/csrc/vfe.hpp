@@ -118,7 +118,10 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     std::vector<T> xs_h, znew_h;
     double logdet_sy = prev ? prev->logdet_sy : 0, dd = prev ? prev->dd : 0, tr_kff = prev ? prev->tr_kff : 0;
     std::vector<T> rs_h, b_h;
-    if (x) {
+    // the N-long host marshalling (scaled inputs, Σy^-1/2, b_y, the scalar sums: ≈ 1 ms at N = 262 144) runs AFTER the M×M prelude has been queued — the
+    // device factors K_zz and inverts L_z meanwhile
+    auto marshal_x = [&]() -> int32_t {
+        if (!x) return 0;
         scale_points<T>(k, x, npad, xs_h);
         rs_h.assign((size_t)npad, T(0));  // s_i = σ_i⁻¹
         b_h.assign((size_t)npad, T(0));   // b_i = s_i δ_i  (b_y, :66)
@@ -133,7 +136,8 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             dd += (double)b_h[i] * (double)b_h[i];
             tr_kff += k->variance / s2;  // tr_Cf_invΣy :307-313
         }
-    }
+        return 0;
+    };
     const long m2p = round_up(std::max(m2, 1L), 128);
     const long znp = mode == VFE_FIT ? mp : m2p;  // leading dimension of the freshly scaled inducing inputs
     if (z) scale_points<T>(k, z, znp, znew_h);
@@ -156,7 +160,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         seg->ctx = c;
         seg->n = n;
         seg->npad = npad;
-        RC(ctx_alloc(c, sizeof(T) * xs_h.size(), &seg->xs));
+        RC(ctx_alloc(c, sizeof(T) * (size_t)d * (size_t)npad, &seg->xs));
         RC(ctx_alloc(c, sizeof(T) * (size_t)npad, &seg->rs));
         RC(ctx_alloc(c, sizeof(T) * (size_t)npad, &seg->b));
     }
@@ -203,9 +207,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     // buffers: kmat of chunk c+1 and the partial-sum adds of chunk c overlap the GEMMs of their neighbours ("vfe_overlap").
     hipStream_t sa = c->vfe_overlap ? c->sp : s;
     const bool ovl = sa != s;
-    // "vfe_dual": the chunk SYRKs on a third stream sy, the triangular products stay on s — Y(c+1) is independent of SYRK(c), so the two launches run
-    // side by side and each fills the other's last partial round of workgroups (SYRK: 528 lower tiles × 8 partials = 4 224 workgroups = 8.25 rounds of the
-    // 512 slots; Y: 4 096 tiles of unequal length).  Same buffers, same arithmetic, same order of the sums into D_acc (the SYRKs stay ordered on sy).
+    // "vfe_dual": the triangular products Y(c) = −inv(L_z) X(c)ᵀ on a third, HIGH-priority stream sy, the chunk SYRKs stay on the main stream.  Y(c+1) is
+    // independent of SYRK(c); with the priority the workgroup slots go to Y(c+1) first and the SYRK in flight fills whatever Y leaves free — in particular
+    // each launch's last partial round of workgroups (SYRK: 528 lower tiles × 8 partials = 4 224 workgroups = 8.25 rounds of the 512 slots, ≈ 0.18 ms idle
+    // per launch when it runs alone; Y: 4 096 tiles of unequal length).  Same buffers, same arithmetic, same order of the sums into D_acc.  (First form of the
+    // round, both launches at EQUAL priority — Y on s, SYRK on the third stream: the two run side by side from the start, end together and leave their
+    // tails open: 79.5 -> 79.05 ms only, profiles/r6/c5_ab.jsonl.)
     hipStream_t sy = s;
     if (ovl && c->vfe_dual) RC(ctx_third_stream(c, &sy));
     const bool dual = sy != s;
@@ -233,22 +240,22 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             const int bb = ovl ? (int)(cidx & 1) : 0;
             if (!ovl || cidx == 0) RC(kmat_chunk(sg, c0, bb));  // (overlapped mode: later chunks were prefetched below)
             if (ovl) {
-                HIPCHK(hipStreamWaitEvent(s, evK[bb], 0));
-                if (evYs[bb]) HIPCHK(hipStreamWaitEvent(s, evYs[bb], 0));  // chunk cidx−2 is done with Y[bb]
-                if (dual && evSy[bb]) HIPCHK(hipStreamWaitEvent(s, evSy[bb], 0));  // ... its SYRK too
+                HIPCHK(hipStreamWaitEvent(sy, evK[bb], 0));
+                if (evYs[bb]) HIPCHK(hipStreamWaitEvent(sy, evYs[bb], 0));  // chunk cidx−2 is done with Y[bb]
+                if (dual && evSy[bb]) HIPCHK(hipStreamWaitEvent(sy, evSy[bb], 0));  // ... its SYRK too
             }
             {
                 GridMap gy = plain_map(0, 0, 0);
                 gy.beta0 = 1;
                 gy.ktri = 1;
-                RC(launch_gemm<T>(c, s, (T*)Yb[bb], ldy, (const T*)Li_v, ld, (const T*)Xb[bb], ld, mp, CH, mp, gy));   // Y = −B_c
+                RC(launch_gemm<T>(c, sy, (T*)Yb[bb], ldy, (const T*)Li_v, ld, (const T*)Xb[bb], ld, mp, CH, mp, gy));   // Y = −B_c
             }
             if (ovl) {
                 hipEvent_t e;
                 RC(ctx_event(c, &e, false));
-                HIPCHK(hipEventRecord(e, s));
+                HIPCHK(hipEventRecord(e, sy));
                 HIPCHK(hipStreamWaitEvent(sa, e, 0));
-                if (dual) HIPCHK(hipStreamWaitEvent(sy, e, 0));
+                if (dual) HIPCHK(hipStreamWaitEvent(s, e, 0));
             }
             hipLaunchKernelGGL(ystats_kernel<T>, dim3((unsigned)(mp - row_lo)), dim3(256), 0, sa, (const T*)Yb[bb], ldy, CH,
                                (const T*)sg.b + c0, row_lo, (double*)cT_v, (double*)rss_v);   // c += B_c b_c ; ‖B‖² rows (fp64)
@@ -263,11 +270,11 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             }
             const T* Yr = (const T*)Yb[bb] + row_lo * ldy;
             if constexpr (is_f64) {
-                RC((launch_gemm<T, double>(c, sy, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, CH,
+                RC((launch_gemm<T, double>(c, s, (double*)D_v + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, CH,
                                            plain_map(1, row_lo, 0))));
                 if (dual) {
                     RC(ctx_event(c, &evSy[bb], false));
-                    HIPCHK(hipEventRecord(evSy[bb], sy));
+                    HIPCHK(hipEventRecord(evSy[bb], s));
                 }
             } else {
                 // fp32: the chunk's SYRK runs on the LDS-DMA kernel into fp32 scratch — NBAT partial products over KS data points
@@ -277,12 +284,12 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                 gs.beta0 = 1;
                 gs.nbatch = NBAT;
                 gs.cstride = (long)(mp + 128) * ld;
-                if (ovl && evAdd[bb]) HIPCHK(hipStreamWaitEvent(sy, evAdd[bb], 0));  // chunk cidx−2's partials have been added
-                RC(launch_gemm<T>(c, sy, (T*)Sb[bb] + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, KS, gs));
+                if (ovl && evAdd[bb]) HIPCHK(hipStreamWaitEvent(s, evAdd[bb], 0));  // chunk cidx−2's partials have been added
+                RC(launch_gemm<T>(c, s, (T*)Sb[bb] + row_lo * ld, ld, Yr, ldy, (const T*)Yb[bb], ldy, mp - row_lo, mp, KS, gs));
                 if (ovl) {
                     hipEvent_t e;
                     RC(ctx_event(c, &e, false));
-                    HIPCHK(hipEventRecord(e, sy));
+                    HIPCHK(hipEventRecord(e, s));
                     HIPCHK(hipStreamWaitEvent(sa, e, 0));
                     if (dual) evSy[bb] = e;
                 }
@@ -314,11 +321,6 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
 
     int32_t rc = [&]() -> int32_t {
         HIPCHK(hipEventRecord(c->ev_phase[0], s));
-        if (x) {
-            HIPCHK(hipMemcpyAsync(seg->xs, xs_h.data(), sizeof(T) * xs_h.size(), hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(seg->rs, rs_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(seg->b, b_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, s));
-        }
         HIPCHK(hipMemcpyAsync(jit_v, jit_h.data(), jit_b, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(c->info_dev, 0, sizeof(int), s));
         HIPCHK(hipMemsetAsync(c->scal_dev, 0, sizeof(double) * 16, s));
@@ -424,6 +426,14 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             hipLaunchKernelGGL((convert_kernel<double, T>), convert_grid((long)mp * ld), dim3(256), 0, s, Ld,
                                (T*)Li_v, (long)mp * ld, 1.0);
             HIPCHK(hipGetLastError());
+        }
+        // ---- the observations: marshalled on the host while the device works through the prelude queued above, uploaded on the helper stream (the first
+        //      consumers — kmat, ystats — run there; the main stream joins through their events)
+        RC(marshal_x());
+        if (x) {
+            HIPCHK(hipMemcpyAsync(seg->xs, xs_h.data(), sizeof(T) * xs_h.size(), hipMemcpyHostToDevice, sa));
+            HIPCHK(hipMemcpyAsync(seg->rs, rs_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, sa));
+            HIPCHK(hipMemcpyAsync(seg->b, b_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, sa));
         }
         HIPCHK(hipEventRecord(c->ev_phase[1], s));
         // ---- streamed pass over the data points                                                   :64-71

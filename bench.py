@@ -148,11 +148,11 @@ def cpu_baseline(n_full: int, d: int, full: bool = True):
 
 def pmc_traffic(n: int) -> dict:
     """HBM/fabric bytes per launch of the dominant kernel, and its MFMA-pipe occupancy, from the committed rocprofv3 --pmc passes over THIS command
-    (round 5: tools/gpu_r5_final.sh -> profiles/r5/pmc_bench_summary.json, written by tools/pmc_bench_summary.py; FETCH_SIZE and WRITE_SIZE are reported
+    (tools/gpu_final.sh -> profiles/r<round>/pmc_bench_summary.json, written by tools/pmc_bench_summary.py; the newest round's file is taken; FETCH_SIZE and WRITE_SIZE are reported
     in KiB and FETCH_SIZE is doubled, the gfx950 correction for 16-B/lane streaming reads of MI355X_MICROARCH.md §HBM).  PMC cannot be sampled from inside
     the timed run, so these are REPLAYED from the file (`source` says which) and null when it is absent or for another N; tests/test_bench_line.py ties the
     file's launch count to `launches_per_step`."""
-    path = next((q for q in (ROOT / "profiles" / r / "pmc_bench_summary.json" for r in ("r5", "r4", "r3", "r2", "r1")) if q.exists()), ROOT / "nonexistent")
+    path = next((q for q in (ROOT / "profiles" / r / "pmc_bench_summary.json" for r in ("r6", "r5", "r4", "r3", "r2", "r1")) if q.exists()), ROOT / "nonexistent")
     if n != 65536 or not path.exists():
         return {"traffic": None}
     s = json.loads(path.read_text())

@@ -8,7 +8,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-ROUNDS = ("r5", "r4", "r3", "r2", "r1")
+ROUNDS = ("r6", "r5", "r4", "r3", "r2", "r1")
 
 
 def _latest():
