@@ -79,6 +79,9 @@ struct gp_ctx {
     int time_kernels = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)
+    int trsv_persist = 1;  // single right-hand side: the whole sweep as ONE persistent launch (kernels.hpp trsv_sweep_kernel); 0: two launches per 256-column block
+    long trsv_slices = 4;  // ... target slices per 256-block (1 / 2 / 4 workgroups share the strip of L that a published block is applied to)
+    int* sweep_flags = nullptr;  // progress counters of that launch
     long leaf_group = 128; // columns factored left-looking by consecutive leaves (64 = every leaf followed by its own GEMM)
     int deterministic = 0; // 1: no floating-point atomics in the exact path (no stream-K tails, one thread per column in the backward sweep): bitwise repeatable
     int leaf_v2 = 1;       // fp64 leaves by panel64v2_kernel (register-resident leaf, round 4); 0: panel64_kernel
@@ -109,8 +112,9 @@ struct gp_ctx {
     long vfe_ks = 2048;    // VFE fp32: data points per fp32 partial product of the chunk SYRK (fp64 sums across partials)
     int vfe_overlap = 1;   // VFE: kmat / ystats / partial-sum adds on the second stream beside the chunk GEMMs (double buffers)
     int vfe_sk = 0;        // VFE: stream-K GEMM tails for the M×M side (K_zz / Λ_ε factorisations, inv(L_z))
-    int vfe_dual = 1;      // VFE: the triangular products Y(c) on a high-priority third stream beside the chunk SYRKs on the main stream: Y(c+1) takes the workgroup
-                           // slots first, SYRK(c) fills what it leaves (4 224 workgroups per SYRK launch = 8.25 rounds of 512 slots); 0: back to back on one stream
+    int vfe_dual = 0;      // VFE experiment switch (round 6, measured and left OFF): the triangular products Y(c) on a high-priority third stream beside the chunk SYRKs
+                           // on the main stream, so that each launch's last partial round of workgroups is filled by the other — C5 +0.4…0.7 ms with the priority,
+                           // −0.45 ms with both at equal priority (profiles/r6/c5_ab*.jsonl): the single-stream pass has no idle tail to fill
     long vfe_inv_nb = 512; // VFE prelude: inv(L_z) with the inverse diagonal blocks of this width built in one batched launch sequence (0: 64-wide leaves)
     int xcd_swizzle = 0;   // XCD-aware super-tile order of the MFMA gemm workgroups
     long xcd_min_tiles = 256;

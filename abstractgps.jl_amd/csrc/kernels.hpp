@@ -1577,11 +1577,11 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const T* __restrict__ L
 // C4's backward sweep 10.2 -> 6.7 ms, C2's 2.05 -> 1.24 ms, profiles/r3/sweep_trsv.jsonl).  A two-stream variant (this chain on
 // one stream, the bulk of every update beside it on another) was built and measured SLOWER — 3.1 / 14.0 ms: two event records and
 // two stream waits per 256-column block cost more host time than the overlap saves — and removed.
+// One nbv-wide (<= 256) diagonal block of a vector solve by the 1 024 threads of a workgroup: r (global, nbv entries at the block's offset) <- L_bb⁻¹ r (FWD)
+// or L_bb⁻ᵀ r; smem: the dynamic LDS of trsv_diag2_kernel.  Every thread of the workgroup must call it (workgroup barriers inside).
 template <typename T, bool FWD>
-__global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
-                                                           T* __restrict__ R, long ldr, int nrhs,
-                                                           const T* __restrict__ W) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void trsv_diag2_block(const T* __restrict__ L, long ldl, long b0, int nbv, T* __restrict__ r, const T* __restrict__ W,
+                                                 unsigned char* smem_raw) {
     T* rv = reinterpret_cast<T*>(smem_raw);  // [256] current rhs / solution
     T* Ws = rv + 256;                        // [64][65] W tile of the current step
     T* red = Ws + 64 * 65;                   // [16][64] GEMV partial sums
@@ -1605,66 +1605,199 @@ __global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ 
             for (int c = 0; c < 16; ++c) lr[c] = src[(long)c * ldl];
         }
     };
-    for (int s = 0; s < nrhs; ++s) {
-        T* r = R + (long)s * ldr + b0;
-        T wreg[4], lreg[16];
-        {
-            const T* W0 = W + ((b0 >> 6) + (FWD ? 0 : ns - 1)) * 4096;
+    T wreg[4], lreg[16];
+    {
+        const T* W0 = W + ((b0 >> 6) + (FWD ? 0 : ns - 1)) * 4096;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wreg[i] = W0[tid + 1024 * i];
+        for (int i = 0; i < 4; ++i) wreg[i] = W0[tid + 1024 * i];
+    }
+    if (tid < nbv) rv[tid] = r[tid];
+    load_l(FWD ? 0 : ns - 1, lreg);  // in flight during the first step's GEMV
+    __syncthreads();
+    for (int ss = 0; ss < ns; ++ss) {
+        const int sb = FWD ? ss : (ns - 1 - ss);
+        const int s0 = sb * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 1024 * i;
+            Ws[(e >> 6) * 65 + (e & 63)] = wreg[i];
         }
-        if (tid < nbv) rv[tid] = r[tid];
-        load_l(FWD ? 0 : ns - 1, lreg);  // in flight during the first step's GEMV
+        if (ss + 1 < ns) {  // next step's W tile: in flight during this step
+            const T* Wn = W + ((b0 >> 6) + (FWD ? sb + 1 : sb - 1)) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wreg[i] = Wn[tid + 1024 * i];
+        }
         __syncthreads();
-        for (int ss = 0; ss < ns; ++ss) {
-            const int sb = FWD ? ss : (ns - 1 - ss);
-            const int s0 = sb * 64;
+        {
+            T acc = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int e = tid + 1024 * i;
-                Ws[(e >> 6) * 65 + (e & 63)] = wreg[i];
+                const int c = 4 * part + i;
+                acc = fma(FWD ? Ws[t * 65 + c] : Ws[c * 65 + t], rv[s0 + c], acc);
             }
-            if (ss + 1 < ns) {  // next step's W tile: in flight during this step
-                const T* Wn = W + ((b0 >> 6) + (FWD ? sb + 1 : sb - 1)) * 4096;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wreg[i] = Wn[tid + 1024 * i];
-            }
-            __syncthreads();
-            {
-                T acc = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 4 * part + i;
-                    acc = fma(FWD ? Ws[t * 65 + c] : Ws[c * 65 + t], rv[s0 + c], acc);
-                }
-                red[part * 64 + t] = acc;
-            }
-            __syncthreads();
-            if (tid < 64) {
-                T acc = 0;
-#pragma unroll
-                for (int qq = 0; qq < 16; ++qq) acc += red[qq * 64 + tid];
-                rv[s0 + tid] -= acc;
-            }
-            __syncthreads();
-            // update the not-yet-solved part of this diagonal block from the registers loaded one step ago
-            const int tgt = FWD ? s0 + 64 + j : j;
-            const bool active = FWD ? (tgt < nbv) : (j < s0);
-            {
-                T acc = 0;
-                if (active) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) acc = fma(lreg[c], rv[s0 + 16 * q + c], acc);
-                }
-                prt[q * 256 + j] = acc;
-            }
-            if (ss + 1 < ns) load_l(FWD ? sb + 1 : sb - 1, lreg);  // the next update's elements: in flight during the next step's GEMV
-            __syncthreads();
-            if (q == 0 && active) rv[tgt] -= prt[j] + prt[256 + j] + prt[512 + j] + prt[768 + j];
-            __syncthreads();
+            red[part * 64 + t] = acc;
         }
-        if (tid < nbv) r[tid] = rv[tid];
         __syncthreads();
+        if (tid < 64) {
+            T acc = 0;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) acc += red[qq * 64 + tid];
+            rv[s0 + tid] -= acc;
+        }
+        __syncthreads();
+        // update the not-yet-solved part of this diagonal block from the registers loaded one step ago
+        const int tgt = FWD ? s0 + 64 + j : j;
+        const bool active = FWD ? (tgt < nbv) : (j < s0);
+        {
+            T acc = 0;
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc = fma(lreg[c], rv[s0 + 16 * q + c], acc);
+            }
+            prt[q * 256 + j] = acc;
+        }
+        if (ss + 1 < ns) load_l(FWD ? sb + 1 : sb - 1, lreg);  // the next update's elements: in flight during the next step's GEMV
+        __syncthreads();
+        if (q == 0 && active) rv[tgt] -= prt[j] + prt[256 + j] + prt[512 + j] + prt[768 + j];
+        __syncthreads();
+    }
+    if (tid < nbv) r[tid] = rv[tid];
+    __syncthreads();
+}
+
+template <typename T, bool FWD>
+__global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,
+                                                           T* __restrict__ R, long ldr, int nrhs,
+                                                           const T* __restrict__ W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    for (int s = 0; s < nrhs; ++s) trsv_diag2_block<T, FWD>(L, ldl, b0, nbv, R + (long)s * ldr + b0, W, smem_raw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// trsv_sweep (round 6): a whole vector solve r <- L⁻¹ r (FWD) or L⁻ᵀ r in ONE persistent launch instead of two dependent launches per 256-column
+// block (C2: 128 launches of 8–10 µs each = 1.13 ms for a 0.27 ms read; the "127-launch backward sweep as one launch" listed since round 3).
+//   Blocks of 256 (the last one may be 128 wide) are solved in step order t = 0 .. nblk−1 (block b(t) = t forward, nblk−1−t backward).
+//   Workgroup 0 is the SOLVER: at step t it waits until every contribution of the earlier blocks has been applied to block b(t), solves the diagonal block
+//   (trsv_diag2_block) and publishes x_b.  Workgroup 1 + k owns ONE unit — slice k % S (256/S target entries) of the block of step 1 + k / S: it applies the
+//   contribution of every earlier block as soon as that block is published (one 256 × 256/S strip of L per step, read once), counts itself in after each, and
+//   exits after the last.  Units are numbered in the order the solver needs them and workgroups are dispatched in index order, so a workgroup that is not
+//   resident yet is never one the resident ones wait for before an earlier one has retired: the launch makes progress at any residency (a CU-masked stream,
+//   a busy device), and late units catch up on the published blocks when they start.  Every target entry is owned by one workgroup and updated in step order:
+//   no atomics on the data, bitwise repeatable.
+//   flags (zeroed before the launch): [0] blocks solved so far, [1] watchdog — a wait that gives up after ≈ 2²⁴ polls sets it, every waiter leaves, the result is
+//   poisoned with NaN (a hang would cost the device; it cannot happen while workgroups are dispatched in order), [8 + g] contributions applied to block g.
+//   Cross-workgroup visibility: data stores, release fence (agent scope) by every thread, workgroup barrier, then ONE relaxed atomic add; the waiter polls with
+//   relaxed atomic loads and every thread issues an acquire fence behind the barrier that follows.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool FWD>
+__global__ __launch_bounds__(1024) void trsv_sweep_kernel(const T* __restrict__ L, long ldl, long np, T* __restrict__ R, const T* __restrict__ W,
+                                                          int* __restrict__ flags, int S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    const int nblk = (int)((np + 255) / 256);
+    auto wait_ge = [&](int* f, int want) -> bool {  // every thread of the workgroup calls it
+        if (tid == 0) {
+            int ok = 1;
+            long spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255) == 0 && (spins > (1L << 24) || __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = 0;
+                    break;
+                }
+            }
+            if (!ok) __hip_atomic_store(flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ok = ok;
+        }
+        __syncthreads();
+        const bool ok = s_ok != 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        return ok;
+    };
+    auto signal = [&](int* f) {  // every thread calls it after its stores
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto block_of = [&](int t) { return FWD ? t : nblk - 1 - t; };
+    if (blockIdx.x == 0) {  // ---- the solver
+        for (int t = 0; t < nblk; ++t) {
+            const int b = block_of(t);
+            const long b0 = (long)b * 256;
+            const int nbv = (int)((np - b0) < 256 ? (np - b0) : 256);
+            if (!wait_ge(flags + 8 + b, S * t)) {
+                for (long i = tid; i < np; i += 1024) R[i] = T(NAN);
+                return;
+            }
+            trsv_diag2_block<T, FWD>(L, ldl, b0, nbv, R + b0, W, smem_raw);
+            signal(flags + 0);
+        }
+        return;
+    }
+    // ---- one unit: slice sl of the block of step tau
+    const int k = (int)blockIdx.x - 1, tau = 1 + k / S, sl = k % S;
+    if (tau >= nblk) return;
+    const int g = block_of(tau);
+    const int CW = 256 / S;                       // target entries of this unit
+    const long g0 = (long)g * 256 + (long)sl * CW;
+    T* xs = reinterpret_cast<T*>(smem_raw);       // [256] the published block
+    T* part = xs + 256;                           // [1024] partial sums (backward form)
+    for (int t = 0; t < tau; ++t) {
+        const int b = block_of(t);
+        const long b0 = (long)b * 256;
+        const int wb = (int)((np - b0) < 256 ? (np - b0) : 256);   // entries of the source block (the last block may be 128 wide)
+        if (!wait_ge(flags + 0, t + 1)) return;
+        if (tid < 256) xs[tid] = tid < wb ? R[b0 + tid] : T(0);
+        __syncthreads();
+        if (FWD) {
+            // target rows g0 .. g0 + CW: r_i −= Σ_j L[i][b0 + j] x_j — a row is 256 contiguous elements: one wave per row, 4 elements per lane
+            const int lane = tid & 63, wv = tid >> 6;
+            T x4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x4[e] = xs[4 * lane + e];
+            const int rpw = CW / 16;  // rows per wave: 16 / 8 / 4
+            T acc[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                acc[rr] = 0;
+                if (rr < rpw) {
+                    const long row = g0 + wv + 16 * rr;
+                    if (row < np) {
+                        const T* src = L + row * ldl + b0 + 4 * lane;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[rr] = fma(src[e], x4[e], acc[rr]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                if (rr < rpw) {
+                    T v = acc[rr];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    const long row = g0 + wv + 16 * rr;
+                    if (lane == 0 && row < np) R[row] -= v;
+                }
+            }
+        } else {
+            // target columns g0 .. g0 + CW: r_j −= Σ_i L[b0 + i][j] x_i — consecutive threads read consecutive columns of one source row
+            const int col = tid % CW, rg = tid / CW, RG = 1024 / CW, rpg = 256 / RG;  // rpg source rows per thread: 64 / 32 / 16
+            T acc = 0;
+            const T* src = L + (b0 + (long)rg * rpg) * ldl + g0 + col;
+#pragma unroll 8
+            for (int i = 0; i < rpg; ++i)
+                if (rg * rpg + i < wb) acc = fma(src[(long)i * ldl], xs[rg * rpg + i], acc);
+            part[rg * CW + col] = acc;
+            __syncthreads();
+            if (rg == 0) {
+                T tot = 0;
+                for (int q = 0; q < RG; ++q) tot += part[q * CW + col];
+                R[g0 + col] -= tot;
+            }
+        }
+        signal(flags + 8 + g);   // (its barrier also separates this step's use of xs / part from the next step's)
     }
 }
 

@@ -207,12 +207,11 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     // buffers: kmat of chunk c+1 and the partial-sum adds of chunk c overlap the GEMMs of their neighbours ("vfe_overlap").
     hipStream_t sa = c->vfe_overlap ? c->sp : s;
     const bool ovl = sa != s;
-    // "vfe_dual": the triangular products Y(c) = −inv(L_z) X(c)ᵀ on a third, HIGH-priority stream sy, the chunk SYRKs stay on the main stream.  Y(c+1) is
-    // independent of SYRK(c); with the priority the workgroup slots go to Y(c+1) first and the SYRK in flight fills whatever Y leaves free — in particular
-    // each launch's last partial round of workgroups (SYRK: 528 lower tiles × 8 partials = 4 224 workgroups = 8.25 rounds of the 512 slots, ≈ 0.18 ms idle
-    // per launch when it runs alone; Y: 4 096 tiles of unequal length).  Same buffers, same arithmetic, same order of the sums into D_acc.  (First form of the
-    // round, both launches at EQUAL priority — Y on s, SYRK on the third stream: the two run side by side from the start, end together and leave their
-    // tails open: 79.5 -> 79.05 ms only, profiles/r6/c5_ab.jsonl.)
+    // "vfe_dual" (experiment switch, default 0): the triangular products Y(c) = −inv(L_z) X(c)ᵀ on a third, HIGH-priority stream sy, the chunk SYRKs on the main
+    // stream — Y(c+1) is independent of SYRK(c), and the idea was that each launch's last partial round of workgroups (SYRK: 528 lower tiles × 8 partials = 4 224
+    // workgroups = 8.25 rounds of the 512 slots) is filled by the other launch.  Measured at C5 in one process (tools/c5_ab.py, profiles/r6/c5_ab*.jsonl): with
+    // the priority +0.4…0.7 ms, with both launches at equal priority −0.45 ms of 79.5 — the single-stream pass has no idle tail worth filling (the helper
+    // kernels of the second stream already run in it).  Same buffers, same arithmetic, same order of the sums into D_acc either way.
     hipStream_t sy = s;
     if (ovl && c->vfe_dual) RC(ctx_third_stream(c, &sy));
     const bool dual = sy != s;

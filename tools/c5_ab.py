@@ -49,5 +49,5 @@ for rnd in range(rounds):
         print(json.dumps({"round": rnd, "vfe_dual": dual, "vfe_inv_nb": inv, "ms_median": round(med, 3), "ms_min": round(min(ts), 3),
                           "frac_fp32": flops / (med * 1e-3) / 157.3e12, "prelude_ms": round(tm["assemble_ms"], 3), "stream_ms": round(tm["potrf_ms"], 3),
                           "mxm_side_ms": round(tm["solve_ms"], 3), "elbo": elbo}), flush=True)
-ctx.set_param("vfe_dual", 1)
+ctx.set_param("vfe_dual", 0)
 ctx.set_param("vfe_inv_nb", 512)
