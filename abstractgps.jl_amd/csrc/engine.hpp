@@ -79,9 +79,6 @@ struct gp_ctx {
     int time_kernels = 0;
     int sched = 0;         // 0: whole panel on the panel stream (look-ahead); 1: diag-first, all-MFMA rows_below
     long trsv_nb = 256;    // diagonal block of the vector solves handled by one workgroup (the rest goes to the multi-CU update kernels)
-    int trsv_persist = 1;  // single right-hand side: the whole sweep as ONE persistent launch (kernels.hpp trsv_sweep_kernel); 0: two launches per 256-column block
-    long trsv_slices = 4;  // ... target slices per 256-block (1 / 2 / 4 workgroups share the strip of L that a published block is applied to)
-    int* sweep_flags = nullptr;  // progress counters of that launch
     long leaf_group = 128; // columns factored left-looking by consecutive leaves (64 = every leaf followed by its own GEMM)
     int deterministic = 0; // 1: no floating-point atomics in the exact path (no stream-K tails, one thread per column in the backward sweep): bitwise repeatable
     int leaf_v2 = 1;       // fp64 leaves by panel64v2_kernel (register-resident leaf, round 4); 0: panel64_kernel

@@ -114,7 +114,6 @@ void ctx_unref(gp_ctx* c) {
     if (c->info_dev) (void)hipFree(c->info_dev);
     if (c->ticket_dev) (void)hipFree(c->ticket_dev);
     if (c->w_ws) (void)hipFree(c->w_ws);
-    if (c->sweep_flags) (void)hipFree(c->sweep_flags);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->sq) (void)hipStreamDestroy(c->sq);
@@ -689,20 +688,6 @@ static int32_t trsv(gp_ctx* c, hipStream_t s, const T* L, long ldl, long np, T* 
     const long nblk = (np + NBV - 1) / NBV;
     T* W = nullptr;
     RC(trtri_tiles<T>(c, s, L, ldl, np, &W));  // I − inv(L_jj) for every 64×64 diagonal tile, one batched launch
-    if (c->trsv_persist && nrhs == 1 && np > 256 && np <= 4096L * 256) {
-        // ONE persistent launch for the whole sweep (kernels.hpp trsv_sweep_kernel): workgroup 0 solves the diagonal blocks in order, workgroup 1 + k applies the
-        // published blocks to slice k % S of the block of step 1 + k / S
-        const int S = (int)std::min<long>(4, std::max<long>(1, c->trsv_slices));
-        const long nb256 = (np + 255) / 256;
-        if (!c->sweep_flags) HIPCHK(hipMalloc((void**)&c->sweep_flags, sizeof(int) * (8 + 4096)));
-        HIPCHK(hipMemsetAsync(c->sweep_flags, 0, sizeof(int) * (size_t)(8 + nb256), s));
-        const size_t sm2 = sizeof(T) * (256 + 64 * 65 + 16 * 64 + 4 * 256);
-        const dim3 grid((unsigned)(1 + (nb256 - 1) * S));
-        if (fwd) hipLaunchKernelGGL((trsv_sweep_kernel<T, true>), grid, dim3(1024), sm2, s, L, ldl, np, R, (const T*)W, c->sweep_flags, S);
-        else hipLaunchKernelGGL((trsv_sweep_kernel<T, false>), grid, dim3(1024), sm2, s, L, ldl, np, R, (const T*)W, c->sweep_flags, S);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
     for (long bb = 0; bb < nblk; ++bb) {
         const long b = fwd ? bb : (nblk - 1 - bb);
         const long b0 = b * NBV;
@@ -1700,8 +1685,6 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
         c->gemm_pad_lds = std::min<int64_t>(std::max<int64_t>(0, v), 32768);
         c->gemm_pad_user = true;
     }
-    else if (!strcmp(name, "trsv_persist")) c->trsv_persist = v != 0;
-    else if (!strcmp(name, "trsv_slices")) c->trsv_slices = v >= 4 ? 4 : (v >= 2 ? 2 : 1);
     else if (!strcmp(name, "trsv_nb")) c->trsv_nb = v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 128));
     else if (!strcmp(name, "deterministic")) c->deterministic = v != 0;
     else if (!strcmp(name, "leaf_v2")) c->leaf_v2 = v != 0;
@@ -1738,7 +1721,7 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"nb", c->nb}, {"nb_small", c->nb_small}, {"nb_large", c->nb_large}, {"lookahead", c->lookahead}, {"lookahead_min_n", c->lookahead_min_n}, {"time_kernels", c->time_kernels},
         {"xcd_swizzle", c->xcd_swizzle}, {"xcd_min_tiles", c->xcd_min_tiles}, {"gemm_streamk", c->gemm_streamk},
         {"sk_max_tiles", c->sk_max_tiles}, {"sk_min_k", c->sk_min_k}, {"gemm_pipe", c->gemm_pipe}, {"gemm_pad_f32", c->gemm_pad_f32},
-        {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb}, {"trsv_persist", c->trsv_persist}, {"trsv_slices", c->trsv_slices}, {"deterministic", c->deterministic},
+        {"gemm_pad_lds", c->gemm_pad_user ? c->gemm_pad_lds : 0}, {"trsv_nb", c->trsv_nb},  {"deterministic", c->deterministic},
         {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_dual", c->vfe_dual}, {"vfe_inv_nb", c->vfe_inv_nb}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},

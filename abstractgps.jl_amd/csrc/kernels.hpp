@@ -1673,134 +1673,11 @@ __global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ 
     for (int s = 0; s < nrhs; ++s) trsv_diag2_block<T, FWD>(L, ldl, b0, nbv, R + (long)s * ldr + b0, W, smem_raw);
 }
 
-// ------------------------------------------------------------------------------------------------
-// trsv_sweep (round 6): a whole vector solve r <- L⁻¹ r (FWD) or L⁻ᵀ r in ONE persistent launch instead of two dependent launches per 256-column
-// block (C2: 128 launches of 8–10 µs each = 1.13 ms for a 0.27 ms read; the "127-launch backward sweep as one launch" listed since round 3).
-//   Blocks of 256 (the last one may be 128 wide) are solved in step order t = 0 .. nblk−1 (block b(t) = t forward, nblk−1−t backward).
-//   Workgroup 0 is the SOLVER: at step t it waits until every contribution of the earlier blocks has been applied to block b(t), solves the diagonal block
-//   (trsv_diag2_block) and publishes x_b.  Workgroup 1 + k owns ONE unit — slice k % S (256/S target entries) of the block of step 1 + k / S: it applies the
-//   contribution of every earlier block as soon as that block is published (one 256 × 256/S strip of L per step, read once), counts itself in after each, and
-//   exits after the last.  Units are numbered in the order the solver needs them and workgroups are dispatched in index order, so a workgroup that is not
-//   resident yet is never one the resident ones wait for before an earlier one has retired: the launch makes progress at any residency (a CU-masked stream,
-//   a busy device), and late units catch up on the published blocks when they start.  Every target entry is owned by one workgroup and updated in step order:
-//   no atomics on the data, bitwise repeatable.
-//   flags (zeroed before the launch): [0] blocks solved so far, [1] watchdog — a wait that gives up after ≈ 2²⁴ polls sets it, every waiter leaves, the result is
-//   poisoned with NaN (a hang would cost the device; it cannot happen while workgroups are dispatched in order), [8 + g] contributions applied to block g.
-//   Cross-workgroup visibility: data stores, release fence (agent scope) by every thread, workgroup barrier, then ONE relaxed atomic add; the waiter polls with
-//   relaxed atomic loads and every thread issues an acquire fence behind the barrier that follows.
-// ------------------------------------------------------------------------------------------------
-template <typename T, bool FWD>
-__global__ __launch_bounds__(1024) void trsv_sweep_kernel(const T* __restrict__ L, long ldl, long np, T* __restrict__ R, const T* __restrict__ W,
-                                                          int* __restrict__ flags, int S) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ int s_ok;
-    const int tid = threadIdx.x;
-    const int nblk = (int)((np + 255) / 256);
-    auto wait_ge = [&](int* f, int want) -> bool {  // every thread of the workgroup calls it
-        if (tid == 0) {
-            int ok = 1;
-            long spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 255) == 0 && (spins > (1L << 24) || __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    ok = 0;
-                    break;
-                }
-            }
-            if (!ok) __hip_atomic_store(flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_ok = ok;
-        }
-        __syncthreads();
-        const bool ok = s_ok != 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
-        return ok;
-    };
-    auto signal = [&](int* f) {  // every thread calls it after its stores
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto block_of = [&](int t) { return FWD ? t : nblk - 1 - t; };
-    if (blockIdx.x == 0) {  // ---- the solver
-        for (int t = 0; t < nblk; ++t) {
-            const int b = block_of(t);
-            const long b0 = (long)b * 256;
-            const int nbv = (int)((np - b0) < 256 ? (np - b0) : 256);
-            if (!wait_ge(flags + 8 + b, S * t)) {
-                for (long i = tid; i < np; i += 1024) R[i] = T(NAN);
-                return;
-            }
-            trsv_diag2_block<T, FWD>(L, ldl, b0, nbv, R + b0, W, smem_raw);
-            signal(flags + 0);
-        }
-        return;
-    }
-    // ---- one unit: slice sl of the block of step tau
-    const int k = (int)blockIdx.x - 1, tau = 1 + k / S, sl = k % S;
-    if (tau >= nblk) return;
-    const int g = block_of(tau);
-    const int CW = 256 / S;                       // target entries of this unit
-    const long g0 = (long)g * 256 + (long)sl * CW;
-    T* xs = reinterpret_cast<T*>(smem_raw);       // [256] the published block
-    T* part = xs + 256;                           // [1024] partial sums (backward form)
-    for (int t = 0; t < tau; ++t) {
-        const int b = block_of(t);
-        const long b0 = (long)b * 256;
-        const int wb = (int)((np - b0) < 256 ? (np - b0) : 256);   // entries of the source block (the last block may be 128 wide)
-        if (!wait_ge(flags + 0, t + 1)) return;
-        if (tid < 256) xs[tid] = tid < wb ? R[b0 + tid] : T(0);
-        __syncthreads();
-        if (FWD) {
-            // target rows g0 .. g0 + CW: r_i −= Σ_j L[i][b0 + j] x_j — a row is 256 contiguous elements: one wave per row, 4 elements per lane
-            const int lane = tid & 63, wv = tid >> 6;
-            T x4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x4[e] = xs[4 * lane + e];
-            const int rpw = CW / 16;  // rows per wave: 16 / 8 / 4
-            T acc[16];
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                acc[rr] = 0;
-                if (rr < rpw) {
-                    const long row = g0 + wv + 16 * rr;
-                    if (row < np) {
-                        const T* src = L + row * ldl + b0 + 4 * lane;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[rr] = fma(src[e], x4[e], acc[rr]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                if (rr < rpw) {
-                    T v = acc[rr];
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    const long row = g0 + wv + 16 * rr;
-                    if (lane == 0 && row < np) R[row] -= v;
-                }
-            }
-        } else {
-            // target columns g0 .. g0 + CW: r_j −= Σ_i L[b0 + i][j] x_i — consecutive threads read consecutive columns of one source row
-            const int col = tid % CW, rg = tid / CW, RG = 1024 / CW, rpg = 256 / RG;  // rpg source rows per thread: 64 / 32 / 16
-            T acc = 0;
-            const T* src = L + (b0 + (long)rg * rpg) * ldl + g0 + col;
-#pragma unroll 8
-            for (int i = 0; i < rpg; ++i)
-                if (rg * rpg + i < wb) acc = fma(src[(long)i * ldl], xs[rg * rpg + i], acc);
-            part[rg * CW + col] = acc;
-            __syncthreads();
-            if (rg == 0) {
-                T tot = 0;
-                for (int q = 0; q < RG; ++q) tot += part[q * CW + col];
-                R[g0 + col] -= tot;
-            }
-        }
-        signal(flags + 8 + g);   // (its barrier also separates this step's use of xs / part from the next step's)
-    }
-}
-
+// (Round 6 built the whole sweep as ONE persistent launch — a solver workgroup taking the diagonal blocks in order, one workgroup per slice of every later block
+//  applying the published blocks, in-kernel progress counters with agent-scope release / acquire — verified it against this path and measured it SLOWER at
+//  every size: N = 4 096 pair 2.20 -> 2.41 ms, C2 28.8 -> 31.5, N = 32 768 185.3 -> 196.4, C4 1 383 -> 1 445, C5 76.8 -> 77.5 (profiles/r6/trsv_persist_ab.jsonl):
+//  a device-scope release is a write-back of the XCD's whole L2 (buffer_wbl2 sc1), an acquire its invalidation (buffer_inv sc1), and the two hand-overs per
+//  block cost ≈ 59 µs where two dependent launches cost ≈ 18.  Removed; in the history at f29d505: "Vector solves as one persistent launch".)
 // rows [row_lo, row_hi): r[s][i] -= Σ_{j<nbv} L[i][b0+j] z[s][b0+j]; one wave per row, 4 rows per block.
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_upd_fwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,

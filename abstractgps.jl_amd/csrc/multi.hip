@@ -1679,9 +1679,6 @@ extern "C" int32_t gp_ctx_create_multi(gp_ctx** out, const int32_t* devices, int
         // profiles/r4/traces/c3_la1_summary.txt: the first leaf of a panel "runs" for the whole 25 ms of the update beside it) — more launch
         // boundaries than the look-ahead depth covers.  The 64-column leaf (46 KB, 226 VGPRs) fits beside one GEMM workgroup and starts at once.
         (void)gp_ctx_set_param(rk.c, "leaf_cols", 64);
-        // the rank contexts keep the launch-per-block vector solves: a persistent sweep per rank thread would hold workgroup slots of a device that several
-        // virtual ranks share, and the distributed backward sweep works on single nb-blocks anyway
-        (void)gp_ctx_set_param(rk.c, "trsv_persist", 0);
         int plo = 0, phi = 0;
         const char* pe = getenv("GPMI_COMM_PRIO");
         if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess ||

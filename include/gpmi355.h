@@ -166,10 +166,6 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *   "sk_min_k"       smallest inner dimension that may use the stream-K GEMM                default 0
  *   "leaf_group"     columns factored left-looking by consecutive fused leaves (64/128/256/512)   default 128
  *   "trsv_nb"        diagonal block of the vector solves handled by one workgroup (128..1024)    default 256
- *   "trsv_persist"   vector solves with one right-hand side (α = L⁻ᵀ z of every fit, the M×M solves of the sparse path) as ONE persistent launch: a solver
- *                    workgroup takes the 256-wide diagonal blocks in order, every other workgroup owns one slice of one block and applies the published blocks
- *                    to it — no atomics, bitwise repeatable; 0 = two dependent launches per block (what the rank contexts of a multi-device ctx keep)   default 1
- *   "trsv_slices"    ... workgroups sharing the strip of L a published block is applied to (1, 2, 4)   default 4
  *   "gemm_pad_lds"   extra dynamic LDS bytes per GEMM workgroup; 20480 = one workgroup per CU (fp64: same speed on one
  *                    large launch, 4-7 % slower over a whole factorisation)                 default 0
  *   "gemm_pad_f32"   the same for the fp32 GEMMs unless "gemm_pad_lds" was set (0: two workgroups per CU — 1 % faster at C5 with the
@@ -216,7 +212,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  * behind for the tests that follow it (tests/conftest.py). */
 #define GPMI355_PARAM_DEFAULTS                                                                                                   \
     "nb=-1,nb_small=4096,nb_large=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
-    "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=0,gemm_pad_lds=0,trsv_nb=256,trsv_persist=1,trsv_slices=4,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
+    "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=0,gemm_pad_lds=0,trsv_nb=256,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
     "updk_max_k=512,updk_rt=0,updk_tall_k=256,updk_tall_m=8192,upd128=1,leaf_group=128,ldpad=32,vfe_ks=2048,vfe_sk=0,"          \
     "vfe_overlap=1,vfe_dual=0,vfe_inv_nb=512,vfe_chunk=16384,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);

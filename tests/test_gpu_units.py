@@ -229,46 +229,6 @@ def test_trsv_block_sizes(lib, h, nbv):
         check(lib.gp_ctx_set_param(h, b"trsv_nb", 256))
 
 
-@pytest.mark.parametrize("slices", [1, 2, 4])
-def test_trsv_persistent_sweep(lib, h, slices):
-    """"trsv_persist" (default 1): a one-right-hand-side vector solve as ONE persistent launch (kernels.hpp trsv_sweep_kernel: a solver workgroup and one
-    workgroup per slice of every later 256-block, in-kernel progress counters) against torch and against the launch-per-block path it replaces, forward
-    and backward, with 1 / 2 / 4 slices per block, at sizes with one block and a half (384), a ragged last block (2 432), more units than the device holds
-    at once (16 512 = 64.5 blocks × 4 slices > 256 CUs) — and twice over: no atomics on the data, so the repeat is bitwise."""
-    from abstractgps_jl_amd._lib import check
-
-    check(lib.gp_ctx_set_param(h, b"trsv_slices", slices))
-    try:
-        for np_ in (384, 2432, 4096, 16512):
-            g = torch.Generator(device="cuda").manual_seed(np_ + slices)
-            G = torch.randn(np_, 64, dtype=torch.float64, device="cuda", generator=g)
-            A = G @ G.T / 64 + 2.0 * torch.eye(np_, dtype=torch.float64, device="cuda")
-            L = torch.linalg.cholesky(A)
-            del A, G
-            ld = np_ + 32
-            Lp = torch.full((np_, ld), float("nan"), dtype=torch.float64, device="cuda")
-            Lp[:, :np_] = torch.tril(L) + torch.triu(torch.full_like(L, float("nan")), 1)  # the upper part must never be read
-            r = torch.randn(1, np_, dtype=torch.float64, device="cuda", generator=g)
-            for fwd in (1, 0):
-                ref = torch.linalg.solve_triangular(L if fwd else L.T, r.T, upper=not fwd).T
-                outs = []
-                for persist in (1, 1, 0):
-                    check(lib.gp_ctx_set_param(h, b"trsv_persist", persist))
-                    W = r.clone()
-                    torch.cuda.synchronize()
-                    check(lib.gpd_trsv(h, P(Lp), ld, np_, P(W), np_, 1, fwd))
-                    _sync(lib, h)
-                    outs.append(W)
-                    assert torch.isfinite(W).all().item(), (np_, fwd, persist)
-                    assert (W - ref).abs().max().item() < 1e-9 * max(1.0, ref.abs().max().item()), (np_, fwd, persist)
-                assert torch.equal(outs[0], outs[1]), (np_, fwd)
-                assert (outs[0] - outs[2]).abs().max().item() < 1e-10 * max(1.0, ref.abs().max().item())
-            del L, Lp
-    finally:
-        check(lib.gp_ctx_set_param(h, b"trsv_persist", 1))
-        check(lib.gp_ctx_set_param(h, b"trsv_slices", 4))
-
-
 @pytest.mark.parametrize("sk", [0, 1])
 def test_fit_with_and_without_streamk(agp, sk):
     """the few-tile GEMMs cut along k over all CUs (stream-K, hardware atomics) or not: same logpdf / α as the oracle"""
