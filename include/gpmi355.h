@@ -74,7 +74,9 @@ typedef struct {
 
 /* Per-phase wall times (ms, HIP events on the ctx streams) of the last fit/logpdf call, and the
  * accumulated duration / algorithmic FLOPs of the dominant kernel (gemm_nt trailing update) when
- * parameter "time_kernels" is 1. */
+ * parameter "time_kernels" is 1.  Exact fits: assemble = Gram phase, potrf = factorisation, solve = vector solves.
+ * Sparse fits (gp_vfe_fit / _update / _append): assemble = the M×M prelude (K_zz, its Cholesky, inv(L_z)), potrf = the streamed pass
+ * over the data points, solve = the M×M side after it (Λ_ε = chol(I + B Bᵀ), the vector solves). */
 typedef struct {
     double assemble_ms;
     double potrf_ms;

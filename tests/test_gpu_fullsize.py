@@ -216,6 +216,64 @@ def test_c4_gradient_vs_finite_differences_of_logpdf(agp):
     ctx.trim()
 
 
+def test_beyond_2_pow_32_matrix_elements(agp):
+    """Maximum sizes: N = 90 112 (a 65 GB factor of 8.1e9 elements — every row offset from row 47 000 on exceeds 2³², where C4's matrix crosses that line only in
+    its last rows) through the size-independent properties, since no host can run the oracle here in reasonable time: the normal equations (K + σ²I) α = δ through
+    the Gram-row kernel (no factor involved) on 512 rows and on the host for 8, sqmahal = δᵀα (forward solve against backward solve), predictive variances in
+    range far from and at the data (the forward solve with the inverse diagonal blocks over 44 blocks), a sequential update with 1 024 points (normal equations over
+    the union); then value + gradient at N = 73 728 (5.4e9 elements: four N×N buffers fit the device) against central differences of gp_logpdf.  Round 6 found a
+    one-thread-per-element launch that wrapped at 2³² work-items without an error (NOTES_r6 §1): this is the test that would have caught its siblings."""
+    n, d, s2 = 90112, 3, 0.01
+    x, y = o.synth_inputs(n, d, 6)
+    ctx = agp.default_context()
+    f = agp.GP(agp.SqExponentialKernel())
+    post = agp.posterior(f(agp.RowVecs(x), s2), y)
+    try:
+        alpha = np.array(post.data.alpha)
+        assert np.all(np.isfinite(alpha)) and np.isfinite(post.logpdf_value)
+        idx = np.linspace(0, n - 1, 512).astype(int)
+        m_tr, v_tr = post.mean_and_var(agp.RowVecs(x[idx]))
+        np.testing.assert_allclose(m_tr, y[idx] - s2 * alpha[idx], rtol=0, atol=1e-8)
+        Krows = o.kernelmatrix(o.Kernel(o.SE), x[idx[-8:]], x)
+        np.testing.assert_allclose(Krows @ alpha + s2 * alpha[idx[-8:]], y[idx[-8:]], rtol=0, atol=1e-8)
+        assert v_tr.min() > -1e-9 and v_tr.max() <= s2 + 1e-9
+        _, v_far = post.mean_and_var(agp.RowVecs(x[:64] + 3.0))
+        assert v_far.min() >= -1e-9 and v_far.max() <= 1 + 1e-9
+        n2 = 1024
+        rng = np.random.default_rng(66)
+        x2 = rng.standard_normal((n2, d))
+        y2 = np.sin(x2.sum(1)) + 0.1 * rng.standard_normal(n2)
+        p2 = agp.posterior(post(agp.RowVecs(x2), s2), y2)
+        try:
+            a2, d2 = np.array(p2.data.alpha), np.array(p2.data.delta)
+            xa = np.concatenate([x, x2], axis=0)
+            j = np.concatenate([idx[::2], n + np.linspace(0, n2 - 1, 256).astype(int)])
+            np.testing.assert_allclose(p2.mean(agp.RowVecs(xa[j])), d2[j] - s2 * a2[j], rtol=0, atol=1e-8)
+        finally:
+            p2.data.C.free()
+    finally:
+        post.data.C.free()
+    ctx.trim()
+    sq = float(agp.sqmahal(f(agp.RowVecs(x), s2), y))
+    assert sq == pytest.approx(float(y @ alpha), rel=1e-9)
+    ctx.trim()
+    n = 73728
+    x, y = x[:n], y[:n]
+
+    def lp_at(var, sc, nz):
+        return float(agp.logpdf(agp.GP(var * agp.SqExponentialKernel() @ agp.ScaleTransform(sc))(agp.RowVecs(x), nz), y))
+
+    lp, g = agp.logpdf_and_grad(agp.GP(agp.SqExponentialKernel() @ agp.ScaleTransform(1.0))(agp.RowVecs(x), s2), y)
+    ctx.trim()
+    h = 1e-4
+    fd = {"variance": (lp_at(1 + h, 1.0, s2) - lp_at(1 - h, 1.0, s2)) / (2 * h),
+          "scale": (lp_at(1.0, 1 + h, s2) - lp_at(1.0, 1 - h, s2)) / (2 * h),
+          "noise": (lp_at(1.0, 1.0, s2 * (1 + h)) - lp_at(1.0, 1.0, s2 * (1 - h))) / (2 * h * s2)}
+    for name, val in fd.items():
+        assert float(g[name]) == pytest.approx(val, rel=2e-5), (name, float(g[name]), val)
+    ctx.trim()
+
+
 def test_committed_fullsize_parity_records():
     """The C4 / C5 (and C2 / C3) value comparisons produced on an MI355X box by tools/fullsize_parity.py."""
     import json
