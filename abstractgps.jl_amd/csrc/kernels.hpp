@@ -268,6 +268,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(CT* C, long ldc, co
     dma_wait_barrier();
 
     if constexpr (PIPE) {
+        // (round 6: a light loop for waves whose 64×64 quarter is never stored — the strictly-upper quarter of a diagonal tile in lower mode: DMAs and
+        //  barriers only, no fragments, no MFMA — was measured at C5 (32 of the SYRK's 528 tiles) and at C2 / C3 / C4: no effect, profiles/r6/c5_idle_ab.txt; removed)
         gemm_kloop_pipe<T>(acc, As, Bs, fa, fb, lg, sw, kt0, nk, [&](int j, int buf, long kt) {
             const int i = j & 3;
             if (j < 4) dma1(Ag[i] + kt * BK, ldsA + (unsigned)(buf * 16384 + (4 * i + w) * 1024));
@@ -1959,11 +1961,28 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const T* __restrict__ L, lo
 template <typename T>
 __global__ __launch_bounds__(256) void add_lower_batched_kernel(const T* __restrict__ S, long cstride, int nbatch, long lds,
                                                                  double* __restrict__ dst, long ldd, long n, long row_lo) {
-    const long j = (long)blockIdx.x * 256 + threadIdx.x, i = row_lo + blockIdx.y;
-    if (j > i || j >= n) return;
-    double acc = 0;
-    for (int b = 0; b < nbatch; ++b) acc += (double)S[(long)b * cstride + i * lds + j];
-    dst[i * ldd + j] += acc;
+    // four consecutive columns per thread (16-byte streaming loads of the partials: they are read once and must not push the GEMM operands out of
+    // the caches they share; rows start 16-byte aligned: lds and ldd are multiples of 4) — a quarter of the wave-instructions of the one-column form,
+    // so the launch holds the issue slots it shares with the chunk GEMMs for a quarter of the time
+    const long j0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4, i = row_lo + blockIdx.y;
+    if (j0 > i || j0 >= n) return;
+    double acc[4] = {0, 0, 0, 0};
+    if constexpr (sizeof(T) == 4) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        for (int b = 0; b < nbatch; ++b) {
+            const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(S + (long)b * cstride + i * lds + j0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (double)v[e];
+        }
+    } else {
+        for (int b = 0; b < nbatch; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (double)S[(long)b * cstride + i * lds + j0 + e];
+    }
+    double* d = dst + i * ldd + j0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (j0 + e <= i && j0 + e < n) d[e] += acc[e];
 }
 // One pass over row (row_lo + blockIdx.x) of Y = −B_c:  rowss[row] += Σ_c Y²  (‖B‖²_F per inducing row, fp64) and
 // cacc[row] −= Σ_c Y·b  (c = B b_y)                                         src/sparse_approximations.jl:66-71, 251
@@ -1974,10 +1993,30 @@ __global__ __launch_bounds__(256) void ystats_kernel(const T* __restrict__ Y, lo
     const long row = row_lo + blockIdx.x;
     const T* y = Y + row * ldy;
     double ss = 0, dot = 0;
-    for (long c = threadIdx.x; c < ncols; c += 256) {
-        const double v = (double)y[c];
-        ss = fma(v, v, ss);
-        dot = fma(v, (double)b[c], dot);
+    if constexpr (sizeof(T) == 4) {  // 16-byte streaming loads, four columns per thread and pass (rows of Y and the chunk's piece of b start 16-byte aligned)
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const long nc4 = ncols & ~3L;
+        for (long c = 4L * threadIdx.x; c < nc4; c += 1024) {
+            const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(y + c));
+            const f4_t w = *reinterpret_cast<const f4_t*>(b + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double vv = (double)v[e];
+                ss = fma(vv, vv, ss);
+                dot = fma(vv, (double)w[e], dot);
+            }
+        }
+        for (long c = nc4 + threadIdx.x; c < ncols; c += 256) {
+            const double v = (double)y[c];
+            ss = fma(v, v, ss);
+            dot = fma(v, (double)b[c], dot);
+        }
+    } else {
+        for (long c = threadIdx.x; c < ncols; c += 256) {
+            const double v = (double)y[c];
+            ss = fma(v, v, ss);
+            dot = fma(v, (double)b[c], dot);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

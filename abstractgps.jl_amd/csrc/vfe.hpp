@@ -294,7 +294,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
                     HIPCHK(hipStreamWaitEvent(sa, e, 0));
                     if (dual) evSy[bb] = e;
                 }
-                hipLaunchKernelGGL(add_lower_batched_kernel<T>, dim3((unsigned)((mp + 255) / 256), (unsigned)(mp - row_lo)), dim3(256),
+                hipLaunchKernelGGL(add_lower_batched_kernel<T>, dim3((unsigned)((mp + 1023) / 1024), (unsigned)(mp - row_lo)), dim3(256),
                                    0, sa, (const T*)Sb[bb], gs.cstride, NBAT, ld, (double*)D_v, ld, mp, row_lo);
                 HIPCHK(hipGetLastError());
                 if (ovl) {
