@@ -266,8 +266,8 @@ int32_t eng_assemble(gp_ctx* c, hipStream_t s, int kind, double variance, const 
 int32_t eng_potrf(gp_ctx* c, hipStream_t s, double* a, long lda, long m, long n, int* info_dev, long col0, long n_valid,
                   double* logdet_dev);
 int32_t eng_trsm(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* l, long ldl, long n);
-// w (nb × ldw) ← −inv(l) of one nb×nb lower block; iw: scratch of the same shape.  x ← x l⁻ᵀ as one triangular-k GEMM with it (sc: (m + 128) × lds scratch).
-int32_t eng_inv_lower(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nb, double* w, long ldw, double* iw);
+// w (nb × ldw) ← −inv(l) of one nb×nb lower block; iw: scratch of the same shape; v: a second one (level-wise batched inverse for nb = 64·2^m; NULL: recursion).  x ← x l⁻ᵀ as one triangular-k GEMM with it (sc: (m + 128) × lds scratch).
+int32_t eng_inv_lower(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nb, double* w, long ldw, double* iw, double* v_or_null);
 int32_t eng_trsm_inv(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* w, long ldw, long nb, double* sc, long lds);
 int32_t eng_gemm_nt(gp_ctx* c, hipStream_t s, double* cm, long ldc, const double* a, long lda, const double* b, long ldb, long m,
                     long n, long k, GridMap g);

@@ -740,9 +740,34 @@ int32_t gpmi::eng_potrf(gp_ctx* c, hipStream_t s, double* a, long lda, long m, l
 int32_t gpmi::eng_trsm(gp_ctx* c, hipStream_t s, double* x, long ldx, long m, const double* l, long ldl, long n) {
     return trsm_rec_v<double>(c, s, x, ldx, m, l, ldl, n);
 }
-// W ← −inv(L) for ONE nb×nb lower block (the multi-device driver's diagonal block): Iw = I, Iw ← Iw L⁻ᵀ (upper; the restricted-row recursion),
-// W = −Iwᵀ.  W, Iw: nb × ldw, both fully overwritten (the caller keeps 128 finite slack rows below W: the B-operand over-read of the GEMM).
-int32_t gpmi::eng_inv_lower(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nb, double* w, long ldw, double* iw) {
+// W ← −inv(L) for ONE nb×nb lower block (the multi-device driver's diagonal block).  W, iw (and v): nb × ldw; the caller keeps 128 finite slack rows below each
+// (the operand over-read of the GEMM) and W zero above its diagonal.
+//   nb = 64·2^m and a second scratch v given — LEVEL-WISE (round 6): −inv and its transpose of every 64×64 diagonal tile in one launch (trtri_64_neg), then per level
+//   s = 64, 128, …, nb/2 and for ALL pairs of the level at once (batched launches): with An = −inv(L11), Cn = −inv(L22) of the level below (lower, in W) and their
+//   transposes (upper, in iw),  V = −AnT·L21ᵀ (= (L21·inv(L11))ᵀ),  W21 = −Cn·Vᵀ (= inv(L22)·L21·inv(L11) = −(−inv(L))21),  WT12 = −V·Cnᵀ (its transpose):
+//   1 + 3·log2(nb/64) launches (13 at nb = 1 024) where the restricted-row recursion on the identity takes nb/64 substitution leaves and as many few-tile GEMMs (33).
+//   iw's lower-left and W's upper-right triangles are never written (the caller zeroed them once).
+//   otherwise: Iw = I, Iw ← Iw L⁻ᵀ (upper; the restricted-row recursion), W = −Iwᵀ.
+int32_t gpmi::eng_inv_lower(gp_ctx* c, hipStream_t s, const double* l, long ldl, long nb, double* w, long ldw, double* iw, double* v) {
+    const long t64 = nb / 64;
+    if (v && nb >= 128 && nb % 64 == 0 && (t64 & (t64 - 1)) == 0) {
+        hipLaunchKernelGGL(trtri_64_neg_kernel<double>, dim3((unsigned)t64), dim3(64), 0, s, l, ldl, w, iw, ldw);
+        HIPCHK(hipGetLastError());
+        for (long sz = 64; sz < nb; sz *= 2) {
+            GridMap g = plain_map(0, 0, 0);
+            g.beta0 = 1;
+            g.nbatch = (int)(nb / (2 * sz));
+            const long sw = 2 * sz * ldw + 2 * sz, sl = 2 * sz * ldl + 2 * sz;  // pair p: diagonal position 2·p·sz in W / iw / v, and in l
+            g.cstride = sw;
+            g.astride = sw;
+            g.bstride = sl;
+            RC(launch_gemm<double>(c, s, v, ldw, iw, ldw, l + sz * ldl, ldl, sz, sz, sz, g));                        // V = −AnT · L21ᵀ
+            g.bstride = sw;
+            RC(launch_gemm<double>(c, s, w + sz * ldw, ldw, w + sz * ldw + sz, ldw, v, ldw, sz, sz, sz, g));         // W21 = −Cn · Vᵀ
+            RC(launch_gemm<double>(c, s, iw + sz, ldw, v, ldw, w + sz * ldw + sz, ldw, sz, sz, sz, g));              // WT12 = −V · Cnᵀ
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((nb + 255) / 256), (unsigned)nb), dim3(256), 0, s, iw, ldw, nb);
     HIPCHK(hipGetLastError());
     RC(trsm_upper_rec<double>(c, s, iw, ldw, l, ldl, 0, nb));

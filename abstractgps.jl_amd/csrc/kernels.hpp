@@ -1479,6 +1479,48 @@ __global__ __launch_bounds__(64) void trtri_64_kernel(const T* __restrict__ L, l
     for (int t = 0; t < 64; ++t) Wj[t * 64 + tid] = ((t == tid) ? T(1) : T(0)) - ((t >= tid) ? x[t] : T(0));
 }
 
+// trtri_64_neg (batched): the base of the level-wise inverse of a lower block (gpmi355.hip eng_inv_lower): for every 64×64 diagonal tile j, −inv(L_jj) into the
+// pitched matrix W (lower, zeros above the diagonal of the tile) and its transpose into WT (upper).  Same substitution as trtri_64_kernel.
+template <typename T>
+__global__ __launch_bounds__(64) void trtri_64_neg_kernel(const T* __restrict__ L, long ldl, T* __restrict__ W, T* __restrict__ WT, long ldw) {
+    using chunk_t = typename Tr<T>::chunk_t;
+    constexpr int VEC = Tr<T>::VEC;
+    __shared__ __attribute__((aligned(16))) T Lt[64][64];
+    const int tid = threadIdx.x;
+    const long j0 = (long)blockIdx.x * 64;
+    const T* Lj = L + j0 * ldl + j0;
+    const chunk_t* lrow = reinterpret_cast<const chunk_t*>(Lj + (long)tid * ldl);
+#pragma unroll
+    for (int t = 0; t < 64 / VEC; ++t) {
+        const chunk_t v = lrow[t];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = VEC * t + e;
+            Lt[c][tid] = (c == tid) ? T(1) / v[e] : v[e];
+        }
+    }
+    __syncthreads();
+    T x[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) x[t] = (t == tid) ? T(1) : T(0);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const T v = x[c] * Lt[c][c];
+        x[c] = v;
+#pragma unroll
+        for (int t = c + 1; t < 64; ++t) x[t] = fma(-v, Lt[c][t], x[t]);
+    }
+    // lane tid holds column tid of inv(L_jj): x[t] = inv[t][tid] for t >= tid
+    T* Wj = W + j0 * ldw + j0;
+    T* WTj = WT + j0 * ldw + j0;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+        const T v = (t >= tid) ? -x[t] : T(0);
+        Wj[(long)t * ldw + tid] = v;
+        WTj[(long)tid * ldw + t] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Vector triangular solves, blocked by NBV = 1024 with 64-wide inner steps.  nrhs right-hand sides
 // are stored as rows: R[s*ldr + i].

@@ -369,7 +369,8 @@ struct gp_multi {
     long fits = 0, retries = 0;  // fit attempts / repetitions after a failed self-check (gp_ctx_multi_stats)
     int chain_cus = 0;       // "multi_chain_cus": CUs reserved for the diagonal block's chain (0: the chain shares the machine with the bulk update)
     bool dry_chain = false;  // (schedule trace only: the chain-stream schedule without streams)
-    int trsm_inv = 1;        // rows-below solve of a panel as ONE triangular-k GEMM with the diagonal owner's −inv(L_kk) ("multi_trsm_inv"; 0: substitution recursion)
+    int trsm_inv = 1;        // rows-below solve of a panel as ONE triangular-k GEMM with the diagonal owner's −inv(L_kk) ("multi_trsm_inv"; 0: substitution recursion;
+                             // 1: the inverse level by level in batched launches when nb = 64·2^m; 2: the inverse by the restricted-row recursion on the identity)
     bool use_inv = true;     // ... for the fit in flight (multi_fit: trsm_inv and the conditioning bound of the inputs)
     long window = 16;        // block steps a rank thread may queue ahead of its device ("multi_window")
     double timeout_s = 600;  // a rank thread that waits longer than this for a peer or for its own streams fails the fit
@@ -613,7 +614,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
     const int check = rr.check;
 
     // ---- buffers
-    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0, *ver_v = 0, *Wi_v = 0, *Iw_v = 0, *Sx_v = 0;
+    void *A_v = 0, *xs_v = 0, *nz_v = 0, *Lkk_v = 0, *acc_v = 0, *ab_v = 0, *tmp_v = 0, *chk_v = 0, *ver_v = 0, *Wi_v = 0, *Iw_v = 0, *Sx_v = 0, *Vs_v = 0;
     // rows-below solve by the explicit inverse of the diagonal block (M->use_inv): the diagonal owner of block column k forms W_k = −inv(L_kk) into ITS
     // slot k / lcm(P, Q) of Winv (a slot per owned diagonal block: nothing is rewritten while a peer may still read it) and W_k travels instead of L_kk;
     // every owner of the column then solves its rows with ONE triangular-k MFMA GEMM, S = −X W_kᵀ = X L_kk⁻ᵀ, copied back over X — instead of the
@@ -645,6 +646,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
         if (use_inv) {
             RC(bufs->get(sizeof(double) * (size_t)(n_own * NB + 128) * LDP, &Wi_v));
             RC(bufs->get(sizeof(double) * (size_t)(NB + 128) * LDP, &Iw_v));
+            if (M->trsm_inv == 1) RC(bufs->get(sizeof(double) * (size_t)(NB + 128) * LDP, &Vs_v));  // second scratch: the level-wise inverse (eng_inv_lower)
             RC(bufs->get(sizeof(double) * (size_t)(m_loc + 128) * LDP, &Sx_v));
         }
     }
@@ -698,6 +700,8 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
                      }
                  }
                  if (Wi_v) MCHK(hipMemsetAsync(Wi_v, 0, sizeof(double) * (size_t)(n_own * NB + 128) * LDP, sm));  // (slack rows below the last slot stay zero)
+                 if (Iw_v) MCHK(hipMemsetAsync(Iw_v, 0, sizeof(double) * (size_t)(NB + 128) * LDP, sm));  // (the level-wise inverse never writes its lower-left triangle)
+                 if (Vs_v) MCHK(hipMemsetAsync(Vs_v, 0, sizeof(double) * (size_t)(NB + 128) * LDP, sm));
                  MCHK(hipMemsetAsync(Lkk_v, fill, sizeof(double) * (size_t)NB * LDP, sm));
                  MCHK(hipMemsetAsync((double*)Lkk_v + NB * LDP, 0, sizeof(double) * (size_t)128 * LDP, sm));
                  RC(eng_assemble(c, sm, kind, variance, (const double*)xs_v, n, npad, dm.d, (const double*)nz_v, g, A, ld, nlb_r * NB, n_loc));
@@ -811,7 +815,7 @@ int32_t fit_rank(gp_multi* M, MRank* me, const Dims& dm, bool dry, int kind, dou
                     double* Wk = me->Winv + slot * NB * LDP;
                     const Fp fw = Fp{"Wi", R_, 0, 0, slot, slot + 1, 0};
                     const double* Ld = A + r0 * ld + c0;
-                    RC(rr.op(SDg, "inv_lkk", k, 0, {fd}, {fw}, [&]() { return eng_inv_lower(c, sdg, Ld, ld, NB, Wk, LDP, (double*)Iw_v); }));
+                    RC(rr.op(SDg, "inv_lkk", k, 0, {fd}, {fw}, [&]() { return eng_inv_lower(c, sdg, Ld, ld, NB, Wk, LDP, (double*)Iw_v, (double*)Vs_v); }));
                     lkk_ptr = Wk;
                     lkk_ld = LDP;
                     f_l = fw;
@@ -1578,7 +1582,7 @@ int32_t multi_set_param(gp_ctx* c, const char* name, int64_t v) {
         return 0;
     }
     if (!strcmp(name, "multi_trsm_inv")) {
-        m->trsm_inv = v != 0;
+        m->trsm_inv = v <= 0 ? 0 : (v >= 2 ? 2 : 1);
         return 0;
     }
     if (!strcmp(name, "multi_chain_cus")) return multi_set_chain_cus(m, (int)v);

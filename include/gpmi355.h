@@ -200,7 +200,9 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    owners instead of L_kk; every owner then solves its rows below the block with ONE triangular-k MFMA GEMM + one copy instead of the
  *                    substitution recursion's nb/64 latency-bound leaf launches and as many few-tile GEMMs (nb = 1 024: 31 launches per rank and step -> 2).
  *                    Same conditioning rule as "dib_nb", decided from the inputs before the fit: every pivot of K + Σy lies in
- *                    [min Σy_ii, variance + max Σy_ii], and a fit with sqrt((variance + max Σy) / min Σy) > 1e5 keeps the substitution solve.   default 1
+ *                    [min Σy_ii, variance + max Σy_ii], and a fit with sqrt((variance + max Σy) / min Σy) > 1e5 keeps the substitution solve.  1: the owner forms the inverse
+ *                    level by level (−inv and its transpose of every 64×64 tile, then 3 batched GEMMs per level: 13 launches at nb = 1 024; nb = 64·2^m), 2: by the
+ *                    restricted-row recursion on the identity (33 launches; what 1 falls back to for other nb).   default 1
  *   "multi_chain_cus" multi-device: r > 0 reserves r CUs (r/8 of every XCD; multiple of 8, at most half the device) of every rank's GPU for the diagonal
  *                    block's chain (Cholesky of the nb×nb block + its inverse) on a CU-masked stream of its own; the panel and main streams' work then
  *                    runs on streams masked to the other CUs.  Measured on one GPU (profiles/r5/cumask_chain_probe.jsonl): a 1 024-column chain beside the bulk

@@ -74,11 +74,11 @@ def test_lookahead_depths_and_ragged_sizes(agp, depth, P, Q, n, nb):
         ctx.close()
 
 
-@pytest.mark.parametrize("inv,cus", [(0, 0), (1, 16), (0, 16), (1, 64)], ids=["subst", "inv_chain16", "subst_chain16", "inv_chain64"])
+@pytest.mark.parametrize("inv,cus", [(0, 0), (2, 0), (1, 16), (0, 16), (1, 64)], ids=["subst", "inv_by_recursion", "inv_chain16", "subst_chain16", "inv_chain64"])
 @pytest.mark.parametrize("P,Q,n,nb", [(2, 2, 2300, 256), (4, 1, 1800, 128), (2, 4, 2100, 128)])
 def test_rows_below_solve_variants_and_the_masked_chain_stream(agp, P, Q, n, nb, inv, cus):
-    """The non-default settings of the panel step: "multi_trsm_inv" = 0 (L_kk travels, substitution recursion below it; the default — −inv(L_kk) travels,
-    one triangular-k GEMM per owner — is what every other test of this file runs) and "multi_chain_cus" = r (the diagonal block's Cholesky + inverse on a
+    """The non-default settings of the panel step: "multi_trsm_inv" = 0 (L_kk travels, substitution recursion below it; the default 1 — −inv(L_kk), formed level
+    by level in batched launches, travels, one triangular-k GEMM per owner — is what every other test of this file runs; 2 forms the inverse by the recursion) and "multi_chain_cus" = r (the diagonal block's Cholesky + inverse on a
     stream masked to r CUs, panel / main work on the complement), against the oracle at the single-GPU tolerances, two fits each; the masked streams are
     dropped again with 0."""
     x, y = o.synth_inputs(n, 3, 90 + P + Q)
