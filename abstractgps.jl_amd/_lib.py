@@ -86,6 +86,8 @@ PROTOTYPES = {
     "gpd_assemble": (i32, [vp, PK, vp, i64, i64, i32, vp, PG, vp, i64, i64, i64]),
     "gpd_potrf": (i32, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
     "gpd_trsm": (i32, [vp, vp, i64, i64, vp, i64, i64]),
+    "gpd_inv_lower": (i32, [vp, vp, i64, i64, vp, i64, vp, vp]),
+    "gpd_trsm_inv": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64]),
     "gpd_gemm_nt": (i32, [vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, PG, i64, i64]),
     "gpd_trsv": (i32, [vp, vp, i64, i64, vp, i64, i32, i32]),
     "gpd_gemv_t": (i32, [vp, vp, i64, i64, i64, vp, vp]),

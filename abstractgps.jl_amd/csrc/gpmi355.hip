@@ -2560,6 +2560,23 @@ int32_t gpd_trsm(gp_ctx* c, double* x, int64_t ldx, int64_t m, const double* lma
     return trsm_rec<double>(c, c->sm, x, ldx, m, lmat, ldl, n);
 }
 
+int32_t gpd_inv_lower(gp_ctx* c, const double* lmat, int64_t ldl, int64_t nb, double* w, int64_t ldw, double* scratch1, double* scratch2) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (nb < 64 || nb % 64) return set_arg_err(4, "nb must be a multiple of 64");
+    if (!lmat || !w || !scratch1) return set_arg_err(2, "l / w / scratch1 is NULL");
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return gpmi::eng_inv_lower(c, c->sm, lmat, ldl, nb, w, ldw, scratch1, scratch2);
+}
+int32_t gpd_trsm_inv(gp_ctx* c, double* x, int64_t ldx, int64_t m, const double* w, int64_t ldw, int64_t nb, double* scratch, int64_t lds) {
+    if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");
+    if (nb % 64 || m % 64) return set_arg_err(3, "m, nb must be multiples of 64");
+    if (m == 0) return 0;
+    std::lock_guard<std::mutex> l(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return gpmi::eng_trsm_inv(c, c->sm, x, ldx, m, w, ldw, nb, scratch, lds);
+}
+
 int32_t gpd_gemm_nt(gp_ctx* c, double* cm, int64_t ldc, const double* a, int64_t lda, const double* b, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, const gp_grid* g, int64_t row0, int64_t col0) {
     if (!c || !reg_has(c)) return set_arg_err(1, "not a live gp_ctx");

@@ -381,6 +381,14 @@ int32_t gpd_potrf(gp_ctx* ctx, double* a, int64_t lda, int64_t m, int64_t n, int
                   int64_t n_valid, double* logdet_dev);
 /* X (m×n) ← X · L⁻ᵀ with L the n×n lower factor (row-major, ldl). */
 int32_t gpd_trsm(gp_ctx* ctx, double* x, int64_t ldx, int64_t m, const double* l, int64_t ldl, int64_t n);
+/* The two pieces of the multi-device panel step ("multi_trsm_inv"; csrc/multi.hip):
+ *   gpd_inv_lower: W (nb × ldw, lower) ← −inv(L) for the nb×nb lower block L.  W must be zero above its diagonal on entry and, like both scratch blocks, followed by
+ *                  128 finite slack rows; scratch1 / scratch2: (nb + 128) × ldw doubles, ZEROED by the caller before the first use (their untouched triangles must stay
+ *                  zero).  nb = 64·2^m with scratch2 != NULL: level by level in 1 + 3·log2(nb/64) batched launches; otherwise (scratch2 NULL or another nb, nb a
+ *                  multiple of 64): the restricted-row recursion on the identity.
+ *   gpd_trsm_inv : X (m × nb) ← X · L⁻ᵀ = −X · Wᵀ with that W as ONE triangular-k GEMM into scratch ((m + 128) × lds doubles) + one copy back. */
+int32_t gpd_inv_lower(gp_ctx* ctx, const double* l, int64_t ldl, int64_t nb, double* w, int64_t ldw, double* scratch1, double* scratch2_or_null);
+int32_t gpd_trsm_inv(gp_ctx* ctx, double* x, int64_t ldx, int64_t m, const double* w, int64_t ldw, int64_t nb, double* scratch, int64_t lds);
 /* C (m×n) -= A (m×k) · B (n×k)ᵀ.  With g != NULL and g->lower, 64×64 sub-tiles strictly above the
  * global diagonal are skipped; row0/col0 = local absolute index of C's first row/column (mapped to
  * global indices through g).  g == NULL: plain rectangular update. */

@@ -229,6 +229,48 @@ def test_trsv_block_sizes(lib, h, nbv):
         check(lib.gp_ctx_set_param(h, b"trsv_nb", 256))
 
 
+@pytest.mark.parametrize("nb", [128, 256, 384, 1024, 2048])
+def test_block_inverse_and_inverse_block_solve(lib, h, nb):
+    """The two pieces of the multi-device panel step through their device-level entry points: gpd_inv_lower — W = −inv(L) of an nb×nb lower block, level by level in
+    batched launches (nb = 64·2^m with the second scratch) or by the restricted-row recursion (nb = 384; or no second scratch) — against torch, both forms against each
+    other, and gpd_trsm_inv — X ← X L⁻ᵀ as one triangular-k GEMM with that W — against gpd_trsm (substitution) and torch, with a ragged row count."""
+    from abstractgps_jl_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(nb)
+    G = torch.randn(nb, 64, dtype=torch.float64, device="cuda", generator=g)
+    L = torch.linalg.cholesky(G @ G.T / 64 + 2.0 * torch.eye(nb, dtype=torch.float64, device="cuda"))
+    ld = nb + 32
+    Lp = torch.zeros(nb + 128, ld, dtype=torch.float64, device="cuda")
+    Lp[:nb, :nb] = torch.tril(L) + torch.triu(torch.full_like(L, float("nan")), 1)      # the strictly upper part must never be read
+    ref = -torch.linalg.inv(L)
+    out = {}
+    for tag, two in (("levels", True), ("recursion", False)):
+        W = torch.zeros(nb + 128, ld, dtype=torch.float64, device="cuda")
+        S1 = torch.zeros(nb + 128, ld, dtype=torch.float64, device="cuda")
+        S2 = torch.zeros(nb + 128, ld, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(lib.gpd_inv_lower(h, P(Lp), ld, nb, P(W), ld, P(S1), P(S2) if two else None))
+        _sync(lib, h)
+        assert torch.isfinite(W).all().item()
+        assert (W[:nb, :nb] - ref).abs().max().item() < 1e-11 * ref.abs().max().item() * nb, (nb, tag)
+        assert W[:nb, :nb].triu(1).abs().max().item() == 0.0
+        out[tag] = W
+    assert (out["levels"][:nb, :nb] - out["recursion"][:nb, :nb]).abs().max().item() < 1e-11 * ref.abs().max().item() * nb
+    m = 64 * 37                                                                           # not a multiple of 128
+    X0 = torch.randn(m + 128, ld, dtype=torch.float64, device="cuda", generator=g)
+    want = torch.linalg.solve_triangular(L, X0[:m, :nb].T, upper=False).T
+    Xa, Xb = X0.clone(), X0.clone()
+    S = torch.zeros(m + 128, ld, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    check(lib.gpd_trsm_inv(h, P(Xa), ld, m, P(out["levels"]), ld, nb, P(S), ld))
+    check(lib.gpd_trsm(h, P(Xb), ld, m, P(Lp), ld, nb))
+    _sync(lib, h)
+    scale = want.abs().max().item()
+    assert (Xa[:m, :nb] - want).abs().max().item() < 1e-10 * scale
+    assert (Xb[:m, :nb] - want).abs().max().item() < 1e-10 * scale
+    assert torch.equal(Xa[m:], X0[m:]) and torch.equal(Xa[:m, nb:], X0[:m, nb:])          # nothing outside the m × nb block is touched
+
+
 @pytest.mark.parametrize("sk", [0, 1])
 def test_fit_with_and_without_streamk(agp, sk):
     """the few-tile GEMMs cut along k over all CUs (stream-K, hardware atomics) or not: same logpdf / α as the oracle"""

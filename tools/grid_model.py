@@ -38,6 +38,21 @@ TRSM_RATE = 45e12   # MFMA TRSM of a tall block against an NB×NB factor (recurs
 CHAIN_MS = {"standalone": {512: 0.179, 1024: 0.358}, "unmasked": {512: 1.023, 1024: 3.590}, "masked16": {512: 0.174, 1024: 0.456}}
 BULK_SLOW = {"standalone": 1.0, "unmasked": 1.0, "masked16": 1.04}
 CHAIN = None        # None: pm.panel(NB, NB) × CORES (the rounds 2–4 model)
+# Round 6: the panel step's pieces measured STANDALONE on one idle device through gpd_potrf / gpd_inv_lower / gpd_trsm_inv / gpd_trsm with the rank-context settings
+# (tools/panel_step_probe.py, profiles/r6/panel_step_probe.jsonl; ms): Cholesky of the diagonal block, its inverse level by level, and the rows-below solve of m rows
+# by one GEMM with the inverse ("inv", what the driver ships) / by the substitution recursion ("subst"), each as a + b·m through the two measured row counts.
+# `python tools/grid_model.py step=inv|subst` prices panel(k) with these instead of CHAIN_MS / TRSM_RATE (an idle chain stream: the optimistic end; beside an unmasked
+# bulk update every launch of the chain waits for workgroup slots, and the inverse form has 46 launches per step where the substitution form has 62).
+STEP = None
+STEP_MS = {512: {"potrf": 0.1688, "inv": 0.2182, "solve_inv": (8192, 0.0866, 32768, 0.3080), "solve_subst": (8192, 0.2347, 32768, 0.3296)},
+           1024: {"potrf": 0.3537, "inv": 0.4166, "solve_inv": (8192, 0.2788, 32768, 0.9784), "solve_subst": (8192, 0.5401, 32768, 0.9497)},
+           2048: {"potrf": 0.8532, "inv": 0.7906, "solve_inv": (8192, 0.8304, 32768, 2.7166), "solve_subst": (8192, 1.3504, 32768, 2.7897)}}
+
+
+def _lin(tab, m):
+    m0, t0, m1, t1 = tab
+    b = (t1 - t0) / (m1 - m0)
+    return max(0.0, t0 + b * (m - m0)) if m > 0 else 0.0
 CORES = 1.0         # slow-down of the diagonal block's leaf chain when it runs BESIDE the bulk update (round 4, one GPU: a 64-column leaf that shares CUs
                     # with the tile GEMM runs ≈ 5× slower, profiles/r4/traces/c3_c64_summary.txt; `python tools/grid_model.py cores=5` prices that)
 
@@ -73,6 +88,16 @@ def model(N, P, Q, NB, depth=2, forward=False):
 
     def panel_time(k):
         m = nblk - k - 1
+        if STEP is not None and NB in STEP_MS:                 # measured standalone pieces of the shipped panel step
+            tab = STEP_MS[NB]
+            rows = math.ceil(m / P) * NB
+            t = tab["potrf"] * 1e-3
+            if P > 1:
+                t += (tab["inv"] * 1e-3 if STEP == "inv" else 0.0) + 8.0 * NB * NB / LINK + MSG_LAT
+                t += _lin(tab["solve_inv" if STEP == "inv" else "solve_subst"], rows) * 1e-3
+            else:
+                t += _lin(tab["solve_subst"], rows) * 1e-3     # P = 1: the column is factored in place (eng_potrf over all rows)
+            return t
         if CHAIN is None:
             t = pm.panel(NB, NB) * CORES                       # diagonal block on its owner (beside the bulk update: CORES)
         else:                                                  # measured (NB = 2 048 was not: scaled from 1 024 by the model's own ratio)
@@ -178,6 +203,9 @@ if __name__ == "__main__":
         if a.startswith("cores="):
             CORES = float(a.split("=")[1])
             print(f"diagonal-block chain priced {CORES:g}x slower (co-resident with the bulk update)")
+        if a.startswith("step="):
+            STEP = a.split("=")[1]
+            print(f"panel step: MEASURED standalone pieces '{STEP}' (tools/panel_step_probe.py, profiles/r6/panel_step_probe.jsonl)")
         if a.startswith("chain="):
             CHAIN = a.split("=")[1]
             print(f"diagonal-block chain: MEASURED durations '{CHAIN}' {CHAIN_MS[CHAIN]} ms (tools/cumask_chain_probe.py), bulk update x{BULK_SLOW[CHAIN]}")
