@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(1024) void trsv_diag2_kernel(const T* __restrict__ 
 //  applying the published blocks, in-kernel progress counters with agent-scope release / acquire — verified it against this path and measured it SLOWER at
 //  every size: N = 4 096 pair 2.20 -> 2.41 ms, C2 28.8 -> 31.5, N = 32 768 185.3 -> 196.4, C4 1 383 -> 1 445, C5 76.8 -> 77.5 (profiles/r6/trsv_persist_ab.jsonl):
 //  a device-scope release is a write-back of the XCD's whole L2 (buffer_wbl2 sc1), an acquire its invalidation (buffer_inv sc1), and the two hand-overs per
-//  block cost ≈ 59 µs where two dependent launches cost ≈ 18.  Removed; in the history at f29d505: "Vector solves as one persistent launch".)
+//  block cost ≈ 59 µs where the two launches they replace take ≈ 18 (3 µs of dispatch each, the rest their own work).  Removed; in the history at f29d505: "Vector solves as one persistent launch".)
 // rows [row_lo, row_hi): r[s][i] -= Σ_{j<nbv} L[i][b0+j] z[s][b0+j]; one wave per row, 4 rows per block.
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_upd_fwd_kernel(const T* __restrict__ L, long ldl, long b0, int nbv,

@@ -35,18 +35,25 @@ def test_missing_library_fails_loudly(agp, monkeypatch, tmp_path):
 
 
 def test_marshal_layouts(agp):
-    """ColVecs (D×N column-major) / RowVecs (N×D column-major) reach the ABI in the documented layout
-    (reference src/finite_gp_projection.jl:32-37)."""
+    """ColVecs / RowVecs (reference src/finite_gp_projection.jl:32-37) reach the ABI in one of its two documented layouts — layout 1: element (dimension dd, point i)
+    at data[dd + i·D], layout 2: at data[i + dd·N] — and WITHOUT a host copy whenever the array already lies in one of them (a C-ordered RowVecs matrix is layout 1 as
+    it lies, a Fortran-ordered one — what Julia's RowVecs holds — layout 2; ColVecs the other way round); other dtypes / strided views are copied."""
     X = np.arange(12.0).reshape(4, 3)  # 4 points, D = 3
+
+    def element(p, i, dd):
+        buf = np.ctypeslib.as_array(C.cast(p.data, C.POINTER(C.c_double)), shape=(12,))
+        return buf[dd + i * 3] if p.layout == 1 else buf[i + dd * 4]
+
     m = agp.api._Marshal(np.float64)
-    p = m.points(agp.RowVecs(X))
-    assert (p.n, p.d, p.layout) == (4, 3, 2)
-    buf = np.ctypeslib.as_array(C.cast(p.data, C.POINTER(C.c_double)), shape=(12,))
-    assert [buf[i + dd * 4] for i in range(4) for dd in range(3)] == list(X.ravel())
-    p = m.points(agp.ColVecs(X.T.copy()))
-    assert (p.n, p.d, p.layout) == (4, 3, 1)
-    buf = np.ctypeslib.as_array(C.cast(p.data, C.POINTER(C.c_double)), shape=(12,))
-    assert [buf[dd + i * 3] for i in range(4) for dd in range(3)] == list(X.ravel())
+    cases = [(agp.RowVecs(X), 1, True), (agp.RowVecs(np.asfortranarray(X)), 2, True), (agp.ColVecs(X.T.copy()), 2, True), (agp.ColVecs(X.T), 1, True),
+             (agp.RowVecs(X.astype(np.float32)), 2, False), (agp.RowVecs(np.arange(24.0).reshape(4, 6)[:, ::2]), 2, False)]
+    for inp, layout, zero_copy in cases:
+        p = m.points(inp)
+        A = np.asarray(inp.X)
+        pts = A if isinstance(inp, agp.RowVecs) else A.T
+        assert (p.n, p.d, p.layout) == (4, 3, layout)
+        assert [element(p, i, dd) for i in range(4) for dd in range(3)] == [float(v) for v in pts.ravel()]
+        assert (p.data == A.ctypes.data) == zero_copy
     p = m.points(np.arange(5.0))
     assert (p.n, p.d, p.layout) == (5, 1, 0)
 
