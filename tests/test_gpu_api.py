@@ -663,3 +663,49 @@ def test_fp32_predictions_with_inverse_diagonal_blocks(agp, dib_nb):
         finally:
             c0.close()
         assert np.array_equal(vg, v0)
+
+
+def test_input_containers_in_every_memory_order(agp):
+    """RowVecs / ColVecs with C-ordered, Fortran-ordered and strided arrays (the Python mirror passes an array that already lies in one of the two ABI layouts without a
+    host copy, anything else through one — tests/test_abi.py pins which): the same points give the same logpdf, α, predictions and ∂logpdf/∂x (in the shape of the
+    container's array) whichever way they are stored — against the oracle and against each other."""
+    rng = np.random.default_rng(61)
+    n, d = 700, 3
+    X = rng.standard_normal((n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    xs = rng.standard_normal((40, d))
+    big = rng.standard_normal((n, 2 * d))
+    big[:, ::2] = X
+    forms = {"row_c": agp.RowVecs(np.ascontiguousarray(X)), "row_f": agp.RowVecs(np.asfortranarray(X)), "row_strided": agp.RowVecs(big[:, ::2]),
+             "col_c": agp.ColVecs(np.ascontiguousarray(X.T)), "col_f": agp.ColVecs(np.asfortranarray(X.T))}
+    k = 1.3 * agp.Matern52Kernel() @ agp.ARDTransform([0.7, 1.1, 0.9])
+    ok = o.Kernel(o.MATERN52, 1.3, np.array([0.7, 1.1, 0.9]))
+    lp_o, post_o = o.logpdf_and_posterior(o.FiniteGP(o.GP(ok), X, 0.05), y)
+    gx_o = o.logpdf_grad(o.FiniteGP(o.GP(ok), X, 0.05), y)["x"]
+    ctx = agp.Context(0)
+    ctx.set_param("deterministic", 1)
+    try:
+        f = agp.GP(k, ctx=ctx)
+        ref = None
+        for name, xin in forms.items():
+            fx = f(xin, 0.05)
+            post = agp.posterior(fx, y)
+            xs_in = agp.RowVecs(xs) if name.startswith("row") else agp.ColVecs(np.asfortranarray(xs.T))
+            m, v = post.mean_and_var(xs_in)
+            lp, g = agp.logpdf_and_grad(fx, y, wrt_x=True)
+            assert float(lp) == pytest.approx(lp_o, rel=1e-10), name
+            assert np.linalg.norm(post.data.alpha - post_o.alpha) / np.linalg.norm(post_o.alpha) <= 1e-8, name
+            gx = g["x"] if name.startswith("row") else g["x"].T
+            assert gx.shape == (n, d), name
+            np.testing.assert_allclose(gx, gx_o, rtol=1e-6, atol=1e-8)
+            cur = (float(lp), np.array(post.data.alpha), np.array(m), np.array(v), np.array(gx))
+            post.data.C.free()
+            if ref is None:
+                ref = cur
+            else:  # the library sees the same scaled, dimension-major inputs whatever the container: identical bits with the no-atomics path
+                assert cur[0] == ref[0], name  # (the gradient kernels keep their atomics: agreement to rounding there)
+                for a, b in zip(cur[1:4], ref[1:4]):
+                    assert np.array_equal(a, b), name
+                np.testing.assert_allclose(cur[4], ref[4], rtol=1e-11, atol=1e-13)
+    finally:
+        ctx.close()
