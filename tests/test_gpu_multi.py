@@ -389,8 +389,8 @@ def test_schedule_under_truly_concurrent_streams():
     """The schedule's event dependencies under real concurrency: with the default 4 hardware queues HIP mostly serialises the
     3·P·Q streams of the virtual ranks, which hid a missing dependency in development (a rank's own panel was not covered by
     its `arrived` event when gcd(P, Q) > 1).  GPU_MAX_HW_QUEUES=32 has to be set before HIP initialises, hence a subprocess:
-    tools/multi_diag.py repeats logpdf / matrix-logpdf / posterior on six grids (up to 16 ranks = 48 streams) and three look-ahead depths vs the oracle
-    (round 6: one call of each kind per context and the two P×1 / 1×Q grids that the parity tests above cover left out — 176 s -> ≈ 95 s of a suite that had grown
+    tools/multi_diag.py repeats logpdf / matrix-logpdf / posterior on four grids with gcd(P, Q) > 1 or coprime P, Q (up to 16 ranks = 48 streams) and three look-ahead
+    depths vs the oracle (round 6: one call of each kind per context, and the P×1 / 1×Q / 2×4 grids that the parity tests above cover left out — 176 s -> ≈ 75 s of a suite that had grown
     past ten minutes; the schedule of every grid is checked exhaustively on its trace without a device, tests/test_multi_schedule.py)."""
     import os
     import subprocess
@@ -398,7 +398,7 @@ def test_schedule_under_truly_concurrent_streams():
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", DIAG_ITERS="3", DIAG_GRIDS="2x2,4x2,2x4,2x3,8x1,4x4")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", DIAG_ITERS="3", DIAG_GRIDS="2x2,4x2,2x3,4x4")
     r = subprocess.run([sys.executable, str(root / "tools" / "multi_diag.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "FAILURES 0" in r.stdout
@@ -417,9 +417,9 @@ def test_fresh_context_first_fits_with_every_diagnostic_on():
 
     root = Path(__file__).resolve().parent.parent
     for comm in ("p2p", "rccl"):
-        r = subprocess.run([sys.executable, str(root / "tools" / "multi_fresh_stress.py"), "6", "check=7", "verify=1", f"comm={comm}", "grids=8x1,4x2", "n=1537"],
+        r = subprocess.run([sys.executable, str(root / "tools" / "multi_fresh_stress.py"), "4", "check=7", "verify=1", f"comm={comm}", "grids=8x1,4x2", "n=1537"],
                            capture_output=True, text=True, timeout=600)
         tail = (r.stdout.strip().splitlines() or [""])[-1]
         print(f"[fresh-context stress, {comm}] {tail}")
         assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
-        assert "0 bad of 12" in tail, tail
+        assert "0 bad of 8" in tail, tail
