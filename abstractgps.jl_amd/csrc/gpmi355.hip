@@ -94,14 +94,27 @@ void ctx_release(gp_ctx* c, void* p, size_t /*requested*/) {
         bytes = it->second;
         c->blk.erase(it);
     }
-    if (c->dead || bytes == 0 || bytes > c->pool_cap) {
+    if (c->dead || bytes == 0 || c->pool_cap == 0) {  // pool_cap_mb = 0: nothing is cached
         (void)hipFree(p);
+        return;
+    }
+    if (bytes > c->pool_cap) {
+        // ONE block larger than the cap may stay cached: the factor of N > 110 000 points is 100+ GB and re-allocating it costs seconds per fit (N = 131 072: 17.2 s per
+        // pair with the block freed and allocated again against ≈ 12 s of work).  It takes the whole cache (everything else goes, a previous oversize block included);
+        // ctx_alloc drops the cache and retries when an allocation fails, and gp_ctx_trim returns it like any other block.
+        while (!c->pool.empty()) pool_drop(c, c->pool.size() - 1);
+        c->pool.push_back({p, bytes});
+        c->pool_bytes += bytes;
         return;
     }
     c->pool.push_back({p, bytes});
     c->pool_bytes += bytes;
-    // bound the cache by bytes and by count (a VFE fit alone cycles through ~16 buffers); oldest blocks go first
-    while (c->pool.size() > 1 && (c->pool_bytes > c->pool_cap || c->pool.size() > 48)) pool_drop(c, 0);
+    // bound the cache by bytes and by count (a VFE fit alone cycles through ~16 buffers); oldest blocks go first — an oversize block (above) is the last to go and
+    // keeps 4 GiB of room beside it for the small buffers of the calls that follow
+    size_t big = 0;
+    for (const auto& b : c->pool) big = std::max(big, b.bytes);
+    const size_t limit = big > c->pool_cap ? big + ((size_t)4 << 30) : c->pool_cap;
+    while (c->pool.size() > 1 && (c->pool_bytes > limit || c->pool.size() > 48)) pool_drop(c, (c->pool[0].bytes > c->pool_cap) ? 1 : 0);
 }
 void ctx_unref(gp_ctx* c) {
     if (--c->refs != 0) return;
@@ -1750,7 +1763,8 @@ int32_t gp_ctx_get_param(gp_ctx* c, const char* name, int64_t* out) {
         {"leaf_v2", c->leaf_v2}, {"leaf_xr", c->leaf_xr}, {"leaf_cols", c->leaf_cols}, {"updk_max_k", c->updk_max_k}, {"updk_rt", c->updk_rt},
         {"updk_tall_k", c->updk_tall_k}, {"updk_tall_m", c->updk_tall_m}, {"upd128", c->upd128}, {"leaf_group", c->leaf_group},
         {"ldpad", c->ldpad}, {"vfe_ks", c->vfe_ks}, {"vfe_sk", c->vfe_sk}, {"vfe_dual", c->vfe_dual}, {"vfe_inv_nb", c->vfe_inv_nb}, {"vfe_overlap", c->vfe_overlap}, {"vfe_chunk", c->vfe_chunk},
-        {"kmat_rows", g_kmat_rows.load()}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)}};
+        {"kmat_rows", g_kmat_rows.load()}, {"dib_nb", c->dib_nb}, {"pool_cap_mb", (int64_t)(c->pool_cap >> 20)},
+        {"pool_cached_mb", (int64_t)(c->pool_bytes >> 20)}, {"pool_blocks", (int64_t)c->pool.size()}};  // the last two are read-only
     for (const auto& e : tab)
         if (!strcmp(name, e.n)) {
             *out = e.v;

@@ -210,7 +210,11 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    loses its priority over the bulk update — the trade-off a multi-GPU run has to price (tools/scale_sweep.sh A/Bs it).   default 0
  *   "multi_debug_sync", "multi_inject_fault"  multi-device diagnostics: host synchronisation points of the rank threads (bit mask) /
  *                    hand the next fit's self-check a spoiled α once (tests/test_gpu_multi.py)      default 0, 0
- *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free       default 98304 */
+ *   "pool_cap_mb"    device bytes (MiB) the ctx keeps cached for reuse after *_free; ONE block larger than the cap may stay cached (the 137 GB factor
+ *                    of N = 131 072: 17.2 s per pair when it is returned to the driver and allocated again every fit, 11.0 s cached) — it takes the
+ *                    place of everything else in the cache and is the last block to go; 0 caches nothing; gp_ctx_trim empties the cache; an
+ *                    allocation that fails drops the cache and retries.   default 98304
+ *   "pool_cached_mb", "pool_blocks"   read-only (gp_ctx_get_param): MiB and number of blocks in the cache now */
 /* The defaults above, machine-readable (single-device parameters; gp_ctx_get_param reads the same names): the test-suite asserts before
  * every GPU test that the shared default context still has exactly these values, so that no test can leave a non-production setting
  * behind for the tests that follow it (tests/conftest.py). */

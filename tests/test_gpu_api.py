@@ -709,3 +709,46 @@ def test_input_containers_in_every_memory_order(agp):
                 np.testing.assert_allclose(cur[4], ref[4], rtol=1e-11, atol=1e-13)
     finally:
         ctx.close()
+
+
+def test_block_cache_policy(agp):
+    """The per-ctx cache of device blocks (`ctx_release` in csrc/gpmi355.hip; "pool_cap_mb", read back through the read-only "pool_cached_mb" /
+    "pool_blocks"): freed blocks are kept up to the cap and reused by the next fit; ONE block larger than the cap may stay cached (round 6: the
+    137 GB factor of N = 131 072 used to be returned to the driver and allocated again on every fit — 17.2 s per pair against 11.0 s with it
+    cached, profiles/r6/n131072_properties.json) and takes the place of everything else; "pool_cap_mb" = 0 caches nothing; `gp_ctx_trim`
+    empties the cache.  Results do not depend on any of it."""
+    n, d = 4096, 2
+    x, y = o.synth_inputs(n, d, 5)
+    ctx = agp.Context(0)
+    try:
+        f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
+
+        def fit_and_free():
+            post = agp.posterior(f(agp.RowVecs(x), 0.05), y)
+            out = (np.float64(post.logpdf_value), np.array(post.data.alpha))
+            post.data.C.free()
+            return out
+
+        base = fit_and_free()
+        assert ctx.get_param("pool_blocks") >= 1 and ctx.get_param("pool_cached_mb") >= n * n * 8 >> 20   # the factor's block is in the cache
+        ctx.trim()
+        assert ctx.get_param("pool_blocks") == 0 and ctx.get_param("pool_cached_mb") == 0
+        ctx.set_param("pool_cap_mb", 64)            # the 128 MiB factor is now above the cap
+        r1 = fit_and_free()
+        assert ctx.get_param("pool_blocks") >= 1 and ctx.get_param("pool_cached_mb") >= n * n * 8 >> 20   # … and stays, alone or with ≤ 4 GiB of small blocks
+        cached = ctx.get_param("pool_cached_mb")
+        r2 = fit_and_free()                          # takes the cached block and hands it back
+        assert ctx.get_param("pool_cached_mb") <= cached + 4096
+        small = agp.posterior(f(agp.RowVecs(x[:512]), 0.05), y[:512])
+        small.data.C.free()                          # small blocks ride beside the oversize one
+        assert ctx.get_param("pool_cached_mb") >= n * n * 8 >> 20
+        ctx.set_param("pool_cap_mb", 0)
+        ctx.trim()
+        r3 = fit_and_free()
+        assert ctx.get_param("pool_blocks") == 0 and ctx.get_param("pool_cached_mb") == 0
+        for r in (r1, r2, r3):
+            assert r[0] == pytest.approx(base[0], rel=1e-12) and np.allclose(r[1], base[1], rtol=1e-9, atol=1e-12)
+        with pytest.raises((ValueError, RuntimeError)):
+            ctx.set_param("pool_cached_mb", 1)       # read-only
+    finally:
+        ctx.close()
