@@ -82,6 +82,7 @@ PROTOTYPES = {
     "gp_vfe_get_factors": (i32, [vp, vp, vp]),
     "gp_vfe_n": (i64, [vp]),
     "gp_vfe_get_by": (i32, [vp, vp]),
+    "gp_vfe_grad": (i32, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), vp, vp, vp, i32, vp, i32]),
     "gp_vfe_free": (i32, [vp]),
     "gpd_assemble": (i32, [vp, PK, vp, i64, i64, i32, vp, PG, vp, i64, i64, i64]),
     "gpd_potrf": (i32, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),

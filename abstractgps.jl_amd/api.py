@@ -939,6 +939,56 @@ class ApproxPosteriorGP(AbstractGP):
         return m, c
 
 
+    def objective_grad(self, wrt_x: bool = False) -> dict:
+        """Gradient of the objective this posterior was fitted with (`self.objective`: elbo for VFE, approx_log_evidence for DTC —
+        src/sparse_approximations.jl:248-254, :282-286) at its own parameters, from the state resident on the device (gp_vfe_grad): what an AD backend
+        computes for examples/0-intro-1d/script.jl:385-394.  Keys as `logpdf_and_grad`: "variance", "scale" (None / float / vector), "noise" (the sum
+        Σ_i ∂/∂Σy_ii — the gradient for a scalar σ²) and "noise_diag" (the vector), "y", "mean" (= −"y"), "z" in the shape of the pseudo-input
+        container's array (fp64 posteriors only), and with wrt_x "x" in the shape of the observations' container (all observations seen so far, arrival order, as a
+        RowVecs-shaped (N, D) array when the posterior has been updated)."""
+        st = self._state
+        dt = self._dtype
+        n = int(st.ctx.lib.gp_vfe_n(st.handle))
+        zin = _as_input(self.approx.fz.x)
+        mm = _Marshal(dt)
+        pz = mm.points(self.approx.fz.x)
+        nscale = mm.kernel(self.prior.kernel, pz.d).nscale
+        dvar, dns = C.c_double(), C.c_double()
+        dscale = (C.c_double * max(nscale, 1))()
+        dnoise = np.empty(n, dtype=dt)
+        dy = np.empty(n, dtype=dt)
+        dz = None   # fp64 posteriors only: an fp32 fit's streamed B Bᵀ does not carry ∂/∂z (the C ABI refuses it, include/gpmi355.h)
+        if np.dtype(dt) == np.float64:
+            dz = np.empty((pz.n,) if pz.layout == 0 else ((pz.n, pz.d) if pz.layout == 1 else (pz.d, pz.n)), dtype=np.float64)
+        dxb = np.empty((n, pz.d), dtype=dt) if wrt_x else None          # layout 1: point-contiguous (N, D)
+        check(st.ctx.lib.gp_vfe_grad(st.handle, C.byref(dvar), dscale, C.byref(dns), dnoise.ctypes.data, dy.ctypes.data, None if dz is None else dz.ctypes.data, pz.layout,
+                                     None if dxb is None else dxb.ctypes.data, 1))
+        sc = None if nscale == 0 else (float(dscale[0]) if nscale == 1 else np.array([dscale[i] for i in range(nscale)]))
+        g = {"variance": dvar.value, "scale": sc, "noise": dns.value, "noise_diag": dnoise, "y": dy, "mean": -dy}
+        if dz is not None:
+            if pz.layout == 0:
+                g["z"] = dz
+            else:
+                nd = dz if pz.layout == 1 else dz.T
+                g["z"] = np.ascontiguousarray(nd.T if isinstance(zin, ColVecs) else nd)
+        if wrt_x:
+            g["x"] = dxb[:, 0] if pz.d == 1 and pz.layout == 0 else dxb
+        return g
+
+
+def elbo_and_grad(a, fx: FiniteGP, y, wrt_x: bool = False) -> tuple:
+    """(approx_log_evidence(a, fx, y), its gradient) in one fit + one backward pass on the device — the value / pullback pair an rrule of
+    `elbo(VFE(f(z, jitter)), f(x, Σy), y)` needs (the reference differentiates the same expression by AD: examples/0-intro-1d/script.jl:385-394).
+    "x" comes back in the shape of fx.x's array."""
+    if not isinstance(a, (VFE, DTC)):
+        raise TypeError("elbo_and_grad: VFE or DTC")
+    post = posterior(a, fx, y)
+    g = post.objective_grad(wrt_x)
+    if wrt_x and "x" in g and np.ndim(g["x"]) == 2 and isinstance(_as_input(fx.x), ColVecs):
+        g["x"] = np.ascontiguousarray(g["x"].T)
+    return post.objective, g
+
+
 def inducing_points(f: ApproxPosteriorGP):  # :219
     return f.approx.fz.x
 

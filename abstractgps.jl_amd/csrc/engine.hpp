@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <array>
 #include <atomic>
 #include <mutex>
 #include <set>

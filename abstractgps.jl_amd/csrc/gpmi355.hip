@@ -109,12 +109,12 @@ void ctx_release(gp_ctx* c, void* p, size_t /*requested*/) {
     }
     c->pool.push_back({p, bytes});
     c->pool_bytes += bytes;
-    // bound the cache by bytes and by count (a VFE fit alone cycles through ~16 buffers); oldest blocks go first — an oversize block (above) is the last to go and
+    // bound the cache by bytes and by count (a VFE fit cycles through ~16 buffers, its gradient pass through ~25 more); oldest blocks go first — an oversize block (above) is the last to go and
     // keeps 4 GiB of room beside it for the small buffers of the calls that follow
     size_t big = 0;
     for (const auto& b : c->pool) big = std::max(big, b.bytes);
     const size_t limit = big > c->pool_cap ? big + ((size_t)4 << 30) : c->pool_cap;
-    while (c->pool.size() > 1 && (c->pool_bytes > limit || c->pool.size() > 48)) pool_drop(c, (c->pool[0].bytes > c->pool_cap) ? 1 : 0);
+    while (c->pool.size() > 1 && (c->pool_bytes > limit || c->pool.size() > 96)) pool_drop(c, (c->pool[0].bytes > c->pool_cap) ? 1 : 0);
 }
 void ctx_unref(gp_ctx* c) {
     if (--c->refs != 0) return;
@@ -2367,6 +2367,20 @@ int32_t gp_vfe_get_by(gp_vfe* p, void* by_out) {
         off += es * (size_t)sg->n;
     }
     return 0;
+}
+
+int32_t gp_vfe_grad(gp_vfe* p, double* dvariance, double* dscale, double* dnoise_sum, void* dnoise_diag, void* dy, double* dz, int32_t z_layout,
+                    void* dx, int32_t x_layout) {
+    Guard gd(p);
+    if (!gd.ok) return set_arg_err(1, "not a live gp_vfe");
+    if (dz && p->dtype != 0)
+        return set_arg_err(7, "pseudo-input gradients need an fp64 handle: the fp32-streamed B Bᵀ of an fp32 fit does not carry the cancellation between the K_zz and K_fz terms");
+    if (dz && (z_layout < 0 || z_layout > 2 || (z_layout == 0 && p->d != 1))) return set_arg_err(8, "z_layout must be 0 (vector, D = 1), 1 (ColVecs) or 2 (RowVecs)");
+    if (dx && (x_layout < 0 || x_layout > 2 || (x_layout == 0 && p->d != 1))) return set_arg_err(10, "x_layout must be 0 (vector, D = 1), 1 (ColVecs) or 2 (RowVecs)");
+    gp_ctx* c = gd.c;
+    HIPCHK(hipSetDevice(c->device));
+    return p->dtype == 0 ? vfe_grad_impl<double>(p, dvariance, dscale, dnoise_sum, dnoise_diag, dy, dz, z_layout, dx, x_layout)
+                         : vfe_grad_impl<float>(p, dvariance, dscale, dnoise_sum, dnoise_diag, dy, dz, z_layout, dx, x_layout);
 }
 
 int64_t gp_vfe_m(gp_vfe* p) {

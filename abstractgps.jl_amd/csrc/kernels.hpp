@@ -950,6 +950,205 @@ __global__ __launch_bounds__(256) void noise_grad_kernel(const T* __restrict__ C
 }
 
 // ------------------------------------------------------------------------------------------------
+// vgrad: reverse-mode pass of the SPARSE objective (elbo / approx_log_evidence, src/sparse_approximations.jl:248-254, :282-286) over one
+//   rectangular kernel block K(rows, cols) — a chunk of observations against the pseudo-inputs, or K_zz itself.  Given the weights
+//   W_ij = ∂L/∂K_ij the kernel accumulates, in fp64 and with κ, dκ/dr² recomputed from the inputs (K is never read):
+//     g[0]       += Σ W_ij κ_ij                                         ∂/∂variance
+//     g[2 + p]   += Σ W_ij σ² dκ_ij ∂r²_ij/∂scale_p                     as kgrad_kernel
+//     gz[p][j]   += zfac · Σ_i W_ij σ² dκ_ij (−2 s_p)(u_ip − w_jp)      ∂/∂(column input j)   [ZG]
+//     gx[p][i]   +=        Σ_j W_ij σ² dκ_ij (+2 s_p)(u_ip − w_jp)      ∂/∂(row input i)      [XG]
+//   explicit_w = 1: W = Cm (the M×M weights of K_zz; the caller passes zfac = 2 for the row role of the symmetric pair).
+//   explicit_w = 0: Cm = −T̃ with T̃ = (S K)(∂L/∂ψ) from the chunk's MFMA GEMM (S = Σy^-1/2 rows), and
+//       W_ij = rs_i (2 T̃_ij + b_i ν_j)            (∂L/∂K_fz = Σy⁻¹ (2 K_fz G_ψ + δ νᵀ))
+//       rowq[i] += Σ_j σ²κ_ij T̃_ij,  rowp[i] += Σ_j σ²κ_ij ν_j     (the two row sums the noise / y gradients need)
+//   One 128×128 tile per workgroup, thread = 32 rows × 2 adjacent columns as in kgrad_kernel; NP = per-dimension accumulators kept in registers
+//   (4 for D <= 4, else 16 per launch chunk p0).  Row sums by wave shuffles, column sums through LDS across the 4 waves, then atomics.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void grad_stage_d2_rect(T (*xi)[128], T (*xj)[128], T (*xpi)[128], T (*xpj)[128], const T* __restrict__ xr, long ldxr,
+                                                   const T* __restrict__ xc, long ldxc, int d, int p0, int m0, int n0, T (&d2r)[32][2]) {
+    constexpr int DC = 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) d2r[rr][0] = d2r[rr][1] = T(0);
+    for (int dc = 0; dc < d; dc += DC) {
+        __syncthreads();
+        for (int e = tid; e < DC * 128; e += 256) {
+            const int dd = e >> 7, i = e & 127;
+            const bool in = dc + dd < d;
+            const T vi = in ? xr[(long)(dc + dd) * ldxr + m0 + i] : T(0), vj = in ? xc[(long)(dc + dd) * ldxc + n0 + i] : T(0);
+            xi[dd][i] = vi;
+            xj[dd][i] = vj;
+            if (dc == p0) {
+                xpi[dd][i] = vi;
+                xpj[dd][i] = vj;
+            }
+        }
+        __syncthreads();
+        const int dcnt = (d - dc < DC) ? (d - dc) : DC;
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+            const int row = w + 4 * rr;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int col = 2 * lane + cc;
+                T acc = d2r[rr][cc];
+                for (int dd = 0; dd < dcnt; ++dd) {
+                    const T t = xi[dd][row] - xj[dd][col];
+                    acc = fma(t, t, acc);
+                }
+                d2r[rr][cc] = acc;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, int NP, bool ZG, bool XG>
+__global__ __launch_bounds__(256) void vgrad_kernel(const T* __restrict__ Cm, long ldc, int explicit_w, const T* __restrict__ xr, long ldxr,
+                                                     const T* __restrict__ xc, long ldxc, int d, int kind, T variance, int nscale,
+                                                     const double* __restrict__ scale, const T* __restrict__ rs, const T* __restrict__ bv,
+                                                     const double* __restrict__ nu, long nr, long nc, double* __restrict__ g,
+                                                     double* __restrict__ gz, long ldgz, double zfac, double* __restrict__ rowq,
+                                                     double* __restrict__ rowp, double* __restrict__ gx, long ldgx, int p0) {
+    constexpr int DC = 16;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    __shared__ T xi[DC][128];
+    __shared__ T xj[DC][128];
+    __shared__ T xpi[DC][128];
+    __shared__ T xpj[DC][128];
+    __shared__ double red[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T d2r[32][2];
+    grad_stage_d2_rect<T>(xi, xj, xpi, xpj, xr, ldxr, xc, ldxc, d, p0, m0, n0, d2r);
+    const int npd = min(NP, d - p0);                          // input dimensions of this launch (z / x gradients)
+    const int nps = nscale > 1 ? min(NP, nscale - p0) : 0;    // ARD scales of this launch
+    const bool rows_out = !explicit_w && rowq && p0 == 0;
+    double acch[1 + NP];
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) acch[p] = 0.0;
+    double accz[2][NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) accz[0][p] = accz[1][p] = 0.0;
+    double nuj[2] = {0.0, 0.0};
+    if (!explicit_w) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) nuj[cc] = (n0 + 2 * lane + cc < nc) ? nu[n0 + 2 * lane + cc] : 0.0;
+    }
+    const double var = (double)variance;
+    for (int rr = 0; rr < 32; ++rr) {
+        const int row = w + 4 * rr;
+        const long gi = m0 + row;
+        if (gi >= nr) continue;  // wave-uniform
+        const double rsi = explicit_w ? 0.0 : (double)rs[gi], bi = explicit_w ? 0.0 : (double)bv[gi];
+        double accx[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) accx[p] = 0.0;
+        double aq = 0.0, ap = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int col = 2 * lane + cc;
+            const long gj = n0 + col;
+            if (gj >= nc) continue;
+            const T d2 = d2r[rr][cc];
+            T kap, dk;
+            kappa_and_dr2<T>(kind, d2, kap, dk);
+            const double cij = (double)Cm[gi * ldc + gj];
+            double W;
+            if (explicit_w) {
+                W = cij;
+            } else {
+                W = rsi * (-2.0 * cij + bi * nuj[cc]);
+                aq -= var * (double)kap * cij;
+                ap += var * (double)kap * nuj[cc];
+            }
+            if (p0 == 0) acch[0] += W * (double)kap;
+            const double wk = W * var * (double)dk * 2.0;
+            if (nscale == 1 && p0 == 0) acch[1] += wk * (double)d2;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (p < npd) {
+                    const double t = (double)(xpi[p][row] - xpj[p][col]);
+                    if (p < nps) acch[1 + p] += wk * t * t;
+                    if (ZG) accz[cc][p] -= wk * t;
+                    if (XG) accx[p] += wk * t;
+                }
+        }
+        if (rows_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                aq += __shfl_xor(aq, o, 64);
+                ap += __shfl_xor(ap, o, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(rowq + gi, aq);
+                atomicAdd(rowp + gi, ap);
+            }
+        }
+        if (XG) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (p >= npd) break;
+                double v = accx[p];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) {
+                    const double sp = nscale == 0 ? 1.0 : (nscale == 1 ? scale[0] : scale[p0 + p]);
+                    atomicAdd(gx + (long)(p0 + p) * ldgx + gi, sp * v);
+                }
+            }
+        }
+    }
+    // hyper-parameter sums: waves -> LDS -> one atomic per workgroup and parameter
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) {
+        double v = acch[p];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[w][p] = v;
+    }
+    __syncthreads();
+    {
+        const int nout = nscale == 1 ? (p0 == 0 ? 1 : 0) : nps;
+        if (tid <= nout) {
+            const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            if (tid == 0) {
+                if (p0 == 0) atomicAdd(g, v);
+            } else {
+                atomicAdd(g + 2 + p0 + tid - 1, v / scale[p0 + tid - 1]);
+            }
+        }
+    }
+    if (ZG) {
+        for (int p = 0; p < npd; ++p) {
+            __syncthreads();
+            red[w][2 * lane] = accz[0][p];
+            red[w][2 * lane + 1] = accz[1][p];
+            __syncthreads();
+            if (tid < 128 && n0 + tid < nc) {
+                const double sp = nscale == 0 ? 1.0 : (nscale == 1 ? scale[0] : scale[p0 + p]);
+                atomicAdd(gz + (long)(p0 + p) * ldgz + n0 + tid, zfac * sp * (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+            }
+        }
+    }
+}
+
+// out[i][j] = sa·a[hi][lo] + sb·b[hi][lo] + dg·[i == j] + so·v_i v_j   (hi = max(i, j), lo = min(i, j); a, b lower-stored; b, v may be NULL): the symmetric
+// M×M combinations of the sparse gradient (I − A⁻¹ − B Bᵀ from two lower triangles; ½ E − ½ ααᵀ).  grid (ceil(n/256), n)
+__global__ __launch_bounds__(256) void sym_combine_kernel(double* __restrict__ out, long ldo, long n, const double* __restrict__ a, long lda, double sa,
+                                                          const double* __restrict__ b, long ldb, double sb, double dg,
+                                                          const double* __restrict__ v, double so) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    const long hi = i > j ? i : j, lo = i > j ? j : i;
+    double r = sa * a[hi * lda + lo];
+    if (b) r += sb * b[hi * ldb + lo];
+    if (i == j) r += dg;
+    if (v) r += so * v[i] * v[j];
+    out[i * ldo + j] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // panel64: ONE launch per 64-column leaf of the panel factorisation — Cholesky of the 64×64 diagonal tile AND
 //   X ← X L⁻ᵀ for every row below it (one launch instead of a tile factorisation + a triangular solve and their dependent-launch gap).
 //   info (device int32): first failing global column (1-based) if a pivot is not > 0 (LAPACK dpotrf info), untouched otherwise;

@@ -75,6 +75,31 @@ static void vfe_release(gp_vfe* p) {  // under the ctx lock
     p->segs.clear();
 }
 
+// Iw ((mp + 256) × ld doubles, L_b bytes) ← L⁻ᵀ (upper, row-major) of the lower factor L: I · L⁻ᵀ by the restricted-row recursion.  "vfe_inv_nb" >= 128: the inverse
+// diagonal blocks of L all at once (dib_build: every launch of the restricted-row recursion carries the batch; L_bb⁻ᵀ lands on Iw's diagonal), then the levels
+// above them with ONE triangular-k GEMM per block — the mechanism of the gradient's L⁻ᵀ (grad_impl).  Used by the fit's prelude (inv(L_z)) and by vfe_grad_impl.
+static int32_t vfe_upper_inverse(gp_ctx* c, hipStream_t s, const double* L, long ld, long mp, double* Iw, size_t L_b, DevBufs& bufs) {
+    HIPCHK(hipMemsetAsync(Iw, 0, L_b, s));
+    hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
+    HIPCHK(hipGetLastError());
+    const long inb = c->vfe_inv_nb;
+    if (inb >= 128 && mp >= 2 * inb) {
+        const long ldw = inb + c->ldpad;
+        const size_t wb = sizeof(double) * (size_t)(mp + 128) * ldw;
+        void *Wn_v = 0, *Iw2_v = 0, *Sw_v = 0;
+        RC(bufs.get(wb, &Wn_v));
+        RC(bufs.get(wb, &Iw2_v));
+        RC(bufs.get(wb, &Sw_v));
+        RC(dib_build<double>(c, s, L, ld, mp, inb, (double*)Wn_v, ldw, (double*)Iw2_v, Iw, ld));
+        DibArgs<double> dib;
+        dib.W = (const double*)Wn_v; dib.ldw = ldw; dib.nbi = inb; dib.S = (double*)Sw_v; dib.lds = ldw;
+        RC(trsm_upper_rec<double>(c, s, Iw, ld, L, ld, 0, mp, dib));
+    } else {
+        RC(trsm_upper_rec<double>(c, s, Iw, ld, L, ld, 0, mp));
+    }
+    return 0;
+}
+
 enum { VFE_FIT = 0, VFE_UPDATE = 1, VFE_APPEND = 2 };
 
 // mode VFE_FIT:    x, y, noise, z, jitter given; prev == NULL
@@ -405,26 +430,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
             }
             // ---- inv(L_z): W = I · L_z⁻ᵀ (upper), transposed into Ld's storage (free until the SYRK is done), rounded to T
             double* Iw = (double*)I_v;
-            HIPCHK(hipMemsetAsync(I_v, 0, L_b, s));
-            hipLaunchKernelGGL(identity_kernel<double>, dim3((unsigned)((mp + 255) / 256), (unsigned)mp), dim3(256), 0, s, Iw, ld, mp);
-            HIPCHK(hipGetLastError());
-            const long inb = c->vfe_inv_nb;
-            if (inb >= 128 && mp >= 2 * inb) {
-                // the inverse diagonal blocks of L_z, all at once (dib_build: every launch of the restricted-row recursion carries the batch; L_bb⁻ᵀ lands on Iw's
-                // diagonal), then the levels above them with ONE triangular-k GEMM per block — the mechanism of the gradient's L⁻ᵀ (grad_impl)
-                const long ldw = inb + c->ldpad;
-                const size_t wb = sizeof(double) * (size_t)(mp + 128) * ldw;
-                void *Wn_v = 0, *Iw2_v = 0, *Sw_v = 0;
-                RC(bufs.get(wb, &Wn_v));
-                RC(bufs.get(wb, &Iw2_v));
-                RC(bufs.get(wb, &Sw_v));
-                RC(dib_build<double>(c, s, Lz, ld, mp, inb, (double*)Wn_v, ldw, (double*)Iw2_v, Iw, ld));
-                DibArgs<double> dib;
-                dib.W = (const double*)Wn_v; dib.ldw = ldw; dib.nbi = inb; dib.S = (double*)Sw_v; dib.lds = ldw;
-                RC(trsm_upper_rec<double>(c, s, Iw, ld, Lz, ld, 0, mp, dib));
-            } else {
-                RC(trsm_upper_rec<double>(c, s, Iw, ld, Lz, ld, 0, mp));
-            }
+            RC(vfe_upper_inverse(c, s, Lz, ld, mp, Iw, L_b, bufs));
             hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, s, Iw, ld, Ld, ld, mp);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemsetAsync(Li_v, 0, Li_b, s));
@@ -706,5 +712,322 @@ static int32_t vfe_predict_impl(gp_vfe* p, const gp_points* xs, const void* pm, 
         for (long i = 0; i < ns; ++i) ((T*)mean_out)[i] = (T)((prior ? (double)prior[i] : 0.0) + oh[i]);
     if (what & 2)
         for (long i = 0; i < ns; ++i) ((T*)var_out)[i] = (T)(p->variance - oh[nsp + i] + oh[2 * nsp + i]);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient of the sparse objective of a fitted handle (gp_vfe_grad): elbo (VFE, src/sparse_approximations.jl:248-254) or approx_log_evidence (DTC, :282-286)
+// against the kernel variance, the Scale / ARD parameters, the noise variances, y, the pseudo-inputs z and (optionally) the inputs x — what an AD backend
+// computes when examples/0-intro-1d/script.jl:385-394 maximises the ELBO over kernel parameters and pseudo-points.
+//   With ψ = K_zf Σy⁻¹ K_fz, φ = K_zf Σy⁻¹ δ, Q = K_zz + ψ = L_z A L_zᵀ (A = I + B Bᵀ = Λ_ε) and ν = Q⁻¹φ = α (the posterior's own α):
+//     L = −½ [N log 2π + log|Q| − log|K_zz| + log|Σy| + δᵀΣy⁻¹δ − φᵀQ⁻¹φ] − ½ [tr(Σy⁻¹K_ff) − tr(K_zz⁻¹ψ)]         (second bracket: VFE only)
+//     G_ψ  = ∂L/∂ψ    = ½ [W H_ψ Wᵀ − ααᵀ],   H_ψ  = I − A⁻¹ (VFE) | −A⁻¹ (DTC),            W = L_z⁻ᵀ
+//     G_zz = ∂L/∂K_zz = ½ [W H_zz Wᵀ − ααᵀ],  H_zz = I − A⁻¹ − B Bᵀ (VFE) | I − A⁻¹ (DTC)
+//     ∂L/∂K_fz = Σy⁻¹ (2 K_fz G_ψ + δ αᵀ),   ∂L/∂k_ii = −½/σ_i² (VFE)
+//     ∂L/∂σ_i² = −½/σ_i² + ½ δ_i²/σ_i⁴ [+ ½ k_ii/σ_i⁴ VFE] − (k_iᵀ G_ψ k_i)/σ_i⁴ − (αᵀk_i) δ_i/σ_i⁴,     ∂L/∂y_i = −(δ_i − αᵀk_i)/σ_i²
+//   The M×M side is fp64 (two triangular inverses, A⁻¹, two conjugations: ≈ 10 M³ flops); the N-long side streams the retained observations once more in the
+//   fit's chunks: kmat (S K_c) → ONE MFMA GEMM T̃ = (S K_c) G_ψ (2·CH·M² flops) → vgrad_kernel (κ, dκ recomputed; every reduction fp64).  The pass is fp64 for
+//   fp32 handles too (their retained inputs are widened chunk by chunk): G_ψ carries K_zz⁻¹ (entries up to 1/jitter) against which S K_c cancels to O(1) —
+//   rounded to fp32 it cost 6–8 % of the variance / pseudo-input gradients at N = 3 000 already (measured, round 6), at the fp32 MFMA rate that is not a trade.
+//   (oracle: gp_oracle.elbo_grad — dense N×N calculus on the textbook form; tests/test_gpu_vfe_grad.py)
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool XG>
+static int32_t launch_vgrad(hipStream_t s, dim3 grid, const T* Cm, long ldc, int explicit_w, const T* xr, long ldxr, const T* xc, long ldxc, int d, int kind,
+                            double variance, int nscale, const double* scale, const T* rs, const T* bv, const double* nu, long nr, long nc, double* g,
+                            double* gz, long ldgz, double zfac, double* rowq, double* rowp, double* gx, long ldgx) {
+    if (d <= 4) {
+        hipLaunchKernelGGL((vgrad_kernel<T, 4, true, XG>), grid, dim3(256), 0, s, Cm, ldc, explicit_w, xr, ldxr, xc, ldxc, d, kind, (T)variance, nscale, scale,
+                           rs, bv, nu, nr, nc, g, gz, ldgz, zfac, rowq, rowp, gx, ldgx, 0);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    for (int p0 = 0; p0 < d; p0 += 16) {
+        hipLaunchKernelGGL((vgrad_kernel<T, 16, true, XG>), grid, dim3(256), 0, s, Cm, ldc, explicit_w, xr, ldxr, xc, ldxc, d, kind, (T)variance, nscale, scale,
+                           rs, bv, nu, nr, nc, g, gz, ldgz, zfac, rowq, rowp, gx, ldgx, p0);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+template <typename T>
+static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dnoise_sum, void* dnoise, void* dy, double* dz, int z_layout, void* dx,
+                             int x_layout) {
+    gp_ctx* c = p->ctx;
+    const long m = p->m, mp = p->mp, ld = p->ld, CH = c->vfe_chunk;
+    const int d = p->d;
+    const bool vfe = p->approx == 0;
+    constexpr bool is_f64 = sizeof(T) == 8;
+    for (auto& sg : p->segs)
+        if (sg->npad % CH) return set_arg_err(1, "gp_vfe was built with a different vfe_chunk");
+    hipStream_t s = c->sm;
+    c->ev_used = 0;
+    c->gemm_recs.clear();
+    for (auto& e : c->ev_phase)
+        if (!e) HIPCHK(hipEventCreate(&e));
+    const int nsc = std::max(p->nscale, 1);
+    const size_t L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
+    const size_t X_b = sizeof(double) * (size_t)(CH + 128) * ld, g_b = sizeof(double) * (size_t)(2 + nsc), gz_b = sizeof(double) * (size_t)d * mp;
+    void *W_v = 0, *V_v = 0, *H_v = 0, *R_v = 0, *E_v = 0, *Gp_v = 0, *Gz_v = 0, *X_v = 0, *X2_v = 0, *C2_v = 0, *xc_v = 0, *rc_v = 0, *bc_v = 0, *C_v = 0, *g_v = 0, *gz_v = 0, *sc_v = 0;
+    DevBufs bufs(c);
+    RC(bufs.get(L_b, &W_v));
+    RC(bufs.get(L_b, &V_v));
+    RC(bufs.get(L_b, &H_v));
+    RC(bufs.get(L_b, &R_v));
+    RC(bufs.get(L_b, &E_v));
+    RC(bufs.get(L_b, &Gp_v));
+    RC(bufs.get(L_b, &Gz_v));
+    RC(bufs.get(X_b, &X_v));
+    if (!is_f64) {  // the chunk's inputs, Σy^-1/2 and b_y widened to fp64
+        RC(bufs.get(sizeof(double) * (size_t)d * CH * 2, &xc_v));
+        RC(bufs.get(sizeof(double) * (size_t)CH * 2, &rc_v));
+        RC(bufs.get(sizeof(double) * (size_t)CH * 2, &bc_v));
+    }
+    RC(bufs.get(X_b, &C_v));
+    RC(bufs.get(X_b, &X2_v));  // double buffers in either mode ("vfe_overlap" = 0 issues the same sequence to one stream)
+    RC(bufs.get(X_b, &C2_v));
+    RC(bufs.get(g_b, &g_v));
+    RC(bufs.get(gz_b, &gz_v));
+    RC(bufs.get(sizeof(double) * (size_t)nsc, &sc_v));
+    double *W = (double*)W_v, *V = (double*)V_v, *H = (double*)H_v, *R = (double*)R_v, *E = (double*)E_v, *Gp = (double*)Gp_v, *Gz = (double*)Gz_v;
+    const double* Lz = (const double*)p->Lz;
+    const double* Ld = (const double*)p->Ld;
+    const double* alpha = (const double*)p->vec + 2 * mp;
+    std::vector<double> sc_h((size_t)nsc, 1.0);
+    for (int q = 0; q < p->nscale; ++q) sc_h[q] = p->scale[q];
+    std::vector<double> g_h((size_t)(2 + nsc), 0.0), gz_h((size_t)d * mp, 0.0);
+    // per observation (concatenated over the segments, arrival order): what the host needs to finish ∂/∂σ_i², ∂/∂y_i, ∂/∂x_i
+    long n_all = 0;
+    for (auto& sg : p->segs) n_all += sg->n;
+    std::vector<double> dn_h((size_t)n_all), dy_h((size_t)n_all), gx_all(dx ? (size_t)n_all * d : 0);
+    double sum_rs2 = 0;
+    const dim3 sq((unsigned)((mp + 255) / 256), (unsigned)mp);
+    auto conj = [&](const double* Hm, double* G) -> int32_t {  // G (full, symmetric) = ½ W Hm Wᵀ − ½ ααᵀ
+        GridMap gr = plain_map(0, 0, 0);
+        gr.beta0 = 1;
+        gr.ktri = 2;                                                                           // W upper: k starts at the row tile
+        RC(launch_gemm<double>(c, s, R, ld, W, ld, Hm, ld, mp, mp, mp, gr));                   // R = −W Hm        (Hm symmetric)
+        GridMap ge = plain_map(1, 0, 0);
+        ge.beta0 = 1;
+        RC(launch_gemm<double>(c, s, E, ld, R, ld, W, ld, mp, mp, mp, ge));                    // E = −R Wᵀ = W Hm Wᵀ (lower)
+        hipLaunchKernelGGL(sym_combine_kernel, sq, dim3(256), 0, s, G, ld, mp, (const double*)E, ld, 0.5, (const double*)nullptr, 0L, 0.0, 0.0, alpha, -0.5);
+        HIPCHK(hipGetLastError());
+        return 0;
+    };
+    int32_t rc = [&]() -> int32_t {
+        HIPCHK(hipEventRecord(c->ev_phase[0], s));
+        HIPCHK(hipMemcpyAsync(sc_v, sc_h.data(), sizeof(double) * (size_t)nsc, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(g_v, 0, g_b, s));
+        HIPCHK(hipMemsetAsync(gz_v, 0, gz_b, s));
+        for (void* q : {H_v, R_v, E_v, Gp_v, Gz_v}) HIPCHK(hipMemsetAsync(q, 0, L_b, s));   // the GEMMs over-read whole operand tiles: defined slack rows
+        HIPCHK(hipMemsetAsync(C_v, 0, X_b, s));
+        if (C2_v) HIPCHK(hipMemsetAsync(C2_v, 0, X_b, s));
+        HIPCHK(hipMemsetAsync(X_v, 0, X_b, s));
+        if (X2_v) HIPCHK(hipMemsetAsync(X2_v, 0, X_b, s));
+        // ---- M×M side, fp64
+        RC(vfe_upper_inverse(c, s, Lz, ld, mp, W, L_b, bufs));                                  // W = L_z⁻ᵀ
+        RC(vfe_upper_inverse(c, s, Ld, ld, mp, V, L_b, bufs));                                  // V = Λ_ε.L⁻ᵀ
+        {
+            GridMap gw = plain_map(1, 0, 0);
+            gw.ktri = 2;
+            gw.beta0 = 1;
+            RC(launch_gemm<double>(c, s, E, ld, V, ld, V, ld, mp, mp, mp, gw));                 // E = −V Vᵀ = −A⁻¹ (lower)
+        }
+        // H_ψ, then H_zz (padding rows: A⁻¹ = I and B Bᵀ = 0 there, so the VFE forms vanish on the padding; the DTC H_ψ keeps −1 on the padded diagonal,
+        // which only reaches padded columns of T̃ and padded entries of G — never read)
+        hipLaunchKernelGGL(sym_combine_kernel, sq, dim3(256), 0, s, H, ld, mp, (const double*)E, ld, 1.0, (const double*)nullptr, 0L, 0.0, vfe ? 1.0 : 0.0,
+                           (const double*)nullptr, 0.0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(V, E, L_b, hipMemcpyDeviceToDevice, s));                          // −A⁻¹ (lower) survives the first conjugation in V's storage
+        RC(conj(H, Gp));
+        hipLaunchKernelGGL(sym_combine_kernel, sq, dim3(256), 0, s, H, ld, mp, (const double*)V, ld, 1.0, vfe ? (const double*)p->Dacc : (const double*)nullptr, ld,
+                           1.0, 1.0, (const double*)nullptr, 0.0);                              // Dacc = −B Bᵀ (lower)
+        HIPCHK(hipGetLastError());
+        RC(conj(H, Gz));
+        HIPCHK(hipEventRecord(c->ev_phase[1], s));
+        // ---- the observations, chunk by chunk: the MFMA GEMMs back to back on one stream; the next chunk's kmat (and, for fp32 handles, the widening of its
+        //      inputs) and the previous chunk's vgrad on another beside them, on double buffers ("vfe_overlap")
+        struct Ck {
+            const ObsSeg* sg;
+            long c0;
+            double *rq, *rp, *gx;
+        };
+        std::vector<Ck> cks;
+        std::vector<std::array<void*, 3>> segb;
+        for (auto& sgp : p->segs) {
+            const ObsSeg& sg = *sgp;
+            void *rq_v = 0, *rp_v = 0, *gx_v = 0;
+            const size_t r_b = sizeof(double) * (size_t)std::max(sg.npad, 1L);
+            RC(bufs.get(r_b, &rq_v));
+            RC(bufs.get(r_b, &rp_v));
+            if (dx) RC(bufs.get(r_b * d, &gx_v));
+            HIPCHK(hipMemsetAsync(rq_v, 0, r_b, s));
+            HIPCHK(hipMemsetAsync(rp_v, 0, r_b, s));
+            if (dx) HIPCHK(hipMemsetAsync(gx_v, 0, r_b * d, s));
+            segb.push_back({rq_v, rp_v, gx_v});
+            for (long c0 = 0; c0 < sg.npad && c0 < sg.n; c0 += CH) cks.push_back({&sg, c0, (double*)rq_v + c0, (double*)rp_v + c0, dx ? (double*)gx_v + c0 : nullptr});
+        }
+        // roles: the GEMMs go to the ctx's HIGH-priority stream, the helpers stay on the main (normal-priority) one — the other way round (helpers on the
+        // high-priority stream, as in the fit, whose helpers are light) the fp64 vgrad launches take CUs from the GEMM: 146.8 ms against 142.5 serial at C5
+        const bool ovl = c->vfe_overlap != 0;
+        hipStream_t sa = s, sg = ovl ? c->sp : s;
+        void* Xb[2] = {X_v, X2_v};
+        void* Cb[2] = {C_v, C2_v};
+        hipEvent_t evK[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}, evV[2] = {nullptr, nullptr};
+        struct In {
+            const double *xr, *rs, *b;
+            long ldxr, nr;
+        } in[2];
+        if (ovl) {  // the GEMM stream starts after the M×M side (G_ψ) and the zeroing above
+            hipEvent_t e;
+            RC(ctx_event(c, &e, false));
+            HIPCHK(hipEventRecord(e, s));
+            HIPCHK(hipStreamWaitEvent(sg, e, 0));
+        }
+        auto prep = [&](size_t ci) -> int32_t {  // S K(x_c, z) of chunk ci into X[ci & 1], on the helper stream
+            const int bb = (int)(ci & 1);
+            const ObsSeg& sg = *cks[ci].sg;
+            const long c0 = cks[ci].c0;
+            if (ovl && evG[bb]) HIPCHK(hipStreamWaitEvent(sa, evG[bb], 0));  // the GEMM of chunk ci − 2 has read X[bb]
+            In& I = in[bb];
+            I.nr = std::min(CH, sg.n - c0);
+            if constexpr (is_f64) {
+                I.xr = (const double*)sg.xs + c0; I.ldxr = sg.npad; I.rs = (const double*)sg.rs + c0; I.b = (const double*)sg.b + c0;
+            } else {
+                double* xc = (double*)xc_v + (size_t)bb * d * CH;
+                double* rc2 = (double*)rc_v + (size_t)bb * CH;
+                double* bc2 = (double*)bc_v + (size_t)bb * CH;
+                for (int q = 0; q < d; ++q) {
+                    hipLaunchKernelGGL((convert_kernel<T, double>), convert_grid(CH), dim3(256), 0, sa, (const T*)sg.xs + (long)q * sg.npad + c0, xc + (long)q * CH, CH, 1.0);
+                    HIPCHK(hipGetLastError());
+                }
+                hipLaunchKernelGGL((convert_kernel<T, double>), convert_grid(CH), dim3(256), 0, sa, (const T*)sg.rs + c0, rc2, CH, 1.0);
+                HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL((convert_kernel<T, double>), convert_grid(CH), dim3(256), 0, sa, (const T*)sg.b + c0, bc2, CH, 1.0);
+                HIPCHK(hipGetLastError());
+                I.xr = xc; I.ldxr = CH; I.rs = rc2; I.b = bc2;
+            }
+            GridMap g = plain_map(0, 0, 0);
+            dim3 grid((unsigned)(mp / 128), (unsigned)(CH / 128));
+            launch_kmat<double>(grid, sa, (double*)Xb[bb], ld, I.xr, I.ldxr, (const double*)p->zs, mp, d, p->kind, p->variance, (const double*)nullptr, I.nr, m, 0, g,
+                                (const double*)nullptr, I.rs);
+            HIPCHK(hipGetLastError());
+            if (ovl) {
+                RC(ctx_event(c, &evK[bb], false));
+                HIPCHK(hipEventRecord(evK[bb], sa));
+            }
+            return 0;
+        };
+        if (!cks.empty()) RC(prep(0));
+        for (size_t ci = 0; ci < cks.size(); ++ci) {
+            const int bb = (int)(ci & 1);
+            if (ovl) {
+                HIPCHK(hipStreamWaitEvent(sg, evK[bb], 0));
+                if (evV[bb]) HIPCHK(hipStreamWaitEvent(sg, evV[bb], 0));  // vgrad of chunk ci − 2 has read C[bb]
+            }
+            {
+                GridMap g = plain_map(0, 0, 0);
+                g.beta0 = 1;
+                RC(launch_gemm<double>(c, sg, (double*)Cb[bb], ld, (const double*)Xb[bb], ld, (const double*)Gp, ld, CH, mp, mp, g));   // C = −(S K_c) G_ψ
+            }
+            if (ovl) {
+                RC(ctx_event(c, &evG[bb], false));
+                HIPCHK(hipEventRecord(evG[bb], sg));
+            }
+            const In I = in[bb];
+            if (ci + 1 < cks.size()) RC(prep(ci + 1));  // beside this chunk's GEMM
+            if (ovl) HIPCHK(hipStreamWaitEvent(sa, evG[bb], 0));
+            dim3 grid((unsigned)(mp / 128), (unsigned)((I.nr + 127) / 128));
+            if (dx)
+                RC((launch_vgrad<double, true>(sa, grid, (const double*)Cb[bb], ld, 0, I.xr, I.ldxr, (const double*)p->zs, mp, d, p->kind, p->variance, p->nscale,
+                                               (const double*)sc_v, I.rs, I.b, alpha, I.nr, m, (double*)g_v, (double*)gz_v, mp, 1.0, cks[ci].rq, cks[ci].rp,
+                                               cks[ci].gx, cks[ci].sg->npad)));
+            else
+                RC((launch_vgrad<double, false>(sa, grid, (const double*)Cb[bb], ld, 0, I.xr, I.ldxr, (const double*)p->zs, mp, d, p->kind, p->variance, p->nscale,
+                                                (const double*)sc_v, I.rs, I.b, alpha, I.nr, m, (double*)g_v, (double*)gz_v, mp, 1.0, cks[ci].rq, cks[ci].rp,
+                                                (double*)nullptr, 0L)));
+            if (ovl) {
+                RC(ctx_event(c, &evV[bb], false));
+                HIPCHK(hipEventRecord(evV[bb], sa));
+            }
+        }
+        // (every GEMM is followed by its vgrad on the main stream, which waited for it: nothing to join)
+        long off = 0;
+        for (size_t si = 0; si < p->segs.size(); ++si) {
+            const ObsSeg& sg = *p->segs[si];
+            if (sg.n == 0) continue;
+            const size_t r_b = sizeof(double) * (size_t)sg.npad;
+            std::vector<double> rq_h((size_t)sg.n), rp_h((size_t)sg.n), gx_h(dx ? (size_t)sg.npad * d : 0);
+            std::vector<T> rs_h((size_t)sg.n), b_h((size_t)sg.n);
+            HIPCHK(hipMemcpyAsync(rq_h.data(), segb[si][0], sizeof(double) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(rp_h.data(), segb[si][1], sizeof(double) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(rs_h.data(), sg.rs, sizeof(T) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(b_h.data(), sg.b, sizeof(T) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
+            if (dx) HIPCHK(hipMemcpyAsync(gx_h.data(), segb[si][2], r_b * d, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (long i = 0; i < sg.n; ++i) {
+                const double r = (double)rs_h[i], b = (double)b_h[i], r2 = r * r, r3 = r2 * r;
+                sum_rs2 += r2;
+                dn_h[off + i] = -0.5 * r2 + 0.5 * b * b * r2 - rq_h[i] * r3 - rp_h[i] * b * r3 + (vfe ? 0.5 * p->variance * r2 * r2 : 0.0);
+                dy_h[off + i] = -(b * r - rp_h[i] * r2);
+                if (dx)
+                    for (int q = 0; q < d; ++q) gx_all[(size_t)q * n_all + off + i] = gx_h[(size_t)q * sg.npad + i];
+            }
+            off += sg.n;
+        }
+        HIPCHK(hipEventRecord(c->ev_phase[2], s));
+        // ---- K_zz: explicit weights G_zz over the full square; z_j enters through both arguments (factor 2 on the column role)
+        {
+            dim3 grid((unsigned)(mp / 128), (unsigned)((m + 127) / 128));
+            RC((launch_vgrad<double, false>(s, grid, (const double*)Gz, ld, 1, (const double*)p->zs, mp, (const double*)p->zs, mp, d, p->kind, p->variance, p->nscale,
+                                            (const double*)sc_v, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, m, m, (double*)g_v,
+                                            (double*)gz_v, mp, 2.0, (double*)nullptr, (double*)nullptr, (double*)nullptr, 0L)));
+        }
+        HIPCHK(hipMemcpyAsync(g_h.data(), g_v, g_b, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(gz_h.data(), gz_v, gz_b, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(c->ev_phase[3], s));
+        HIPCHK(hipStreamSynchronize(s));
+        float ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[1]));
+        c->tm.assemble_ms = ms;  // the M×M side
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[1], c->ev_phase[2]));
+        c->tm.potrf_ms = ms;     // the streamed pass
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[2], c->ev_phase[3]));
+        c->tm.solve_ms = ms;     // the K_zz term
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_phase[0], c->ev_phase[3]));
+        c->tm.total_ms = ms;
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(c->sm);
+        return rc;
+    }
+    if (dvar) *dvar = g_h[0] - (vfe ? 0.5 * sum_rs2 : 0.0);
+    if (dscale)
+        for (int q = 0; q < p->nscale; ++q) dscale[q] = g_h[2 + q];
+    if (dnoise_sum) {
+        double sm = 0;
+        for (long i = 0; i < n_all; ++i) sm += dn_h[i];
+        *dnoise_sum = sm;
+    }
+    if (dnoise)
+        for (long i = 0; i < n_all; ++i) ((T*)dnoise)[i] = (T)dn_h[i];
+    if (dy)
+        for (long i = 0; i < n_all; ++i) ((T*)dy)[i] = (T)dy_h[i];
+    if (dz)  // the container layout of the pseudo-inputs (src/finite_gp_projection.jl:32-37): 0 vector, 1 ColVecs (D×M column-major), 2 RowVecs (M×D column-major)
+        for (int q = 0; q < d; ++q)
+            for (long j = 0; j < m; ++j) {
+                const double v = gz_h[(size_t)q * mp + j];
+                if (z_layout == 0) dz[j] = v;
+                else if (z_layout == 1) dz[(long)q + j * d] = v;
+                else dz[j + (long)q * m] = v;
+            }
+    if (dx)
+        for (int q = 0; q < d; ++q)
+            for (long i = 0; i < n_all; ++i) {
+                const T v = (T)gx_all[(size_t)q * n_all + i];
+                if (x_layout == 0) ((T*)dx)[i] = v;
+                else if (x_layout == 1) ((T*)dx)[(long)q + i * d] = v;
+                else ((T*)dx)[i + (long)q * n_all] = v;
+            }
     return 0;
 }

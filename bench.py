@@ -6,8 +6,9 @@
 
 A "step" is one (logpdf, posterior-fit) pair on BASELINE config C4: GP(SqExponentialKernel()) on
 65 536 3-D points, σ² = 0.01, fp64 — one Gram assembly, one Cholesky, logdet, the
-forward/backward solves, logpdf scalar and α back on the host.  Inputs are synthetic (PCG64 seed 4) and
-are uploaded before the timed region (x, y are 2 MB; the N×N matrix never leaves HBM).
+forward/backward solves, logpdf scalar and α back on the host.  Inputs are synthetic (PCG64 seed 4); the
+C ABI takes HOST x, y, so every timed step uploads them (2 MB) and downloads α (0.5 MB) inside the timed region: `value` is
+already the PCIe-inclusive rate (≈ 0.1 ms of 1 370); the N×N matrix is assembled in HBM and never leaves it.
 N > 1: the N×N matrix is partitioned 2D block-cyclically over the N devices INSIDE the library (gp_ctx_create_multi,
 csrc/multi.hip: one internal host thread per device, RCCL grouped send/recv or peer copies over xGMI) — the caller is one
 process, as the reference's caller is (one Julia process calling posterior(fx, y)).  `python bench.py --gpus N` therefore uses

@@ -354,6 +354,20 @@ int32_t gp_vfe_get_factors(gp_vfe* post, void* U_out_or_null, void* Lambda_U_out
 int64_t gp_vfe_n(gp_vfe* post); /* observations seen so far (fit + every update_posterior) */
 /* b_y = U_y⁻ᵀ (y − m) of every observation seen so far, length gp_vfe_n(post) (cache field b_y, :66, :102), posterior's dtype. */
 int32_t gp_vfe_get_by(gp_vfe* post, void* b_y_out);
+/* Gradient of the objective the handle was fitted with — elbo for VFE (src/sparse_approximations.jl:248-254), approx_log_evidence for DTC (:282-286) — at the
+ * handle's own parameters, after any number of gp_vfe_update / gp_vfe_append calls (the observations are retained on the device; B_εf is never stored: they are
+ * streamed once more, one MFMA GEMM per chunk).  The reference has no hand-written adjoint: this is what an AD backend computes when
+ * examples/0-intro-1d/script.jl:385-394 maximises the ELBO over kernel parameters and pseudo-points.  Every output may be NULL.
+ *   dvariance      ∂/∂σ_k² (the ScaledKernel factor)             dscale [nscale]  ∂/∂s (ScaleTransform) or ∂/∂v_p (ARDTransform)
+ *   dnoise_sum     Σ_i ∂/∂Σy_ii (the gradient for a scalar σ²)   dnoise_diag [n]  ∂/∂Σy_ii, the handle's dtype, n = gp_vfe_n(post), arrival order
+ *   dy [n]         ∂/∂y_i (= −∂/∂m_i of the prior mean), the handle's dtype
+ *   dz [m·d]       ∂/∂z in the container layout z_layout (0 vector, 1 ColVecs D×M column-major, 2 RowVecs M×D column-major), fp64.  fp64 handles only (status −7
+ *                  otherwise): ∂/∂z is the small difference of the K_zz and K_fz terms, and the B Bᵀ an fp32 fit accumulated from fp32 products does not carry it
+ *                  (measured at C5: 69 % off; the other outputs of an fp32 handle are within 2e-3 of the fp64 oracle's — the backward pass itself is always fp64)
+ *   dx [n·d]       ∂/∂x in the container layout x_layout, the handle's dtype (adds one row reduction per observation to the streamed pass)
+ * gp_get_timings afterwards: assemble = the M×M side, potrf = the streamed pass, solve = the K_zz term. */
+int32_t gp_vfe_grad(gp_vfe* post, double* dvariance_or_null, double* dscale_or_null, double* dnoise_sum_or_null, void* dnoise_diag_or_null, void* dy_or_null,
+                    double* dz_or_null, int32_t z_layout, void* dx_or_null, int32_t x_layout);
 int32_t gp_vfe_free(gp_vfe* post);
 
 /* ---- device-level building blocks ------------------------------------------------------------ */

@@ -254,3 +254,61 @@ def test_vfe_against_the_dense_textbook_formulas(kind):
     np.testing.assert_allclose(ap.mean(xs), mean, atol=1e-8)
     np.testing.assert_allclose(ap.cov(xs), cov, atol=1e-8)
     np.testing.assert_allclose(ap.mean_and_var(xs)[1], np.diag(cov), atol=1e-8)
+
+
+@pytest.mark.parametrize("vfe", [True, False])
+@pytest.mark.parametrize("kind", [o.SE, o.MATERN12, o.MATERN32, o.MATERN52])
+def test_elbo_grad_matches_finite_differences(kind, vfe):
+    """oracle.elbo_grad (dense N×N calculus on C = Q_ff + Σy) against central differences of oracle.elbo / dtc_log_evidence, for every
+    parameter block: variance, Scale / ARD parameters, scalar / vector noise, y, pseudo-inputs, inputs — the pin of the oracle the device's
+    gp_vfe_grad is compared with (tests/test_gpu_vfe_grad.py)."""
+    rng = np.random.default_rng(40 + kind)
+    n, m, d, h = 60, 9, 2, 1e-6
+    X, Z = rng.normal(size=(n, d)), rng.normal(size=(m, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.normal(size=n)
+    for scale in (None, 0.7, np.array([0.5, 1.2])):
+        for s2 in (0.08, 0.05 + 0.1 * rng.random(n)):
+            par = {"var": 1.3, "scale": scale, "s2": s2, "X": X, "Z": Z, "y": y}
+
+            def obj(**kw):
+                q = dict(par, **kw)
+                f = o.GP(o.Kernel(kind, q["var"], q["scale"]))
+                fx = o.FiniteGP(f, q["X"], q["s2"])
+                return o.elbo(f, q["Z"], 1e-3, fx, q["y"]) if vfe else o.dtc_log_evidence(f, q["Z"], 1e-3, fx, q["y"])
+
+            f = o.GP(o.Kernel(kind, 1.3, scale))
+            g = o.elbo_grad(f, Z, 1e-3, o.FiniteGP(f, X, s2), y, vfe)
+
+            def check(name, an, **plus_minus):
+                lo = {k: par[k] - v for k, v in plus_minus.items()}
+                hi = {k: par[k] + v for k, v in plus_minus.items()}
+                fd = (obj(**hi) - obj(**lo)) / (2 * h)
+                assert abs(fd - an) <= 1e-6 * max(1.0, abs(fd)), (name, fd, an)
+
+            check("variance", g["variance"], var=h)
+            if scale is None:
+                assert g["scale"] is None
+            elif np.ndim(scale) == 0:
+                check("scale", g["scale"], scale=h)
+            else:
+                for p in range(d):
+                    e = np.zeros(d)
+                    e[p] = h
+                    check("ard", g["scale"][p], scale=e)
+            if np.ndim(s2) == 0:
+                check("noise", g["noise"], s2=h)
+            else:
+                for i in (0, 31):
+                    e = np.zeros(n)
+                    e[i] = h
+                    check("noise_i", g["noise"][i], s2=e)
+            for i, p in ((0, 0), (5, 1)):
+                E = np.zeros_like(Z)
+                E[i, p] = h
+                check("z", g["z"][i, p], Z=E)
+                E = np.zeros_like(X)
+                E[i, p] = h
+                check("x", g["x"][i, p], X=E)
+                e = np.zeros(n)
+                e[i] = h
+                check("y", g["y"][i], y=e)
