@@ -735,12 +735,17 @@ template <typename T, bool XG>
 static int32_t launch_vgrad(hipStream_t s, dim3 grid, const T* Cm, long ldc, int explicit_w, const T* xr, long ldxr, const T* xc, long ldxc, int d, int kind,
                             double variance, int nscale, const double* scale, const T* rs, const T* bv, const double* nu, long nr, long nc, double* g,
                             double* gz, long ldgz, double zfac, double* rowq, double* rowp, double* gx, long ldgx) {
-    if (d <= 4) {
-        hipLaunchKernelGGL((vgrad_kernel<T, 4, true, XG>), grid, dim3(256), 0, s, Cm, ldc, explicit_w, xr, ldxr, xc, ldxc, d, kind, (T)variance, nscale, scale,
-                           rs, bv, nu, nr, nc, g, gz, ldgz, zfac, rowq, rowp, gx, ldgx, 0);
+#define GPMI_VGRAD_FAST(ND_)                                                                                                                                  \
+    hipLaunchKernelGGL((vgrad_fast_kernel<T, ND_, XG>), grid, dim3(256), 0, s, Cm, ldc, explicit_w, xr, ldxr, xc, ldxc, d, kind, (T)variance, nscale, scale, \
+                       rs, bv, nu, nr, nc, g, gz, ldgz, zfac, rowq, rowp, gx, ldgx)
+    if (d <= 16 && (ldc & 1) == 0) {   // the scratch-free form (16-byte loads of the weights: even leading dimension)
+        if (d <= 4) GPMI_VGRAD_FAST(4);
+        else if (d <= 8) GPMI_VGRAD_FAST(8);
+        else GPMI_VGRAD_FAST(16);
         HIPCHK(hipGetLastError());
         return 0;
     }
+#undef GPMI_VGRAD_FAST
     for (int p0 = 0; p0 < d; p0 += 16) {
         hipLaunchKernelGGL((vgrad_kernel<T, 16, true, XG>), grid, dim3(256), 0, s, Cm, ldc, explicit_w, xr, ldxr, xc, ldxc, d, kind, (T)variance, nscale, scale,
                            rs, bv, nu, nr, nc, g, gz, ldgz, zfac, rowq, rowp, gx, ldgx, p0);
@@ -866,9 +871,12 @@ static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dn
             segb.push_back({rq_v, rp_v, gx_v});
             for (long c0 = 0; c0 < sg.npad && c0 < sg.n; c0 += CH) cks.push_back({&sg, c0, (double*)rq_v + c0, (double*)rp_v + c0, dx ? (double*)gx_v + c0 : nullptr});
         }
-        // roles: the GEMMs go to the ctx's HIGH-priority stream, the helpers stay on the main (normal-priority) one — the other way round (helpers on the
-        // high-priority stream, as in the fit, whose helpers are light) the fp64 vgrad launches take CUs from the GEMM: 146.8 ms against 142.5 serial at C5
-        const bool ovl = c->vfe_overlap != 0;
+        // One stream.  The two-stream forms were measured at C5 (fp64 handle, tools/c5_grad_probe.py): helpers on the ctx's high-priority stream beside the GEMMs
+        // 146.8 ms against 142.5 serial; GEMMs on the high-priority stream, helpers on the main one 142.6 / 143.3; and after the helper kernel lost its scratch
+        // traffic (vgrad_fast_kernel: 1.1 -> 0.25 ms per chunk) 132.4 with two streams against 129.1 with one — what is left beside the GEMM (kmat + vgrad ≈ 0.4 ms
+        // of 8.1 per chunk) costs more as a co-runner than in line.  The double buffers and events below stay for the experiment switch GPMI_VGRAD_STREAMS=2.
+        static const bool two_streams = [] { const char* e = getenv("GPMI_VGRAD_STREAMS"); return e && e[0] == '2'; }();
+        const bool ovl = two_streams && c->vfe_overlap != 0;
         hipStream_t sa = s, sg = ovl ? c->sp : s;
         void* Xb[2] = {X_v, X2_v};
         void* Cb[2] = {C_v, C2_v};

@@ -15,6 +15,7 @@
 #   mean_and_var(p(xs)); cov(p(xs))                 # -> gp_posterior_predict       src/exact_gpr_posterior.jl:60-90
 #   logpdf(p(xs, σ²), ys); rand(rng, p(xs, σ²), 3)  # -> gp_posterior_logpdf / gp_posterior_rand   (device, no refit)
 #   posterior(VFE(f(z, 1e-6)), fx, y); elbo(...)    # -> gp_vfe_fit / gp_vfe_predict src/sparse_approximations.jl:58-75,248-254
+#   Zygote.gradient(θ -> elbo(VFE(build(θ)(z(θ), 1e-6)), build(θ)(x, σ²), y), θ)   # -> rrule -> gp_vfe_fit + gp_vfe_grad
 #   update_posterior(pa, fx2, y2); update_posterior(pa, f(z2, 1e-6))   # -> gp_vfe_update / gp_vfe_append   :87-176
 module HipGPs
 
@@ -26,7 +27,7 @@ using KernelFunctions: SqExponentialKernel, Matern12Kernel, ExponentialKernel, M
 using LinearAlgebra, FillArrays, Statistics, StatsBase, Distributions, Random
 using ChainRulesCore
 
-export HipGP, HipPosteriorGP, HipApproxPosteriorGP, HipContext, logpdf_and_grad
+export HipGP, HipPosteriorGP, HipApproxPosteriorGP, HipContext, logpdf_and_grad, elbo_and_grad
 
 const libgpmi355 = get(ENV, "GPMI355_LIB", joinpath(@__DIR__, "..", "csrc", "libgpmi355.so"))
 
@@ -616,6 +617,64 @@ function AbstractGPs.approx_log_evidence(approx::Union{VFE,DTC}, fx::FiniteGP{<:
     return r[2]
 end
 AbstractGPs.elbo(vfe::VFE, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}) = approx_log_evidence(vfe, fx, y)  # :254
+
+# ---- value + gradient of the sparse objective: one fit + one backward pass over the retained observations (gp_vfe_grad) ------------------
+# The reference's users maximise `elbo(VFE(f(z, jitter)), f(x, Σy), y)` over kernel parameters and pseudo-points by AD / finite differences
+# (examples/0-intro-1d/script.jl:385-394); the ccall is opaque to AD, so the accelerated objective carries its own pullback.
+# ∂/∂z needs an fp64 fit (an fp32 fit's streamed B Bᵀ does not carry it: the library returns −7), so fp32 inputs get no z-tangent.
+function elbo_and_grad(approx::Union{VFE,DTC}, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}; wrt_x::Bool=false)
+    r = vfe_call(approx, fx, y, true)
+    r === nothing && throw(ArgumentError("kernel / noise / pseudo-input form is not accelerated"))
+    h, obj, T = r
+    a = marshal(fx, eltype(y))
+    zbuf, cz = points(approx.fz.x, T)
+    n = length(y)
+    dvar = Ref{Float64}(0.0); dns = Ref{Float64}(0.0)
+    dscale = zeros(Float64, max(length(a.scales), 1))
+    dnoise = Vector{T}(undef, n); dy = Vector{T}(undef, n)
+    dz = T === Float64 ? similar(zbuf, Float64) : Float64[]             # the container layout of the pseudo-inputs
+    dx = wrt_x ? similar(a.xbuf) : T[]
+    try
+        GC.@preserve dscale dnoise dy dz dx check(ccall((:gp_vfe_grad, libgpmi355), Int32,
+            (Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ref{Float64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Cvoid}, Int32),
+            h[], dvar, dscale, dns, dnoise, dy, T === Float64 ? pointer(dz) : Ptr{Float64}(C_NULL), cz.layout,
+            wrt_x ? pointer(dx) : C_NULL, a.cx.layout))
+    finally
+        ccall((:gp_vfe_free, libgpmi355), Int32, (Ptr{Cvoid},), h[])
+    end
+    return obj, (variance=dvar[], scale=dscale[1:length(a.scales)], noise=a.cn.kind == 0 ? dns[] : dnoise, y=dy, mean=-dy,
+        z=T === Float64 ? dz : nothing, x=wrt_x ? dx : nothing)
+end
+
+function ChainRulesCore.rrule(config::RuleConfig{>:HasReverseMode}, ::typeof(AbstractGPs.approx_log_evidence), approx::Union{VFE,DTC},
+    fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real})
+    desc = descriptor(fx.f.gp.kernel)
+    if desc === nothing || marshal(fx, eltype(y)) === nothing || !(approx.fz.Σy isa Diagonal{<:Any,<:Fill})   # stock path keeps its own AD
+        v0, back = rrule_via_ad(config, (g_, z_, J_, x_, Σ_, y_) -> approx_log_evidence(typeof(approx)(FiniteGP(g_, z_, J_)), FiniteGP(g_, x_, Σ_), y_),
+            fx.f.gp, approx.fz.x, approx.fz.Σy, fx.x, fx.Σy, y)
+        return v0, function (Δ)
+            _, dg, dzz, dJ, dx, dΣ, dy = back(Δ)
+            dfz = Tangent{typeof(approx.fz)}(; f=Tangent{typeof(fx.f)}(; gp=dg, ctx=NoTangent()), x=dzz, Σy=dJ)
+            return NoTangent(), Tangent{typeof(approx)}(; fz=dfz), Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; gp=dg, ctx=NoTangent()), x=dx, Σy=dΣ), dy
+        end
+    end
+    v, g = elbo_and_grad(approx, fx, y; wrt_x=true)
+    function sparse_objective_pullback(Δ)
+        Δr = unthunk(Δ)
+        gp = fx.f.gp
+        dk = kernel_tangent(gp.kernel, Δr * g.variance, desc[2], Δr .* g.scale)
+        dgp = Tangent{typeof(gp)}(; mean=mean_tangent(gp.mean, Δr .* g.mean), kernel=dk)
+        df = Tangent{typeof(fx.f)}(; gp=dgp, ctx=NoTangent())
+        dfx = Tangent{typeof(fx)}(; f=df, x=input_tangent(fx.x, g.x, Δr), Σy=noise_tangent(fx.Σy, Δr .* g.noise))
+        # the prior is shared (approx.fz.f === fx.f): its tangent travels with fx; the pseudo-inputs get theirs, the jitter is a constant of the fit
+        dzt = g.z === nothing ? ChainRulesCore.@not_implemented("HipGPs: ∂/∂z needs Float64 inputs") : input_tangent(approx.fz.x, g.z, Δr)
+        dfz = Tangent{typeof(approx.fz)}(; f=ZeroTangent(), x=dzt, Σy=ZeroTangent())
+        return NoTangent(), Tangent{typeof(approx)}(; fz=dfz), dfx, Δr .* g.y
+    end
+    return v, sparse_objective_pullback
+end
+ChainRulesCore.rrule(config::RuleConfig{>:HasReverseMode}, ::typeof(AbstractGPs.elbo), vfe::VFE, fx::FiniteGP{<:HipGP}, y::AbstractVector{<:Real}) =
+    ChainRulesCore.rrule(config, AbstractGPs.approx_log_evidence, vfe, fx, y)
 
 function vfe_predict(f::HipApproxPosteriorGP, x::AbstractVector, what::Integer)
     T = getfield(f, :T)

@@ -226,6 +226,42 @@ def other_configs(agp, ctx, steps: int = 5) -> dict:
                  "ms_min": min(last_times) * 1e3, "steps": steps, "statistic": "median",
                  "points_per_s": n / dt, "tflops": flops / dt / 1e12, "frac_fp32": flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS,
                  "elbo": obj[-1]}
+    # value + gradient of the ELBO (gp_vfe_grad: what a caller maximising the ELBO over kernel parameters / pseudo-points does next — the reference's
+    # examples/0-intro-1d/script.jl:385-394): the backward pass on the resident fp32 posterior (the pass itself is always fp64), median of 3 after a warm-up
+    post = agp.posterior(approx, fx, y)
+    post.objective_grad()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        g32 = post.objective_grad()
+        ts.append(time.perf_counter() - t0)
+    gdt = float(np.median(ts))
+    ph = ctx.timings()
+    gflops = 2.0 * n * m * m + 5.0 * m**3   # one CH×M×M product per chunk; M×M side: two triangular inverses, A⁻¹, two conjugations
+    del post
+    # check: the gradient of an fp64 posterior of the same inputs along (variance, scale, noise, z) against a central difference of two fp64 fits, and
+    # the fp32 posterior's hyper-parameter gradients against it
+    X64, y64, z64 = X.astype(np.float64), y.astype(np.float64), z.astype(np.float64)
+    dirs, dZ, h = np.array([0.3, -0.2, 0.05]), np.random.default_rng(6).standard_normal(z64.shape), 1e-5
+
+    def obj64(var, sc, s2, zc, grad=False):
+        f64 = agp.GP(var * agp.SqExponentialKernel() @ agp.ScaleTransform(sc), ctx=ctx)
+        a64, fx64 = agp.VFE(f64(agp.RowVecs(zc), 1e-4)), f64(agp.RowVecs(X64), s2)
+        return agp.elbo_and_grad(a64, fx64, y64) if grad else float(agp.approx_log_evidence(a64, fx64, y64))
+
+    t0 = time.perf_counter()
+    _, g64 = obj64(1.0, 1.0, 0.1, z64, grad=True)
+    t64 = time.perf_counter() - t0
+    fd = (obj64(1 + h * dirs[0], 1 + h * dirs[1], 0.1 + h * dirs[2], z64 + h * dZ) - obj64(1 - h * dirs[0], 1 - h * dirs[1], 0.1 - h * dirs[2], z64 - h * dZ)) / (2 * h)
+    an = g64["variance"] * dirs[0] + g64["scale"] * dirs[1] + g64["noise"] * dirs[2] + float(np.sum(g64["z"] * dZ))
+    r32 = max(abs(g32["variance"] - g64["variance"]) / abs(g64["variance"]), abs(g32["noise"] - g64["noise"]) / abs(g64["noise"]))
+    out["C5"]["gradient"] = {
+        "what": "d ELBO / d(variance, noise, y) of the resident fp32 posterior (gp_vfe_grad; + scale, pseudo-inputs on fp64 posteriors): M×M side, one fp64 MFMA product per chunk, fused reductions",
+        "ms": gdt * 1e3, "ms_all": [t * 1e3 for t in ts], "phases_ms": {"mxm_side": ph["assemble_ms"], "streamed_pass": ph["potrf_ms"], "kzz_term": ph["solve_ms"]},
+        "flops": gflops, "tflops": gflops / gdt / 1e12, "frac": gflops / gdt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "peak": FP64_MFMA_PEAK_TFLOPS,
+        "fp64_fit_plus_gradient_ms": t64 * 1e3,
+        "check": {"directional_derivative_fp64": an, "central_difference_of_fp64_fits": fd, "rel": abs(an - fd) / abs(fd), "tol": 1e-4,
+                  "fp32_vs_fp64_posterior_variance_noise_rel": r32, "tol_fp32": 3e-2, "pass": bool(abs(an - fd) <= 1e-4 * abs(fd) and r32 <= 3e-2)}}
     ctx.trim()
     return out
 

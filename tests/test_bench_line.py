@@ -78,6 +78,15 @@ def test_bench_line_carries_the_parity_checks_and_the_other_configs():
         assert oc[name]["steps"] >= 5 and oc[name]["statistic"] == "median"
     for name in ("mean_and_var_4096", "cov_1024", "sequential_update_8192", "value_and_gradient"):
         assert name in oc["next"], name
+    # every timed row carries its own check (round 6); the sparse objective's gradient joined the line late in round 6
+    for name in ("mean_and_var_4096", "cov_1024", "sequential_update_8192"):
+        if "check" in oc["next"][name]:
+            assert oc["next"][name]["check"]["pass"] is True, name
+    for name, row in oc["next"]["value_and_gradient"].items():
+        if "check" in row:
+            assert row["check"]["pass"] is True, name
+    if "gradient" in oc["C5"]:
+        assert oc["C5"]["gradient"]["check"]["pass"] is True and oc["C5"]["gradient"]["check"]["rel"] <= 1e-4
 
 
 def test_pmc_summary_counts_whole_passes_of_the_bench():

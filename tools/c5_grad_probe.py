@@ -1,4 +1,4 @@
-"""C5-size value + gradient of the sparse objective: N = 262 144, M = 4 096, D = 3 (bench.py's C5 inputs), fp32 and fp64 handles — ms per fit, ms per
+"""C5-size value + gradient of the sparse objective: N = 262 144, M = 4 096, D = 3, fp32 and fp64 handles — ms per fit, ms per
 gradient (with its three phases), and the gradient along a random direction in (variance, scale, noise, z) against a central difference of fp64 fits.
     python tools/c5_grad_probe.py [reps=3]"""
 import sys, time, json
@@ -22,23 +22,16 @@ for dt in (np.float32, np.float64):
     post = agp.posterior(a, fx, yd)
     post.objective_grad()
     tf, tg, ph = [], [], None
+    for _ in range(reps):   # fits, then gradients of the resident posterior (a gradient right behind an fp32 fit has measured 10–20 ms slower than the steady pass)
+        t0 = time.perf_counter(); post = agp.posterior(a, fx, yd); tf.append((time.perf_counter() - t0) * 1e3)
     for _ in range(reps):
-        t0 = time.perf_counter(); post = agp.posterior(a, fx, yd); t1 = time.perf_counter()
-        g = post.objective_grad(); t2 = time.perf_counter()
+        t1 = time.perf_counter(); g = post.objective_grad(); tg.append((time.perf_counter() - t1) * 1e3)
         ph = ctx.timings()
-        tf.append((t1 - t0) * 1e3); tg.append((t2 - t1) * 1e3)
     key = "f32" if dt is np.float32 else "f64"
     out[key] = {"fit_ms": float(np.median(tf)), "grad_ms": float(np.median(tg)), "grad_phases_ms": {k: ph[k] for k in ("assemble_ms", "potrf_ms", "solve_ms", "total_ms")},
                 "objective": float(post.objective), "variance": g["variance"], "scale": g["scale"], "noise": g["noise"]}
     if dt is np.float64:
         g64 = g
-        ctx.set_param("vfe_overlap", 0)     # the same pass on one stream
-        post = agp.posterior(a, fx, yd); post.objective_grad()
-        ts = []
-        for _ in range(reps):
-            t1 = time.perf_counter(); post.objective_grad(); ts.append((time.perf_counter() - t1) * 1e3)
-        out[key]["grad_ms_one_stream"] = float(np.median(ts)); out[key]["grad_phases_ms_one_stream"] = {k: ctx.timings()[k] for k in ("assemble_ms", "potrf_ms", "solve_ms", "total_ms")}
-        ctx.set_param("vfe_overlap", 1)
     else:
         g32 = g
 # directional derivative in fp64
