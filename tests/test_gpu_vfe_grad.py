@@ -275,3 +275,38 @@ def test_objective_grad_at_c5_size(agp):
     for key in ("variance", "scale", "noise"):
         assert g32[key] == pytest.approx(g[key], rel=5e-3), key
     assert np.max(np.abs(g32["y"] - g["y"])) <= 5e-3 * np.max(np.abs(g["y"]))
+
+
+def test_lbfgs_on_the_elbo_like_the_reference_example(agp):
+    """examples/0-intro-1d/script.jl:359-420 on the device (tools/train_sparse_example.py): LBFGS over softplus(variance), softplus(inverse lengthscale) and
+    logistic(pseudo-points) with `elbo_and_grad` as value / gradient.  The optimiser must make progress with these gradients (a wrong chain would stall the
+    line search), and the optimum's value must be the oracle's ELBO at the optimum's parameters."""
+    import importlib.util
+    from pathlib import Path
+
+    from scipy.optimize import minimize
+
+    spec = importlib.util.spec_from_file_location("train_sparse_example", Path(__file__).resolve().parent.parent / "tools" / "train_sparse_example.py")
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    rng = np.random.default_rng(0)
+    n, m = 3000, 10
+    x = rng.random(n)
+    y = np.sin(4 * np.pi * x) + np.cos(11 * x) * x + 0.3 * rng.standard_normal(n)
+    calls = []
+    fun = ex.make_objective(x, y, 0.09, calls=calls)
+    p0 = rng.random(2 + m)
+    v0 = -fun(p0)[0]
+    res = minimize(fun, p0, jac=True, method="L-BFGS-B", options={"maxiter": 30})
+    v1 = -float(res.fun)
+    assert v1 > v0 + 100.0, (v0, v1)
+    var, sc, z = ex.softplus(res.x[0]), ex.softplus(res.x[1]), ex.logistic(res.x[2:])
+    of = o.GP(o.Kernel(o.MATERN52, float(var), float(sc)))
+    assert v1 == pytest.approx(o.elbo(of, z, 1e-6, o.FiniteGP(of, x, 0.09), y), rel=1e-7)
+    # the chain-ruled gradient at the optimum against central differences of the objective in the unconstrained parameters
+    g = fun(res.x)[1]
+    for i in (0, 1, 2, 2 + m // 2):
+        e = np.zeros_like(res.x)
+        e[i] = 1e-5
+        fd = (fun(res.x + e)[0] - fun(res.x - e)[0]) / 2e-5
+        assert g[i] == pytest.approx(fd, rel=1e-3, abs=2e-3), (i, g[i], fd)
