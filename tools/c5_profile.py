@@ -1,6 +1,6 @@
 """C5 (VFE, N = 262 144, M = 4 096, fp32 streamed / fp64 M×M side) alone, for rocprofv3 --kernel-trace --stats: `reps` fits, the
 phase split of the last one (assemble = K_zz + chol + inv(L_z) prelude; potrf = streamed pass + Λ_ε side) and optional parameter
-overrides NAME=VALUE on the command line.    python tools/c5_profile.py [reps=3] [vfe_chunk=...] [vfe_ks=...] [vfe_overlap=0|1]"""
+overrides NAME=VALUE on the command line.    python tools/c5_profile.py [reps=3] [dtype=f32|f64] [vfe_chunk=...] [vfe_ks=...] [vfe_overlap=0|1]"""
 import json
 import sys
 import time
@@ -11,25 +11,27 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import abstractgps_jl_amd as agp  # noqa: E402
 
-reps, params, mfma_ref = 3, {}, 0
+reps, params, mfma_ref, dt = 3, {}, 0, np.float32
 for a in sys.argv[1:]:
     k, v = a.split("=")
     if k == "reps":
         reps = int(v)
     elif k == "mfma_ref":
         mfma_ref = int(v)
+    elif k == "dtype":
+        dt = np.float64 if v in ("f64", "float64") else np.float32
     else:
         params[k] = int(v)
 n, m, d = 262144, 4096, 3
 rng = np.random.default_rng(5)
-X = (rng.uniform(0, 1, (n, d)) * 4).astype(np.float32)
-y = (np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n)).astype(np.float32)
+X = (rng.uniform(0, 1, (n, d)) * 4).astype(dt)
+y = (np.sin(X.sum(1)) + 0.3 * rng.standard_normal(n)).astype(dt)
 z = X[rng.permutation(n)[:m]].copy()
 ctx = agp.default_context()
 for k, v in params.items():
     ctx.set_param(k, v)
 f = agp.GP(agp.SqExponentialKernel())
-fx = f(agp.RowVecs(X), np.float32(0.1))
+fx = f(agp.RowVecs(X), dt(0.1))
 approx = agp.VFE(f(agp.RowVecs(z), 1e-4))
 ts = []
 for _ in range(reps):
