@@ -122,7 +122,7 @@ struct gp_ctx {
     std::unordered_map<void*, size_t> blk;     // true size of every block handed out by ctx_alloc
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)96 << 30;        // bytes kept in the cache at most ("pool_cap_mb"; gp_ctx_trim drops it all)
-    long vfe_chunk = 16384;                    // data points per streamed VFE chunk (multiple of vfe_ks; 16 384 measured best at C5)
+    long vfe_chunk = 0;                        // data points per streamed VFE chunk (multiple of vfe_ks); 0: automatic — 16 384 (measured best at C5) × a power of two for fewer pseudo-points (vfe.hpp)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct GemmRec {

@@ -886,7 +886,14 @@ static void scale_points(const gp_kernel* k, const gp_points* x, long ldx, std::
         if (k->nscale == 1) s = (T)k->scale[0];
         else if (k->nscale > 1) s = (T)k->scale[dd];
         T* o = out.data() + (size_t)dd * ldx;
-        for (long i = 0; i < x->n; ++i) o[i] = s * pt_get<T>(x, i, dd);
+        const T* p = (const T*)x->data;
+        const long n = x->n;
+        if (x->layout == 1) {  // point-contiguous: stride d
+            for (long i = 0; i < n; ++i) o[i] = s * p[(long)dd + i * d];
+        } else {               // a vector, or dimension-contiguous: unit stride
+            const T* q = x->layout == 0 ? p : p + (long)dd * n;
+            for (long i = 0; i < n; ++i) o[i] = s * q[i];
+        }
     }
 }
 
@@ -1741,7 +1748,7 @@ int32_t gp_ctx_set_param(gp_ctx* c, const char* name, int64_t v) {
     else if (!strcmp(name, "vfe_dual")) c->vfe_dual = v != 0;
     else if (!strcmp(name, "vfe_inv_nb")) c->vfe_inv_nb = v <= 0 ? 0 : round_up(v, 128);
     else if (!strcmp(name, "vfe_overlap")) c->vfe_overlap = v != 0;
-    else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = std::max<int64_t>(2048, round_up(v, 2048));
+    else if (!strcmp(name, "vfe_chunk")) c->vfe_chunk = v <= 0 ? 0 : std::max<int64_t>(2048, round_up(v, 2048));
     else if (!strcmp(name, "pool_cap_mb")) c->pool_cap = (size_t)std::max<int64_t>(0, v) << 20;
     else if (!strcmp(name, "lookahead_depth") || !strcmp(name, "dist_nb") || !strcmp(name, "copy_kernel") || !strcmp(name, "multi_debug_sync") ||
              !strcmp(name, "multi_check") || !strcmp(name, "multi_verify") || !strcmp(name, "multi_inject_fault") || !strcmp(name, "multi_dist_predict") || !strcmp(name, "multi_window") || !strcmp(name, "multi_timeout_s") || !strcmp(name, "multi_gemm_streamk") || !strcmp(name, "multi_leaf_cols")) return c->multi ? 0 : set_arg_err(2, "multi-device parameter on a single-device ctx");

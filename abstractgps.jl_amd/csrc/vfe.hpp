@@ -50,6 +50,7 @@ struct gp_vfe {
     void* vec = nullptr;                // double [4][mp]: rows c, m_ε, α, spare
     int approx = 0;
     long n_obs = 0;
+    long chunk = 16384;  // data points per streamed chunk of THIS handle (chosen by its first fit; its updates / appends / gradient keep it: the retained segments are padded to it)
     // streaming state before the M×M finalisation: −B Bᵀ (lower), B b_y, per-row ‖B‖², inv(L_z) and scaled z in T
     void *Dacc = nullptr, *cacc = nullptr, *rowss = nullptr, *Li = nullptr, *zsT = nullptr;
     std::vector<std::shared_ptr<ObsSeg>> segs;  // every observation seen so far (shared between a posterior and its updates)
@@ -114,7 +115,15 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     const long m = mode == VFE_FIT ? z->n : m_old + m2;
     const long mp = round_up(m, 128);
     const int d = prev ? prev->d : x->d;
-    const long CH = c->vfe_chunk;               // data points per streamed chunk
+    // data points per streamed chunk: the handle's own once it exists; else the ctx parameter "vfe_chunk" (> 0), or automatic (0, the default): 16 384 — measured
+    // best at C5 (M = 4 096) — times a power of two that keeps chunk × M at C5's footprint for fewer pseudo-points (M = 64 … 256 and N = 2·10⁶: 123 chunks of
+    // 16 384 cost 13.5 / 17.0 ms per fit pass, 16 of 131 072 6.4 / ≈ 12 — launches of a few hundred µs of work each), never more than the batch itself
+    long CH = prev ? prev->chunk : c->vfe_chunk;
+    if (CH <= 0) {
+        long f = 1;
+        while (f < 16 && 2 * f * mp <= 4096) f *= 2;
+        CH = std::min(16384 * f, round_up(std::max(x ? x->n : 1L, 1L), 16384));
+    }
     const long KS = std::min(c->vfe_ks, CH);    // fp32: data points per fp32 partial product
     const int NBAT = (int)(CH / KS);
     if (CH % KS) return set_arg_err(1, "vfe_chunk must be a multiple of vfe_ks");
@@ -150,8 +159,32 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         scale_points<T>(k, x, npad, xs_h);
         rs_h.assign((size_t)npad, T(0));  // s_i = σ_i⁻¹
         b_h.assign((size_t)npad, T(0));   // b_i = s_i δ_i  (b_y, :66)
+        if (noise->kind == 0) {  // Σy = σ² I: one square root, one logarithm (the general loop below spends ≈ 15 ns per observation on them: 30 ms at N = 2·10⁶)
+            const double s2 = noise->s;
+            if (!(s2 > 0)) return n > 0 ? 1 : 0;  // chol(Σy) fails at the first observation (reference :61 / :296)
+            const double si = 1.0 / std::sqrt(s2);
+            std::fill(rs_h.begin(), rs_h.begin() + n, (T)si);
+            double acc = 0;
+            if (mean) {
+                for (long i = 0; i < n; ++i) {
+                    const T bi = (T)((double)(T)(y[i] - mean[i]) * si);
+                    b_h[i] = bi;
+                    acc += (double)bi * (double)bi;
+                }
+            } else {
+                for (long i = 0; i < n; ++i) {
+                    const T bi = (T)((double)y[i] * si);
+                    b_h[i] = bi;
+                    acc += (double)bi * (double)bi;
+                }
+            }
+            dd += acc;
+            logdet_sy += (double)n * std::log(s2);
+            tr_kff += (double)n * (k->variance / s2);  // tr_Cf_invΣy :307-313
+            return 0;
+        }
         for (long i = 0; i < n; ++i) {
-            const double s2 = noise->kind == 0 ? noise->s : (double)((const T*)noise->diag)[i];
+            const double s2 = (double)((const T*)noise->diag)[i];
             if (!(s2 > 0)) return 1 + (int32_t)i;  // chol(Σy) fails at i (reference :61 / :296)
             const double delta = (double)(T)(y[i] - (mean ? mean[i] : T(0)));
             const double si = 1.0 / std::sqrt(s2);
@@ -540,6 +573,7 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         out->vec = bufs.keep(vec_v);
         out->approx = approx;
         out->n_obs = n_all;
+        out->chunk = CH;
         out->Dacc = bufs.keep(D_v);
         out->cacc = bufs.keep(cT_v);
         out->rowss = bufs.keep(rss_v);
@@ -758,7 +792,7 @@ template <typename T>
 static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dnoise_sum, void* dnoise, void* dy, double* dz, int z_layout, void* dx,
                              int x_layout) {
     gp_ctx* c = p->ctx;
-    const long m = p->m, mp = p->mp, ld = p->ld, CH = c->vfe_chunk;
+    const long m = p->m, mp = p->mp, ld = p->ld, CH = p->chunk;
     const int d = p->d;
     const bool vfe = p->approx == 0;
     constexpr bool is_f64 = sizeof(T) == 8;
@@ -771,7 +805,7 @@ static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dn
         if (!e) HIPCHK(hipEventCreate(&e));
     const int nsc = std::max(p->nscale, 1);
     const size_t L_b = sizeof(double) * (size_t)(mp + 128 + 128) * ld;
-    const size_t X_b = sizeof(double) * (size_t)(CH + 128) * ld, g_b = sizeof(double) * (size_t)(2 + nsc), gz_b = sizeof(double) * (size_t)d * mp;
+    const size_t X_b = sizeof(double) * (size_t)(CH + 128) * ld, g_b = sizeof(double) * (size_t)(2 + nsc + 2), gz_b = sizeof(double) * (size_t)d * mp;
     void *W_v = 0, *V_v = 0, *H_v = 0, *R_v = 0, *E_v = 0, *Gp_v = 0, *Gz_v = 0, *X_v = 0, *X2_v = 0, *C2_v = 0, *xc_v = 0, *rc_v = 0, *bc_v = 0, *C_v = 0, *g_v = 0, *gz_v = 0, *sc_v = 0;
     DevBufs bufs(c);
     RC(bufs.get(L_b, &W_v));
@@ -799,12 +833,11 @@ static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dn
     const double* alpha = (const double*)p->vec + 2 * mp;
     std::vector<double> sc_h((size_t)nsc, 1.0);
     for (int q = 0; q < p->nscale; ++q) sc_h[q] = p->scale[q];
-    std::vector<double> g_h((size_t)(2 + nsc), 0.0), gz_h((size_t)d * mp, 0.0);
+    std::vector<double> g_h((size_t)(2 + nsc + 2), 0.0), gz_h((size_t)d * mp, 0.0);   // [0] ∂/∂variance, [2 + p] ∂/∂scale_p, [2 + nsc] Σ ∂/∂σ_i², [3 + nsc] Σ σ_i⁻²
     // per observation (concatenated over the segments, arrival order): what the host needs to finish ∂/∂σ_i², ∂/∂y_i, ∂/∂x_i
     long n_all = 0;
     for (auto& sg : p->segs) n_all += sg->n;
-    std::vector<double> dn_h((size_t)n_all), dy_h((size_t)n_all), gx_all(dx ? (size_t)n_all * d : 0);
-    double sum_rs2 = 0;
+    std::vector<double> gx_all(dx ? (size_t)n_all * d : 0);
     const dim3 sq((unsigned)((mp + 255) / 256), (unsigned)mp);
     auto conj = [&](const double* Hm, double* G) -> int32_t {  // G (full, symmetric) = ½ W Hm Wᵀ − ½ ααᵀ
         GridMap gr = plain_map(0, 0, 0);
@@ -959,26 +992,25 @@ static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dn
             }
         }
         // (every GEMM is followed by its vgrad on the main stream, which waited for it: nothing to join)
+        // ---- per observation: ∂/∂σ_i², ∂/∂y_i and the two N-long sums on the device; only what the caller asked for comes back
         long off = 0;
         for (size_t si = 0; si < p->segs.size(); ++si) {
             const ObsSeg& sg = *p->segs[si];
             if (sg.n == 0) continue;
-            const size_t r_b = sizeof(double) * (size_t)sg.npad;
-            std::vector<double> rq_h((size_t)sg.n), rp_h((size_t)sg.n), gx_h(dx ? (size_t)sg.npad * d : 0);
-            std::vector<T> rs_h((size_t)sg.n), b_h((size_t)sg.n);
-            HIPCHK(hipMemcpyAsync(rq_h.data(), segb[si][0], sizeof(double) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(rp_h.data(), segb[si][1], sizeof(double) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(rs_h.data(), sg.rs, sizeof(T) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(b_h.data(), sg.b, sizeof(T) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
-            if (dx) HIPCHK(hipMemcpyAsync(gx_h.data(), segb[si][2], r_b * d, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            for (long i = 0; i < sg.n; ++i) {
-                const double r = (double)rs_h[i], b = (double)b_h[i], r2 = r * r, r3 = r2 * r;
-                sum_rs2 += r2;
-                dn_h[off + i] = -0.5 * r2 + 0.5 * b * b * r2 - rq_h[i] * r3 - rp_h[i] * b * r3 + (vfe ? 0.5 * p->variance * r2 * r2 : 0.0);
-                dy_h[off + i] = -(b * r - rp_h[i] * r2);
-                if (dx)
-                    for (int q = 0; q < d; ++q) gx_all[(size_t)q * n_all + off + i] = gx_h[(size_t)q * sg.npad + i];
+            void *dn_v = 0, *dy_v = 0;
+            RC(bufs.get(sizeof(T) * (size_t)sg.n, &dn_v));
+            RC(bufs.get(sizeof(T) * (size_t)sg.n, &dy_v));
+            hipLaunchKernelGGL(vgrad_finish_kernel<T>, dim3((unsigned)std::min<long>((sg.n + 255) / 256, 2048)), dim3(256), 0, s, (const T*)sg.rs, (const T*)sg.b,
+                               (const double*)segb[si][0], (const double*)segb[si][1], sg.n, p->variance, vfe ? 1 : 0, (T*)dn_v, (T*)dy_v, (double*)g_v + 2 + nsc);
+            HIPCHK(hipGetLastError());
+            if (dnoise) HIPCHK(hipMemcpyAsync((T*)dnoise + off, dn_v, sizeof(T) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
+            if (dy) HIPCHK(hipMemcpyAsync((T*)dy + off, dy_v, sizeof(T) * (size_t)sg.n, hipMemcpyDeviceToHost, s));
+            if (dx) {
+                std::vector<double> gx_h((size_t)sg.npad * d);
+                HIPCHK(hipMemcpyAsync(gx_h.data(), segb[si][2], sizeof(double) * (size_t)sg.npad * d, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                for (int q = 0; q < d; ++q)
+                    for (long i = 0; i < sg.n; ++i) gx_all[(size_t)q * n_all + off + i] = gx_h[(size_t)q * sg.npad + i];
             }
             off += sg.n;
         }
@@ -1009,18 +1041,10 @@ static int32_t vfe_grad_impl(gp_vfe* p, double* dvar, double* dscale, double* dn
         (void)hipStreamSynchronize(c->sm);
         return rc;
     }
-    if (dvar) *dvar = g_h[0] - (vfe ? 0.5 * sum_rs2 : 0.0);
+    if (dvar) *dvar = g_h[0] - (vfe ? 0.5 * g_h[3 + nsc] : 0.0);   // − ½ Σ_i ∂k_ii/∂σ_k² / σ_i²: the trace term
     if (dscale)
         for (int q = 0; q < p->nscale; ++q) dscale[q] = g_h[2 + q];
-    if (dnoise_sum) {
-        double sm = 0;
-        for (long i = 0; i < n_all; ++i) sm += dn_h[i];
-        *dnoise_sum = sm;
-    }
-    if (dnoise)
-        for (long i = 0; i < n_all; ++i) ((T*)dnoise)[i] = (T)dn_h[i];
-    if (dy)
-        for (long i = 0; i < n_all; ++i) ((T*)dy)[i] = (T)dy_h[i];
+    if (dnoise_sum) *dnoise_sum = g_h[2 + nsc];
     if (dz)  // the container layout of the pseudo-inputs (src/finite_gp_projection.jl:32-37): 0 vector, 1 ColVecs (D×M column-major), 2 RowVecs (M×D column-major)
         for (int q = 0; q < d; ++q)
             for (long j = 0; j < m; ++j) {

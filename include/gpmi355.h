@@ -183,7 +183,8 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    carries an error of order cond(L_bb)·ε where substitution is backward stable: a handle whose factor has max |L_ii| / min |L_ii|
  *                    above 1e5 (cond(K + Σy) >= 1e10) keeps the substitution leaves                   default 2048
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32
- *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks)              default 16384
+ *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks); 0 = automatic: 16 384 for M >= 2 048 pseudo-points (measured best at C5),
+ *                    × 2 … 16 for fewer (chunk × M kept at C5's footprint), at most the batch; a handle keeps the chunk of its first fit        default 0
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
  *   "vfe_dual"       VFE experiment switch: 1 = the triangular products of the chunks on a high-priority third stream beside the chunk SYRKs on the main stream
@@ -222,7 +223,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
     "nb=-1,nb_small=4096,nb_large=2048,lookahead=1,lookahead_min_n=24576,time_kernels=0,xcd_swizzle=0,xcd_min_tiles=256,gemm_streamk=1,sk_max_tiles=4096," \
     "sk_min_k=0,gemm_pipe=1,gemm_pad_f32=0,gemm_pad_lds=0,trsv_nb=256,deterministic=0,leaf_v2=1,leaf_xr=0,leaf_cols=128,"    \
     "updk_max_k=512,updk_rt=0,updk_tall_k=256,updk_tall_m=8192,upd128=1,leaf_group=128,ldpad=32,vfe_ks=2048,vfe_sk=0,"          \
-    "vfe_overlap=1,vfe_dual=0,vfe_inv_nb=512,vfe_chunk=16384,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"
+    "vfe_overlap=1,vfe_dual=0,vfe_inv_nb=512,vfe_chunk=0,kmat_rows=1,dib_nb=2048,pool_cap_mb=98304"
 int32_t gp_ctx_set_param(gp_ctx* ctx, const char* name, int64_t value);
 /* Read a parameter back (same names; "gemm_pad_lds" reads 0 until it has been set explicitly).  Used by the test-suite to assert that
  * every GPU test starts from the documented defaults. */

@@ -233,6 +233,7 @@ def test_vfe_schedule_variants(agp, dual, inv_nb):
     ctx = agp.Context(0)
     ctx.set_param("vfe_dual", dual)
     ctx.set_param("vfe_inv_nb", inv_nb)
+    ctx.set_param("vfe_chunk", 16384)   # three chunks (the automatic choice for M = 700 would stream this batch as one)
     try:
         f = agp.GP(agp.SqExponentialKernel(), ctx=ctx)
         for dt, rtol, atol in ((np.float32, 1e-4, 1e-3), (np.float64, 1e-8, 1e-6)):
