@@ -312,3 +312,21 @@ def test_elbo_grad_matches_finite_differences(kind, vfe):
                 e = np.zeros(n)
                 e[i] = h
                 check("y", g["y"][i], y=e)
+
+
+def test_elbo_grad_survives_an_ill_conditioned_kzz():
+    """128 pseudo-points on a line under the SE kernel with jitter 1.8e-6 (cond(K_zz) ≈ 1e8 — a configuration of the round-6 random sweep): the
+    pseudo-input gradient along a direction against central differences of `elbo` (itself Cholesky-based).  The first form of `elbo_grad`, with
+    explicit inverses, was 0.8 % off here; the device's gradient agreed with the differences."""
+    rng = np.random.default_rng(1770111)
+    n, m = 640, 128
+    X, Z = rng.standard_normal((n, 1)), rng.standard_normal((m, 1))
+    y = np.sin(X[:, 0]) + 0.1 * rng.standard_normal(n)
+    f = o.GP(o.Kernel(o.SE, 1.7), 0.4)
+    fx = o.FiniteGP(f, X, 0.11)
+    g = o.elbo_grad(f, Z, 1.8e-6, fx, y)
+    dZ = rng.standard_normal(Z.shape)
+    fds = [(o.elbo(f, Z + h * dZ, 1.8e-6, fx, y) - o.elbo(f, Z - h * dZ, 1.8e-6, fx, y)) / (2 * h) for h in (1e-4, 1e-5)]
+    an = float(np.sum(g["z"] * dZ))
+    assert abs(fds[0] - fds[1]) <= 1e-3 * abs(fds[1])          # the difference quotient has converged
+    assert an == pytest.approx(fds[1], rel=1e-3), (an, fds)
