@@ -62,12 +62,21 @@ def build(name, n, d, kind, variance, scale, sigma2, mean, ns):
     dtc = o.dtc_log_evidence(f, z, jitter, fx, y)
     ap = o.vfe_posterior(f, z, jitter, fx, y)
     vm, vv = ap.mean_and_var(xs)
+    # gradient of the sparse objectives (oracle.elbo_grad: dense N×N calculus, pinned by central differences in tests/test_oracle.py); the pseudo-points here are
+    # a subset of the inputs at jitter 1e-6 — the ill-conditioned end of what the device is held to
+    ge, gd = o.elbo_grad(f, z, jitter, fx, y, vfe=True), o.elbo_grad(f, z, jitter, fx, y, vfe=False)
+    gpack = {}
+    for tag, g in (("elbo", ge), ("dtc", gd)):
+        gpack[f"{tag}_grad_variance"] = g["variance"]
+        gpack[f"{tag}_grad_scale"] = np.asarray(np.nan if g["scale"] is None else g["scale"], dtype=np.float64)
+        gpack[f"{tag}_grad_noise"] = np.asarray(g["noise"])
+        gpack[f"{tag}_grad_y"], gpack[f"{tag}_grad_z"], gpack[f"{tag}_grad_x"] = g["y"], g["z"], g["x"]
     np.savez_compressed(OUT / f"{name}.npz", x=x, y=y, Y=Y, xs=xs, kind=kind, variance=variance,
                         scale=np.asarray(np.nan if scale is None else scale, dtype=np.float64),
                         sigma2=np.asarray(s2), mean=np.asarray(np.nan if mean is None else mean),
                         logpdf=lp, logpdf_Y=lpY, alpha=post.alpha, post_mean=pm, post_var=pv, post_cov=pc,
                         z=z, jitter=jitter, elbo=e, dtc=dtc, vfe_alpha=ap.alpha, vfe_m_eps=ap.m_eps, vfe_mean=vm,
-                        vfe_var=vv)
+                        vfe_var=vv, **gpack)
     print(f"{name}: logpdf={lp:.12g} elbo={e:.12g}")
 
 

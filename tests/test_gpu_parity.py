@@ -93,6 +93,25 @@ def test_vfe_vs_golden(agp, path):
     np.testing.assert_allclose(v, g["vfe_var"], atol=1e-7)
 
 
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_vfe_grad_vs_golden(agp, path):
+    """gp_vfe_grad against the committed fixtures' `elbo_grad_*` / `dtc_grad_*` fields (written by oracle.elbo_grad; tests/golden/make_golden.py): the
+    pseudo-points of the fixtures are a subset of the inputs at jitter 1e-6 — cond(K_zz) up to 1e8, so every block is held to 1e-5 of its largest
+    component (the well-conditioned configurations of tests/test_gpu_vfe_grad.py are held to 1e-7)."""
+    g, f, fx, of, ofx = _golden(agp, path)
+    for tag, A in (("elbo", agp.VFE), ("dtc", agp.DTC)):
+        val, gr = agp.elbo_and_grad(A(f(g["z"], float(g["jitter"]))), fx, g["y"], wrt_x=True)
+        assert val == pytest.approx(float(g[tag]), rel=1e-8)
+        pairs = [("variance", gr["variance"]), ("noise", gr["noise_diag"] if g["sigma2"].ndim else gr["noise"]), ("y", gr["y"]), ("z", gr["z"]), ("x", gr["x"])]
+        if gr["scale"] is not None:
+            pairs.append(("scale", gr["scale"]))
+        for key, got in pairs:
+            ref = np.asarray(g[f"{tag}_grad_{key}"], dtype=np.float64)
+            got = np.asarray(got, dtype=np.float64).reshape(ref.shape)
+            err = float(np.max(np.abs(got - ref))) / max(1.0, float(np.max(np.abs(ref))))
+            assert err <= 1e-5, (tag, key, err)
+
+
 @pytest.mark.parametrize("n,d,kind,layout", [(1000, 3, 0, "row"), (777, 8, 2, "col"), (2048, 1, 3, "vec"),
                                              (4099, 3, 0, "row")])
 def test_mid_size_parity(agp, n, d, kind, layout):

@@ -34,6 +34,12 @@ def test_golden_reproduces(path):
     np.testing.assert_allclose(m, g["post_mean"], atol=1e-10)
     np.testing.assert_allclose(v, g["post_var"], atol=1e-10)
     assert o.elbo(f, g["z"], float(g["jitter"]), fx, g["y"]) == pytest.approx(float(g["elbo"]), rel=1e-10)
+    for tag, vfe in (("elbo", True), ("dtc", False)):   # the sparse objectives' gradients (round 6)
+        gr = o.elbo_grad(f, g["z"], float(g["jitter"]), fx, g["y"], vfe=vfe)
+        assert gr["variance"] == pytest.approx(float(g[f"{tag}_grad_variance"]), rel=1e-7)
+        for key in ("noise", "y", "z", "x"):
+            ref = g[f"{tag}_grad_{key}"]
+            np.testing.assert_allclose(gr[key], ref, rtol=0, atol=1e-7 * max(1.0, float(np.max(np.abs(ref)))))
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
