@@ -12,6 +12,7 @@
 #   posterior(VFE(fz), fx, y) → data.{m_ε, Λ_ε.U, U, α, b_y}, elbo, approx_log_evidence(DTC)
 #                                                        src/sparse_approximations.jl:58-75, 248-254, 282-286
 #   update_posterior (new observations / new pseudo-points)   src/sparse_approximations.jl:87-176
+#   central differences of elbo along (variance, transform parameters, noise, pseudo-inputs): the pin of the accelerated path's ELBO gradient
 # and writes tests/golden/julia/<case>.gpb.  tests/test_julia_golden.py compares the CPU oracle (-m "not gpu") and the HIP
 # path (-m gpu) with those files when they are present and skips LOUDLY when they are not: Julia is not installed in the image
 # this repository is built in, so a maintainer with Julia runs this once and commits tests/golden/julia/*.gpb.
@@ -132,6 +133,26 @@ function run_case(inp)
     push!(out, "vfe_mean" => vm)
     push!(out, "vfe_var" => vv)
     push!(out, "vfe_cov" => cov(ap, xs))
+
+    # --- derivatives of the ELBO along four directions by central differences of the reference's own `elbo` (t = ±1e-4): variance·(1 + t), every transform
+    #     parameter·(1 + t), every noise variance·(1 + t), z + t·D with D_ij = sin(i + 3j) — what the accelerated path's gp_vfe_grad returns analytically,
+    #     contracted with the same directions (examples/0-intro-1d/script.jl:385-394 differentiates this expression)
+    function elbo_at(variance, scale, s2t, Zt)
+        kt = build_kernel(kind, variance, scale)
+        ft = isnan(inp["mean"]) ? GP(kt) : GP(inp["mean"], kt)
+        return elbo(VFE(ft(points(Zt), jitter)), ft(x, noise(s2t, 1:n)), y)
+    end
+    t = 1e-4
+    function central(g)
+        return (g(t) - g(-t)) / (2t)
+    end
+    D = ndims(Z) == 1 ? [sin(i + 3.0) for i in 1:m] : [sin(i + 3.0 * j) for i in 1:m, j in 1:size(Z, 2)]
+    sc = inp["scale"]
+    has_scale = !(sc isa Number && isnan(sc))
+    push!(out, "elbo_dir" => [central(u -> elbo_at(inp["variance"] * (1 + u), sc, s2, Z)),
+                              has_scale ? central(u -> elbo_at(inp["variance"], sc .* (1 + u), s2, Z)) : 0.0,
+                              central(u -> elbo_at(inp["variance"], sc, s2 .* (1 + u), Z)),
+                              central(u -> elbo_at(inp["variance"], sc, s2, Z .+ u .* D))])
 
     # --- update_posterior: new observations on the same pseudo-points (src/sparse_approximations.jl:87-121)
     a1 = posterior(VFE(fz), f(points(rows(X, 1:n1)), noise(s2, 1:n1)), y[1:n1])

@@ -35,6 +35,7 @@ TOL_ORACLE = {
     "elbo": ("rel", 1e-9), "dtc": ("rel", 1e-9), "vfe_alpha": ("relnorm", 1e-6), "vfe_m_eps": ("relnorm", 1e-7),
     "vfe_Lam_U": ("abs", 1e-7), "vfe_U": ("abs", 1e-9), "vfe_b_y": ("abs", 1e-12),
     "vfe_mean": ("abs", 1e-8), "vfe_var": ("abs", 1e-8), "vfe_cov": ("abs", 1e-8),
+    "elbo_dir": ("relnorm", 1e-4),   # the reference side of this field is a central difference (t = 1e-4) of its own elbo
     "upd_obs_alpha": ("relnorm", 1e-5), "upd_obs_m_eps": ("relnorm", 1e-6), "upd_obs_mean": ("abs", 1e-7), "upd_obs_var": ("abs", 1e-7),
     "upd_z_alpha": ("relnorm", 1e-4), "upd_z_m_eps": ("relnorm", 1e-5), "upd_z_mean": ("abs", 1e-6), "upd_z_var": ("abs", 1e-6),
 }
@@ -64,6 +65,18 @@ def _nan_fields(m: int, ns: int) -> dict:
             "upd_z_var": np.full(ns, np.nan)}
 
 
+def _elbo_dir(g, var, scale, s2, z) -> np.ndarray:
+    """The analytic ELBO gradient contracted with the generator's four directions: variance·(1 + t), transform parameters·(1 + t), noise·(1 + t),
+    z + t·D with D_ij = sin(i + 3j) (1-based, as make_golden.jl builds it)."""
+    zz = np.asarray(z, dtype=np.float64)
+    m = zz.shape[0]
+    i = np.arange(1, m + 1, dtype=np.float64)
+    D = np.sin(i + 3.0) if zz.ndim == 1 else np.sin(i[:, None] + 3.0 * np.arange(1, zz.shape[1] + 1, dtype=np.float64)[None, :])
+    d_scale = 0.0 if scale is None else float(np.sum(np.asarray(g["scale"]) * np.asarray(scale)))
+    noise = g["noise_diag"] if "noise_diag" in g and np.ndim(s2) else g["noise"]
+    return np.array([g["variance"] * var, d_scale, float(np.sum(np.asarray(noise) * np.asarray(s2))), float(np.sum(np.asarray(g["z"]) * D))])
+
+
 def oracle_outputs(inp) -> dict:
     kind, var, scale, mean, s2 = _case(inp)
     f = o.GP(o.Kernel(kind, var, scale), mean)
@@ -85,6 +98,7 @@ def oracle_outputs(inp) -> dict:
     out.update(vfe_alpha=ap.alpha, vfe_m_eps=ap.m_eps, vfe_Lam_U=np.triu(ap.Lam_U), vfe_U=np.triu(ap.U), vfe_b_y=ap.b_y)
     out["vfe_mean"], out["vfe_var"] = ap.mean_and_var(xs)
     out["vfe_cov"] = ap.cov(xs)
+    out["elbo_dir"] = _elbo_dir(o.elbo_grad(f, z, jitter, fx, y), var, scale, s2, z)
     a1 = o.vfe_posterior(f, z, jitter, o.FiniteGP(f, x[:n1], _noise(s2, slice(0, n1))), y[:n1])
     a2 = o.vfe_update_obs(a1, o.FiniteGP(f, x[n1:], _noise(s2, slice(n1, n))), y[n1:])
     out.update(upd_obs_alpha=a2.alpha, upd_obs_m_eps=a2.m_eps)
@@ -128,6 +142,7 @@ def device_outputs(agp, inp) -> dict:
     out.update(vfe_alpha=d["alpha"], vfe_m_eps=d["m_eps"], vfe_Lam_U=d["Lam_U"], vfe_U=d["U"], vfe_b_y=d["b_y"])
     out["vfe_mean"], out["vfe_var"] = ap.mean_and_var(xs)
     out["vfe_cov"] = ap.cov(xs)
+    out["elbo_dir"] = _elbo_dir(ap.objective_grad(), var, scale, s2, z)
     a1 = agp.posterior(vfe, f(x[:n1], _noise(s2, slice(0, n1))), y[:n1])
     a2 = agp.update_posterior(a1, f(x[n1:], _noise(s2, slice(n1, n))), y[n1:])
     out.update(upd_obs_alpha=a2.data["alpha"], upd_obs_m_eps=a2.data["m_eps"])
