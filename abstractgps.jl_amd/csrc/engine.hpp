@@ -69,6 +69,8 @@ struct gp_ctx {
     int device = 0;
     hipStream_t sm = nullptr;  // main stream (trailing updates, assembly, solves)
     hipStream_t sp = nullptr;  // panel stream (look-ahead)
+    void* pin = nullptr;       // page-locked staging for N-long host vectors of the sparse fit (ctx_pinned); grows on demand, freed with the ctx
+    size_t pin_bytes = 0;
     hipStream_t sq = nullptr;  // third stream (high priority), created on first use (VFE: the next chunk's triangular product beside the chunk SYRK — "vfe_dual")
     bool own_sm = false;
     std::mutex mu;
@@ -191,6 +193,10 @@ struct Guard {
 
 // RAII owner of the device blocks of one call: everything still owned when it goes out of scope returns to the ctx cache
 // (every early-return / error path included); keep() hands a block over to a handle.
+// page-locked host staging of at least `bytes` (NULL above 1 GiB or when the allocation fails: the caller then stages through pageable memory); valid until the next
+// ctx_pinned call on the ctx — callers hold the ctx lock and synchronise their uploads before they return
+void* ctx_pinned(gp_ctx* c, size_t bytes);
+
 struct DevBufs {
     gp_ctx* c;
     std::vector<void*> v;

@@ -125,6 +125,7 @@ void ctx_unref(gp_ctx* c) {
     for (auto e : c->ev_phase)
         if (e) (void)hipEventDestroy(e);
     if (c->info_dev) (void)hipFree(c->info_dev);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->ticket_dev) (void)hipFree(c->ticket_dev);
     if (c->w_ws) (void)hipFree(c->w_ws);
     if (c->scal_dev) (void)hipFree(c->scal_dev);
@@ -144,6 +145,21 @@ int32_t ctx_third_stream(gp_ctx* c, hipStream_t* out) {
     }
     *out = c->sq;
     return 0;
+}
+void* ctx_pinned(gp_ctx* c, size_t bytes) {
+    if (bytes > ((size_t)1 << 30)) return nullptr;
+    if (c->pin && c->pin_bytes >= bytes) return c->pin;
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr;
+    c->pin_bytes = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&c->pin, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->pin = nullptr;
+        return nullptr;
+    }
+    c->pin_bytes = want;
+    return c->pin;
 }
 int32_t ctx_event(gp_ctx* c, hipEvent_t* out, bool timing) {
     // timing events are separate objects (created on demand, pooled)
@@ -878,16 +894,23 @@ static int32_t check_points(const gp_points* x, int argi) {
 }
 // scaled, dimension-major, zero-padded copy [d][ldx]
 template <typename T>
+static void scale_points_into(const gp_kernel* k, const gp_points* x, long ldx, T* out);
+template <typename T>
 static void scale_points(const gp_kernel* k, const gp_points* x, long ldx, std::vector<T>& out) {
+    out.resize((size_t)x->d * ldx);
+    scale_points_into<T>(k, x, ldx, out.data());
+}
+template <typename T>
+static void scale_points_into(const gp_kernel* k, const gp_points* x, long ldx, T* out) {  // out: [d][ldx], every element written (padding zero)
     const int d = x->d;
-    out.assign((size_t)d * ldx, T(0));
     for (int dd = 0; dd < d; ++dd) {
         T s = T(1);
         if (k->nscale == 1) s = (T)k->scale[0];
         else if (k->nscale > 1) s = (T)k->scale[dd];
-        T* o = out.data() + (size_t)dd * ldx;
+        T* o = out + (size_t)dd * ldx;
         const T* p = (const T*)x->data;
         const long n = x->n;
+        std::fill(o + n, o + ldx, T(0));
         if (x->layout == 1) {  // point-contiguous: stride d
             for (long i = 0; i < n; ++i) o[i] = s * p[(long)dd + i * d];
         } else {               // a vector, or dimension-contiguous: unit stride

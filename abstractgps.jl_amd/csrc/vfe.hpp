@@ -149,21 +149,30 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
     RC(ctx_scal(c, 16 + 128));
 
     // ---- host marshalling
-    std::vector<T> xs_h, znew_h;
+    std::vector<T> znew_h, host_pageable;
+    T *xs_h = nullptr, *rs_h = nullptr, *b_h = nullptr;   // the N-long host vectors: page-locked staging of the ctx when it is to be had (three 16 MB uploads from
+                                                          // pageable memory cost ≈ 10 ms at N = 2·10⁶; C5's are 1–3 MB and ride behind the prelude either way)
     double logdet_sy = prev ? prev->logdet_sy : 0, dd = prev ? prev->dd : 0, tr_kff = prev ? prev->tr_kff : 0;
-    std::vector<T> rs_h, b_h;
     // the N-long host marshalling (scaled inputs, Σy^-1/2, b_y, the scalar sums: ≈ 1 ms at N = 262 144) runs AFTER the M×M prelude has been queued — the
     // device factors K_zz and inverts L_z meanwhile
     auto marshal_x = [&]() -> int32_t {
         if (!x) return 0;
-        scale_points<T>(k, x, npad, xs_h);
-        rs_h.assign((size_t)npad, T(0));  // s_i = σ_i⁻¹
-        b_h.assign((size_t)npad, T(0));   // b_i = s_i δ_i  (b_y, :66)
+        const size_t cnt = (size_t)(d + 2) * (size_t)npad;
+        xs_h = (T*)ctx_pinned(c, sizeof(T) * cnt);
+        if (!xs_h) {
+            host_pageable.resize(cnt);
+            xs_h = host_pageable.data();
+        }
+        rs_h = xs_h + (size_t)d * npad;   // s_i = σ_i⁻¹
+        b_h = rs_h + npad;                // b_i = s_i δ_i  (b_y, :66)
+        scale_points_into<T>(k, x, npad, xs_h);
+        std::fill(rs_h + n, rs_h + npad, T(0));
+        std::fill(b_h + n, b_h + npad, T(0));
         if (noise->kind == 0) {  // Σy = σ² I: one square root, one logarithm (the general loop below spends ≈ 15 ns per observation on them: 30 ms at N = 2·10⁶)
             const double s2 = noise->s;
             if (!(s2 > 0)) return n > 0 ? 1 : 0;  // chol(Σy) fails at the first observation (reference :61 / :296)
             const double si = 1.0 / std::sqrt(s2);
-            std::fill(rs_h.begin(), rs_h.begin() + n, (T)si);
+            std::fill(rs_h, rs_h + n, (T)si);
             double acc = 0;
             if (mean) {
                 for (long i = 0; i < n; ++i) {
@@ -475,9 +484,9 @@ static int32_t vfe_fit_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, c
         //      consumers — kmat, ystats — run there; the main stream joins through their events)
         RC(marshal_x());
         if (x) {
-            HIPCHK(hipMemcpyAsync(seg->xs, xs_h.data(), sizeof(T) * xs_h.size(), hipMemcpyHostToDevice, sa));
-            HIPCHK(hipMemcpyAsync(seg->rs, rs_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, sa));
-            HIPCHK(hipMemcpyAsync(seg->b, b_h.data(), sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, sa));
+            HIPCHK(hipMemcpyAsync(seg->xs, xs_h, sizeof(T) * (size_t)d * (size_t)npad, hipMemcpyHostToDevice, sa));
+            HIPCHK(hipMemcpyAsync(seg->rs, rs_h, sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, sa));
+            HIPCHK(hipMemcpyAsync(seg->b, b_h, sizeof(T) * (size_t)npad, hipMemcpyHostToDevice, sa));
         }
         if (ev_z && x && mode == VFE_FIT && n > 0) {  // chunk 0's kmat beside the prelude (0.34 ms at C5); everything else of the helper stream waits for the prelude below
             HIPCHK(hipStreamWaitEvent(sa, ev_z, 0));
