@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void noise_grad_kernel(const T* __restrict__ C
 //       W_ij = rs_i (2 T̃_ij + b_i ν_j)            (∂L/∂K_fz = Σy⁻¹ (2 K_fz G_ψ + δ νᵀ))
 //       rowq[i] += Σ_j σ²κ_ij T̃_ij,  rowp[i] += Σ_j σ²κ_ij ν_j     (the two row sums the noise / y gradients need)
 //   One 128×128 tile per workgroup, thread = 32 rows × 2 adjacent columns as in kgrad_kernel; NP = per-dimension accumulators kept in registers
-//   (4 for D <= 4, else 16 per launch chunk p0).  Row sums by wave shuffles, column sums through LDS across the 4 waves, then atomics.
+//   (16 per launch chunk p0; the host takes this kernel for D > 16 only — vgrad_fast_kernel below serves D <= 16).  Row sums by wave shuffles, column sums through LDS across the 4 waves, then atomics.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void grad_stage_d2_rect(T (*xi)[128], T (*xj)[128], T (*xpi)[128], T (*xpj)[128], const T* __restrict__ xr, long ldxr,
