@@ -183,7 +183,7 @@ int32_t gp_ctx_destroy(gp_ctx* ctx);
  *                    carries an error of order cond(L_bb)·ε where substitution is backward stable: a handle whose factor has max |L_ii| / min |L_ii|
  *                    above 1e5 (cond(K + Σy) >= 1e10) keeps the substitution leaves                   default 2048
  *   "ldpad"          row padding in elements (multiple of 16)                             default 32
- *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks); 0 = automatic: 16 384 for M >= 2 048 pseudo-points (measured best at C5),
+ *   "vfe_chunk"      data points per streamed VFE chunk (multiple of vfe_ks); 0 = automatic: 16 384 for M > 2 048 pseudo-points (measured best at C5),
  *                    × 2 … 16 for fewer (chunk × M kept at C5's footprint), at most the batch; a handle keeps the chunk of its first fit        default 0
  *   "vfe_ks"         fp32 VFE: data points per fp32 partial product of the chunk SYRK      default 2048
  *   "vfe_overlap"    VFE: kmat / reductions / partial-sum adds on a second stream beside the chunk GEMMs   default 1
