@@ -1227,22 +1227,27 @@ static int32_t grad_impl(gp_ctx* c, const gp_kernel* k, const gp_points* x, cons
             GridMap gw = plain_map(1, 0, 0);
             gw.ktri = 2;                                                                   // W upper: k starts at the row tile
             gw.beta0 = 1;                                                                  // Ci is overwritten (its upper tiles are never read)
-            RC(launch_gemm<T>(c, s, Ci, ld, W, ld, W, ld, np, np, np, gw));                // Ci = −W Wᵀ = −C⁻¹ (lower)
+            RC(launch_gemm<T>(c, s, Ci, ld, W, ld, W, ld, np, np, np, gw));                // Ci = −W Wᵀ = −C⁻¹ (lower), read as it is
         }
-        // fold the sign: the kernels below read +C⁻¹
-        {
-            const long cnt = np * ld;
-            hipLaunchKernelGGL((convert_kernel<T, T>), convert_grid(cnt), dim3(256), 0, s, (const T*)Ci, Ci, cnt,
-                               -1.0);
-            HIPCHK(hipGetLastError());
-        }
+        // (no sign fold: the kernels below add the −C⁻¹ the product left — kernels.hpp)
         dim3 grid((unsigned)(np / 128), (unsigned)(np / 128));
         // one launch per chunk of 16 ARD scales (a single launch for scalar / no transform, whatever D is)
-        for (int p0 = 0; p0 < (post.nscale > 1 ? post.nscale : 1); p0 += 16) {
-            hipLaunchKernelGGL(kgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
-                               (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)g_v, p0);
+#define GPMI_KGRAD_FAST(ND_)                                                                                                                  \
+    hipLaunchKernelGGL((kgrad_fast_kernel<T, ND_>), grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind, (T)post.variance, \
+                       post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)g_v)
+        if (d <= 16 && (ld * (long)sizeof(T)) % 16 == 0) {  // the scratch-free form (16-byte loads of the weights)
+            if (d <= 4) GPMI_KGRAD_FAST(4);
+            else if (d <= 8) GPMI_KGRAD_FAST(8);
+            else GPMI_KGRAD_FAST(16);
             HIPCHK(hipGetLastError());
+        } else {
+            for (int p0 = 0; p0 < (post.nscale > 1 ? post.nscale : 1); p0 += 16) {
+                hipLaunchKernelGGL(kgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)Ci, ld, (const T*)post.xs, np, d, post.kind,
+                                   (T)post.variance, post.nscale, (const double*)sc_v, (const T*)post.alpha, n, (double*)g_v, p0);
+                HIPCHK(hipGetLastError());
+            }
         }
+#undef GPMI_KGRAD_FAST
         hipLaunchKernelGGL(noise_grad_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)Ci, ld,
                            (const T*)post.alpha, n, (T*)dn_v, (double*)g_v + 1);
         HIPCHK(hipGetLastError());

@@ -739,7 +739,8 @@ static inline void launch_kmat(dim3 grid, hipStream_t s, T* out, long ld, const 
 //     g[0]        ∂/∂variance           (∂C_ij = κ_ij)
 //     g[1..ns]    ∂/∂scale_p            (ScaleTransform: ns = 1, ∂r² = 2 r²/s;  ARD: ∂r² = 2 (u_ip − u_jp)²/v_p)
 //   with dκ/dr²: SE −κ/2 · Matern12 −κ/(2r) · Matern32 −(3/2)e^{−√3 r} · Matern52 −(5/6)(1+√5 r)e^{−√5 r}.
-//   x: pre-scaled inputs u = s∘x, dimension-major.  Cinv: row-major lower.  NSMAX bounds the ARD dimension.
+//   x: pre-scaled inputs u = s∘x, dimension-major.  Cinv: row-major lower, holding −C⁻¹ as the triangular product leaves it (the kernels add it: until round 6 a
+//   pass over the N×N block folded the sign first — 12.5 ms at C4, and the pass whose wrapped launch was the C4 gradient bug).  NSMAX bounds the ARD dimension.
 // ------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void kappa_and_dr2(int kind, T d2, T& kap, T& dk) {
     if (kind == 0) {
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, 
             const T d2 = d2r[rr][cc];
             T kap, dk;
             kappa_and_dr2<T>(kind, d2, kap, dk);
-            const double wgt = ((double)ai * (double)alpha[gj] - (double)Cinv[gi * ld + gj]) * (gi == gj ? 0.5 : 1.0);
+            const double wgt = ((double)ai * (double)alpha[gj] + (double)Cinv[gi * ld + gj]) * (gi == gj ? 0.5 : 1.0);   // Cinv holds −C⁻¹
             acc[0] += wgt * (double)kap;
             const double wk = wgt * (double)variance * (double)dk * 2.0;
             if (nscale == 1) {
@@ -873,6 +874,86 @@ __global__ __launch_bounds__(256) void kgrad_kernel(const T* __restrict__ Cinv, 
         } else {
             atomicAdd(g + 2 + p0 + tid - 1, v / scale[p0 + tid - 1]);  // the 1/s (1/v_p) factor of ∂r²
         }
+    }
+}
+// kgrad for D <= ND (4 / 8 / 16) without scratch memory (kgrad_kernel keeps its 64 r² values in a dynamically indexed array = 512 bytes of scratch per lane; the
+// same reorganisation as vgrad_fast_kernel: column inputs and α_j in registers, row inputs as LDS broadcasts, r² and the differences on the fly, the weights as one
+// 16-byte load per thread and row).  C2: 2.27 -> see NOTES_r6 §9.  Same sums, same g layout, Cinv = −C⁻¹.
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void kgrad_fast_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ x, long ldx, int d, int kind, T variance,
+                                                          int nscale, const double* __restrict__ scale, const T* __restrict__ alpha, long n,
+                                                          double* __restrict__ g) {
+    typedef T t2_t __attribute__((ext_vector_type(2)));
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    if (n0 > m0) return;
+    __shared__ T xi[ND][128];
+    __shared__ double red[4][1 + ND];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < ND * 128; e += 256) {
+        const int dd = e >> 7, i = e & 127;
+        xi[dd][i] = dd < d ? x[(long)dd * ldx + m0 + i] : T(0);
+    }
+    const long gj0 = n0 + 2 * lane;
+    T xj[2][ND];
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+        xj[0][dd] = dd < d ? x[(long)dd * ldx + gj0] : T(0);
+        xj[1][dd] = dd < d ? x[(long)dd * ldx + gj0 + 1] : T(0);
+    }
+    const double aj[2] = {gj0 < n ? (double)alpha[gj0] : 0.0, gj0 + 1 < n ? (double)alpha[gj0 + 1] : 0.0};
+    const int nps = nscale > 1 ? nscale : 0;
+    double acc[1 + ND];
+#pragma unroll
+    for (int p = 0; p <= ND; ++p) acc[p] = 0.0;
+    const double var = (double)variance;
+    __syncthreads();
+    for (int rr = 0; rr < 32; ++rr) {
+        const int row = w + 4 * rr;
+        const long gi = m0 + row;
+        if (gi >= n) continue;  // wave-uniform
+        const double ai = (double)alpha[gi];
+        const t2_t c2 = *reinterpret_cast<const t2_t*>(Cinv + gi * ld + gj0);
+        T xrow[ND];
+#pragma unroll
+        for (int dd = 0; dd < ND; ++dd) xrow[dd] = xi[dd][row];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const long gj = gj0 + cc;
+            if (gj > gi || gj >= n) continue;
+            T tp[ND];
+            T d2 = T(0);
+#pragma unroll
+            for (int dd = 0; dd < ND; ++dd) {
+                tp[dd] = xrow[dd] - xj[cc][dd];
+                d2 = fma(tp[dd], tp[dd], d2);
+            }
+            T kap, dk;
+            kappa_and_dr2<T>(kind, d2, kap, dk);
+            const double wgt = (ai * aj[cc] + (double)c2[cc]) * (gi == gj ? 0.5 : 1.0);
+            acc[0] += wgt * (double)kap;
+            const double wk = wgt * var * (double)dk * 2.0;
+            if (nscale == 1) acc[1] += wk * (double)d2;
+#pragma unroll
+            for (int p = 0; p < ND; ++p)
+                if (p < nps) {
+                    const double t = (double)tp[p];
+                    acc[1 + p] += wk * t * t;
+                }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p <= ND; ++p) {
+        double v = acc[p];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[w][p] = v;
+    }
+    __syncthreads();
+    const int nout = nscale == 1 ? 1 : nps;
+    if (tid <= nout) {
+        const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid == 0) atomicAdd(g, v);
+        else atomicAdd(g + 2 + tid - 1, v / scale[tid - 1]);
     }
 }
 // kgradx: ∂logpdf/∂x_ip = 2 s_p σ² Σ_j (α_i α_j − C⁻¹_ij) dκ/dr²(r²_ij) (u_ip − u_jp)   (u = s∘x; both orders of the symmetric pair
@@ -912,7 +993,7 @@ __global__ __launch_bounds__(256) void kgradx_kernel(const T* __restrict__ Cinv,
             T kap, dk;
             kappa_and_dr2<T>(kind, d2r[rr][cc], kap, dk);
             const T ci = gi >= gj ? Cinv[gi * ld + gj] : Cinv[gj * ld + gi];
-            const double wgt = ((double)ai * (double)aj[col] - (double)ci) * (double)dk;
+            const double wgt = ((double)ai * (double)aj[col] + (double)ci) * (double)dk;   // ci from −C⁻¹
 #pragma unroll
             for (int p = 0; p < DC; ++p)
                 if (p < np_) acc[p] += wgt * (double)(xpi[p][row] - xpj[p][col]);
@@ -930,7 +1011,7 @@ __global__ __launch_bounds__(256) void kgradx_kernel(const T* __restrict__ Cinv,
         }
     }
 }
-// out[i] = ½ (α_i² − Cinv_ii)   (∂logpdf/∂Σy_ii);  sum[0] += Σ_i out[i]   (one block of 256 threads per 256 rows)
+// out[i] = ½ (α_i² − C⁻¹_ii)   (∂logpdf/∂Σy_ii; Cinv holds −C⁻¹);  sum[0] += Σ_i out[i]   (one block of 256 threads per 256 rows)
 template <typename T>
 __global__ __launch_bounds__(256) void noise_grad_kernel(const T* __restrict__ Cinv, long ld, const T* __restrict__ alpha, long n,
                                                           T* __restrict__ out, double* __restrict__ sum) {
@@ -939,7 +1020,7 @@ __global__ __launch_bounds__(256) void noise_grad_kernel(const T* __restrict__ C
     double v = 0;
     if (i < n) {
         const double a = (double)alpha[i];
-        v = 0.5 * (a * a - (double)Cinv[i * ld + i]);
+        v = 0.5 * (a * a + (double)Cinv[i * ld + i]);   // Cinv holds −C⁻¹
         out[i] = (T)v;
     }
 #pragma unroll
